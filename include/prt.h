@@ -1,0 +1,191 @@
+/* prt.h - C ABI of the MI355X ray-trace hot path (libprt_hip.so).
+ *
+ * The reference (ACEfanatic02/par_raytracer) has no plugin / FFI interface: main.cpp #includes the
+ * whole renderer as one translation unit of static functions.  The seam this ABI replaces is
+ *
+ *     RenderTask(RenderJob*, DebugCounters*)                      main.cpp:267-283
+ *       "fill buffer[0 .. end_idx-start_idx) with linear RGBA float4 for the linear pixel indices
+ *        [start_idx, end_idx) of a w x h image, given an immutable camera, scene, global params
+ *        and an RNG seed"
+ *
+ * one level below Render(Camera*, Scene*, u32 w, u32 h) -> Framebuffer (main.cpp:301-358), which the
+ * host mirror (par_raytracer_amd/host/) re-implements on top of these entry points.
+ *
+ * Everything here is plain C: pointers, sizes and POD structs; no C++ or torch types.
+ * Return convention: 0 = ok, negative = error (message via prt_last_error); nothing aborts.
+ * Threading: one host thread per context at a time; one HIP device and one stream per context.
+ */
+#ifndef PRT_H_
+#define PRT_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PRT_ABI_VERSION 1
+
+/* ---- scene description: the reference's pointer graph flattened to POD arrays ---------------- */
+
+/* Material (mesh.h:15-32).  Colours are Vector4 {x,y,z,w}.  Texture slots are indices into
+ * prt_scene_desc.textures or -1; the texture path is a "next" row. */
+typedef struct prt_material {
+    float specular_intensity;      /* Ns */
+    float index_of_refraction;     /* Ni */
+    float alpha;                   /* d  */
+    float ambient_color[4];        /* Ka */
+    float diffuse_color[4];        /* Kd */
+    float specular_color[4];       /* Ks */
+    int32_t ambient_texture;
+    int32_t diffuse_texture;
+    int32_t specular_texture;
+    int32_t alpha_texture;
+    int32_t bump_texture;
+} prt_material;
+
+/* LightSource (scene.h:3-15). */
+enum { PRT_LIGHT_DIRECTIONAL = 0, PRT_LIGHT_POINT = 1 };
+typedef struct prt_light {
+    int32_t type;
+    float color[4];
+    float position[3];
+    float facing[3];
+    float falloff;
+} prt_light;
+
+/* MeshGroup (mesh.h:40-47): a contiguous run of the concatenated index buffers. */
+typedef struct prt_group {
+    uint32_t first_index;          /* offset into idx_* (multiple of 3) */
+    uint32_t index_count;          /* 3 * triangles */
+    int32_t material;              /* index into materials */
+} prt_group;
+
+/* BoundingSphere (bsphere.cpp:316-320), 24 bytes, same field order. */
+typedef struct prt_bsphere {
+    float center[3];
+    float radius;
+    uint32_t c0;
+    uint32_t c1;
+} prt_bsphere;
+
+/* Texture (mesh.h:8-13). */
+typedef struct prt_texture {
+    uint32_t size_x, size_y, channels;
+    const uint8_t * texels;
+} prt_texture;
+
+typedef struct prt_scene_desc {
+    /* Mesh (mesh.h:49-57) */
+    const float * positions;   uint32_t position_count;    /* xyz */
+    const float * normals;     uint32_t normal_count;      /* xyz */
+    const float * texcoords;   uint32_t texcoord_count;    /* uv  */
+    const float * tangents;                                /* xyz per normal, may be NULL */
+    /* MeshGroup index buffers of all groups, concatenated in group order */
+    const uint32_t * idx_positions;
+    const uint32_t * idx_texcoords;
+    const uint32_t * idx_normals;
+    uint32_t index_count;
+    const prt_group * groups;        uint32_t group_count;
+    const prt_material * materials;  uint32_t material_count;
+    const prt_texture * textures;    uint32_t texture_count;
+    /* Scene (scene.h:29-36) */
+    const prt_light * lights;        uint32_t light_count;
+    /* BoundingHierarchy (bsphere.cpp:322-326), flattened: node i <-> spheres[i]; sphere_group[i] is
+     * the group index of a leaf or -1.  The HIP path builds its own per-triangle BVH and uses this
+     * tree only to derive the reference's leaf visit order for exact-tie breaking (may be NULL);
+     * the CPU oracle traverses it exactly as the reference does. */
+    const prt_bsphere * spheres;
+    const int32_t * sphere_group;
+    uint32_t sphere_count;
+} prt_scene_desc;
+
+/* Camera (main.cpp:133-143), same field order. */
+typedef struct prt_camera {
+    float tan_a2, aspect, inv_width, inv_height;
+    float position[3];
+    float forward[3];
+    float right[3];
+    float up[3];
+} prt_camera;
+
+/* The subset of gParams (globals.h:9-22) the hot path reads, plus what the reference hard-codes:
+ * spp (main.cpp:308-309 -> min_samples = max_samples = spp) and the RNG seed (main.cpp:60-67 ->
+ * per-(pixel,sample) key, include/prt_key.h). */
+typedef struct prt_params {
+    float ray_bias;
+    uint32_t reflection_samples;
+    uint32_t spec_samples;
+    uint32_t bounce_depth;
+    float background_color[4];
+    uint32_t spp;
+    uint32_t pipeline;             /* PRT_PIPELINE_* ; 0 = library default */
+    uint64_t seed;
+} prt_params;
+
+enum { PRT_PIPELINE_DEFAULT = 0, PRT_PIPELINE_MEGAKERNEL = 1, PRT_PIPELINE_WAVEFRONT = 2 };
+
+/* DebugCounters (globals.h:3-7) re-cast for a per-triangle BVH.  ray_count has the reference's
+ * meaning (one per TraceRay call, raytracer.cpp:161) and must equal the CPU value exactly. */
+typedef struct prt_counters {
+    uint64_t ray_count;
+    uint64_t node_visits;          /* BVH nodes fetched (replaces sphere_check_count) */
+    uint64_t tri_tests;            /* triangle tests (the reference tests every triangle of a leaf group) */
+    uint64_t shaded_hits;          /* closest-hit shading events */
+    double render_ms;              /* ray generation -> resolved framebuffer, device time */
+    double trace_kernel_ms;        /* time inside the dominant (traversal) kernel(s) */
+    uint32_t trace_kernel_launches;
+    uint32_t reserved;
+} prt_counters;
+
+typedef struct prt_ctx prt_ctx;
+
+/* Lifecycle.  device_id is a HIP device ordinal. */
+prt_ctx * prt_create(int device_id);
+void prt_destroy(prt_ctx * ctx);
+const char * prt_last_error(const prt_ctx * ctx);   /* ctx may be NULL: last creation error */
+int prt_abi_version(void);
+
+/* Copies the scene to the device, builds the per-triangle BVH and the sampler tables. */
+int prt_upload_scene(prt_ctx * ctx, const prt_scene_desc * scene);
+
+/* Replaces RenderTask (main.cpp:267-283): pixels [start_idx, end_idx) of a w x h image, 16 B/pixel,
+ * row-major, w component = 1.  rgba_out is a HOST pointer of (end_idx-start_idx)*4 floats. */
+int prt_render(prt_ctx * ctx, const prt_camera * cam, const prt_params * params,
+               uint32_t width, uint32_t height, uint32_t start_idx, uint32_t end_idx,
+               float * rgba_out, prt_counters * counters);
+
+/* Same, but rgba_out is a DEVICE pointer on the context's device and the work is enqueued on
+ * `stream` (a hipStream_t, NULL = the context's own stream) without a final synchronisation of the
+ * output copy: used by the multi-GPU path, which gathers shards with RCCL afterwards.
+ * counters (may be NULL) are read back with one stream synchronisation. */
+int prt_render_device(prt_ctx * ctx, const prt_camera * cam, const prt_params * params,
+                      uint32_t width, uint32_t height, uint32_t start_idx, uint32_t end_idx,
+                      void * d_rgba_out, void * stream, prt_counters * counters);
+
+/* Interleaved scan-line-block sharding: rank r of n renders the blocks of
+ * `block_rows` rows whose block index % n == r, packed densely into d_rgba_out in ascending row
+ * order.  prt_shard_rows reports how many rows that is. */
+uint32_t prt_shard_rows(uint32_t height, uint32_t block_rows, uint32_t rank, uint32_t nranks);
+int prt_render_shard_device(prt_ctx * ctx, const prt_camera * cam, const prt_params * params,
+                            uint32_t width, uint32_t height, uint32_t block_rows, uint32_t rank,
+                            uint32_t nranks, void * d_rgba_out, void * stream, prt_counters * counters);
+
+/* Introspection for DESIGN.md / bench.py: sizes of what upload built. */
+typedef struct prt_scene_info {
+    uint32_t triangle_count;
+    uint32_t bvh_node_count;
+    uint32_t bvh_max_depth;
+    uint32_t bvh_node_bytes;       /* bytes fetched per node visit */
+    uint32_t tri_record_bytes;     /* bytes fetched per triangle test */
+    uint32_t shade_record_bytes;   /* bytes fetched per shaded hit */
+    uint64_t device_bytes;         /* total resident scene bytes */
+    double bvh_build_ms;
+} prt_scene_info;
+int prt_get_scene_info(const prt_ctx * ctx, prt_scene_info * info);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PRT_H_ */

@@ -1,0 +1,171 @@
+"""Thin Python objects over the C ABI: HostScene (reference-style host pipeline) and Renderer (prt_ctx).
+
+Mirrors the reference driver's call sequence (main.cpp:537-612) so tests read like the reference's
+own main(): load OBJ -> hierarchy -> scene -> camera -> Render -> image.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import capi
+from .capi import PrtCamera, PrtCounters, PrtParams, PrtSceneDesc, PrtSceneInfo
+
+
+class HostScene:
+    """ParseOBJ + CalculateTangents + BuildHierarchy + InitScene + object list, flattened."""
+
+    def __init__(self, directory: str, obj_name: str = "sponza.obj", light_mode: int = 0,
+                 camera_position: Sequence[float] = (0.0, 0.0, 0.0)):
+        lib = capi.host_lib()
+        cp = (C.c_float * 3)(*[float(v) for v in camera_position])
+        self._lib = lib
+        self._h = lib.prt_host_load_obj(directory.encode(), obj_name.encode(), int(light_mode), cp)
+        if not self._h:
+            raise RuntimeError("prt_host_load_obj failed: %s" % lib.prt_host_last_error().decode())
+
+    @property
+    def handle(self):
+        return self._h
+
+    @property
+    def desc(self) -> "C.POINTER(PrtSceneDesc)":
+        return self._lib.prt_host_scene_desc(self._h)
+
+    @property
+    def hierarchy_seconds(self) -> float:
+        return self._lib.prt_host_scene_hierarchy_seconds(self._h)
+
+    @property
+    def parse_seconds(self) -> float:
+        return self._lib.prt_host_scene_parse_seconds(self._h)
+
+    @property
+    def n_tris(self) -> int:
+        return self.desc.contents.index_count // 3
+
+    def arrays(self) -> dict:
+        """numpy copies of the flattened scene (for tests)."""
+        d = self.desc.contents
+        f = capi.np_from_ptr
+        out = {
+            "positions": f(d.positions, d.position_count * 3, np.float32).reshape(-1, 3),
+            "normals": f(d.normals, d.normal_count * 3, np.float32).reshape(-1, 3),
+            "texcoords": f(d.texcoords, d.texcoord_count * 2, np.float32).reshape(-1, 2),
+            "idx_positions": f(d.idx_positions, d.index_count, np.uint32),
+            "idx_texcoords": f(d.idx_texcoords, d.index_count, np.uint32),
+            "idx_normals": f(d.idx_normals, d.index_count, np.uint32),
+            "groups": np.array([(d.groups[i].first_index, d.groups[i].index_count, d.groups[i].material)
+                                for i in range(d.group_count)], dtype=np.int64).reshape(-1, 3),
+            "spheres": np.array([(tuple(d.spheres[i].center) + (d.spheres[i].radius,)) for i in range(d.sphere_count)],
+                                dtype=np.float32).reshape(-1, 4),
+            "sphere_children": np.array([(d.spheres[i].c0, d.spheres[i].c1) for i in range(d.sphere_count)],
+                                        dtype=np.uint32).reshape(-1, 2),
+            "sphere_group": f(d.sphere_group, d.sphere_count, np.int32),
+            "materials": np.array([[m.specular_intensity, m.index_of_refraction, m.alpha] + list(m.ambient_color) +
+                                   list(m.diffuse_color) + list(m.specular_color)
+                                   for m in (d.materials[i] for i in range(d.material_count))], dtype=np.float32),
+        }
+        return out
+
+    def close(self):
+        if self._h:
+            self._lib.prt_host_free_scene(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def make_camera(fov: float, width: int, height: int, position: Sequence[float], facing: Sequence[float]) -> PrtCamera:
+    cam = PrtCamera()
+    p = (C.c_float * 3)(*[float(v) for v in position])
+    f = (C.c_float * 3)(*[float(v) for v in facing])
+    capi.host_lib().prt_host_make_camera(float(fov), int(width), int(height), p, f, C.byref(cam))
+    return cam
+
+
+def default_params(spp: int, seed: int = 1234, bounce_depth: Optional[int] = None, reflection_samples: Optional[int] = None,
+                   spec_samples: Optional[int] = None, pipeline: int = 0) -> PrtParams:
+    p = PrtParams()
+    capi.host_lib().prt_host_default_params(int(spp), int(seed), C.byref(p))
+    if bounce_depth is not None:
+        p.bounce_depth = int(bounce_depth)
+    if reflection_samples is not None:
+        p.reflection_samples = int(reflection_samples)
+    if spec_samples is not None:
+        p.spec_samples = int(spec_samples)
+    p.pipeline = int(pipeline)
+    return p
+
+
+class Renderer:
+    """prt_ctx: one HIP device, one uploaded scene."""
+
+    def __init__(self, device_id: int = 0):
+        lib = capi.hip_lib()
+        self._lib = lib
+        self._ctx = lib.prt_create(int(device_id))
+        if not self._ctx:
+            raise RuntimeError("prt_create(%d) failed: %s" % (device_id, lib.prt_last_error(None).decode()))
+        self.device_id = device_id
+
+    def _check(self, rc: int, what: str):
+        if rc != 0:
+            raise RuntimeError("%s failed (%d): %s" % (what, rc, self._lib.prt_last_error(self._ctx).decode()))
+
+    def upload(self, scene) -> PrtSceneInfo:
+        desc = scene.desc if isinstance(scene, HostScene) else scene
+        self._check(self._lib.prt_upload_scene(self._ctx, desc), "prt_upload_scene")
+        return self.scene_info()
+
+    def scene_info(self) -> PrtSceneInfo:
+        info = PrtSceneInfo()
+        self._check(self._lib.prt_get_scene_info(self._ctx, C.byref(info)), "prt_get_scene_info")
+        return info
+
+    def render(self, cam: PrtCamera, params: PrtParams, width: int, height: int, start_idx: int = 0,
+               end_idx: Optional[int] = None) -> Tuple[np.ndarray, PrtCounters]:
+        if end_idx is None:
+            end_idx = width * height
+        out = np.empty((end_idx - start_idx, 4), dtype=np.float32)
+        counters = PrtCounters()
+        self._check(self._lib.prt_render(self._ctx, C.byref(cam), C.byref(params), width, height, start_idx, end_idx,
+                                         out.ctypes.data_as(C.c_void_p), C.byref(counters)), "prt_render")
+        return out, counters
+
+    def render_device(self, cam, params, width, height, start_idx, end_idx, d_ptr: int, stream: int = 0,
+                      want_counters: bool = True) -> Optional[PrtCounters]:
+        counters = PrtCounters() if want_counters else None
+        self._check(self._lib.prt_render_device(self._ctx, C.byref(cam), C.byref(params), width, height, start_idx,
+                                                end_idx, C.c_void_p(d_ptr), C.c_void_p(stream),
+                                                C.byref(counters) if want_counters else None), "prt_render_device")
+        return counters
+
+    def shard_rows(self, height: int, block_rows: int, rank: int, nranks: int) -> int:
+        return int(self._lib.prt_shard_rows(height, block_rows, rank, nranks))
+
+    def render_shard_device(self, cam, params, width, height, block_rows, rank, nranks, d_ptr: int, stream: int = 0,
+                            want_counters: bool = True) -> Optional[PrtCounters]:
+        counters = PrtCounters() if want_counters else None
+        self._check(self._lib.prt_render_shard_device(self._ctx, C.byref(cam), C.byref(params), width, height,
+                                                      block_rows, rank, nranks, C.c_void_p(d_ptr), C.c_void_p(stream),
+                                                      C.byref(counters) if want_counters else None),
+                    "prt_render_shard_device")
+        return counters
+
+    def close(self):
+        if self._ctx:
+            self._lib.prt_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
