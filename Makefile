@@ -16,7 +16,7 @@ ARCH    ?= gfx950
 HIP_SRCS  := $(PKG)/csrc/prt_api.hip
 HIP_DEPS  := $(wildcard $(PKG)/csrc/*.h) $(wildcard $(PKG)/csrc/*.hip) $(wildcard $(PKG)/csrc/*.cpp) $(ROOT)/include/prt.h $(ROOT)/include/prt_key.h
 HIP_FLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -shared -ffp-contract=off -fno-fast-math \
-             -fgpu-rdc=0 -Wall -Wno-unused-function -I$(ROOT)/include
+             -Wall -Wno-unused-function -I$(ROOT)/include
 
 HOST_SRCS := $(PKG)/host/obj_loader.cpp $(PKG)/host/sphere_tree.cpp $(PKG)/host/host_scene.cpp \
              $(PKG)/host/image_out.cpp $(PKG)/host/host_capi.cpp $(PKG)/host/render_host.cpp

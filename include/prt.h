@@ -124,7 +124,10 @@ typedef struct prt_params {
     uint64_t seed;
 } prt_params;
 
-enum { PRT_PIPELINE_DEFAULT = 0, PRT_PIPELINE_MEGAKERNEL = 1, PRT_PIPELINE_WAVEFRONT = 2 };
+enum { PRT_PIPELINE_DEFAULT = 0, PRT_PIPELINE_MEGAKERNEL = 1, PRT_PIPELINE_WAVEFRONT = 2, PRT_PIPELINE_MASK = 0xFF };
+/* OR-ed into prt_params.pipeline: also count BVH node visits and triangle tests (costs a few percent;
+ * ray_count and shaded_hits are always counted). */
+enum { PRT_FLAG_COUNT_VISITS = 0x100 };
 
 /* DebugCounters (globals.h:3-7) re-cast for a per-triangle BVH.  ray_count has the reference's
  * meaning (one per TraceRay call, raytracer.cpp:161) and must equal the CPU value exactly. */
@@ -156,21 +159,31 @@ int prt_render(prt_ctx * ctx, const prt_camera * cam, const prt_params * params,
                uint32_t width, uint32_t height, uint32_t start_idx, uint32_t end_idx,
                float * rgba_out, prt_counters * counters);
 
-/* Same, but rgba_out is a DEVICE pointer on the context's device and the work is enqueued on
- * `stream` (a hipStream_t, NULL = the context's own stream) without a final synchronisation of the
- * output copy: used by the multi-GPU path, which gathers shards with RCCL afterwards.
- * counters (may be NULL) are read back with one stream synchronisation. */
+/* Same, but d_rgba_out is a DEVICE pointer on the context's device (hipMalloc'ed or a torch tensor's
+ * data_ptr): used by the multi-GPU path, which gathers the shards with RCCL afterwards.  The call
+ * returns after the context's stream has drained, so the buffer may be consumed on any stream. */
 int prt_render_device(prt_ctx * ctx, const prt_camera * cam, const prt_params * params,
                       uint32_t width, uint32_t height, uint32_t start_idx, uint32_t end_idx,
-                      void * d_rgba_out, void * stream, prt_counters * counters);
+                      void * d_rgba_out, prt_counters * counters);
 
 /* Interleaved scan-line-block sharding: rank r of n renders the blocks of
  * `block_rows` rows whose block index % n == r, packed densely into d_rgba_out in ascending row
- * order.  prt_shard_rows reports how many rows that is. */
+ * order, in ONE launch.  prt_shard_rows reports how many rows that is. */
 uint32_t prt_shard_rows(uint32_t height, uint32_t block_rows, uint32_t rank, uint32_t nranks);
 int prt_render_shard_device(prt_ctx * ctx, const prt_camera * cam, const prt_params * params,
                             uint32_t width, uint32_t height, uint32_t block_rows, uint32_t rank,
-                            uint32_t nranks, void * d_rgba_out, void * stream, prt_counters * counters);
+                            uint32_t nranks, void * d_rgba_out, prt_counters * counters);
+/* Host-output variant of the same (used by the C++ driver's multi-GPU Render()). */
+int prt_render_shard(prt_ctx * ctx, const prt_camera * cam, const prt_params * params,
+                     uint32_t width, uint32_t height, uint32_t block_rows, uint32_t rank,
+                     uint32_t nranks, float * rgba_out, prt_counters * counters);
+
+/* Arbitrary pixel subset: pixel_ids are linear indices (y*width + x), rgba_out (HOST) gets n_pixels
+ * float4 in list order.  Pixels are independently seeded, so any subset reproduces the same values as
+ * the full frame; the parity tests use it to render exactly the sparse lattice a CPU fixture holds. */
+int prt_render_pixel_list(prt_ctx * ctx, const prt_camera * cam, const prt_params * params,
+                          uint32_t width, uint32_t height, const uint32_t * pixel_ids, uint32_t n_pixels,
+                          float * rgba_out, prt_counters * counters);
 
 /* Introspection for DESIGN.md / bench.py: sizes of what upload built. */
 typedef struct prt_scene_info {

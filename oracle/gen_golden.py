@@ -1,0 +1,129 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz from the compiled, unmodified reference (oracle/_ref/ref_harness).
+
+Run in the build container only (needs /root/reference):  python oracle/gen_golden.py [--only NAME ...]
+
+Each fixture is DATA: the inputs (scene name -> par_raytracer_amd.scenes generator, camera, params, seed,
+lattice) and the reference's outputs (float RGB at the lattice pixels, the three DebugCounters).  Pixels are
+independently seeded (include/prt_key.h), so any pixel subset of a frame is a valid fixture; the big
+configs are sampled on a sparse lattice to keep fixtures small.
+`kat.npz` holds per-function known-answer vectors (PRNG, Hammersley, bounce directions, Fresnel,
+ray/triangle, ray/sphere, camera rays) produced by calling the reference's own functions.
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+
+import oracle_py as orc                                  # noqa: E402
+from par_raytracer_amd import scenes                     # noqa: E402
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+# name -> dict(scene, width, height, spp, lattice, depth, light_mode, rs, ss, seed)
+FIXTURES = {
+    # BASELINE configs (C1 full frame; C2 full small frame + lattice of the 512^2 frame; C3-C5 sparse lattices)
+    "c1_sphere_plane_256": dict(scene="sphere_plane", width=256, height=256, spp=1, lattice=1),
+    "c2_cornell_128": dict(scene="cornell_box", width=128, height=128, spp=4, lattice=1),
+    "c2_cornell_512_l4": dict(scene="cornell_box", width=512, height=512, spp=4, lattice=4),
+    "c3_icosphere_1080p_l24": dict(scene="icosphere_l6", width=1920, height=1080, spp=8, lattice=24),
+    "c4_terrain1m_1080p_l40": dict(scene="terrain_1m", width=1920, height=1080, spp=8, lattice=40),
+    "c5_terrain1m_4k_l120": dict(scene="terrain_1m", width=3840, height=2160, spp=64, lattice=120, depth=8),
+    # code-path coverage: two lights, point light (inverted occlusion test), deeper trees, multi-sample bounces
+    "cornell_point_light_d5": dict(scene="cornell_box", width=48, height=48, spp=2, lattice=1, depth=5, light_mode=2, rs=2, ss=2),
+    "icosphere_l3_two_lights": dict(scene="icosphere_l3", width=64, height=48, spp=2, lattice=1, light_mode=1),
+    "terrain64_d3": dict(scene="terrain_64", width=80, height=60, spp=2, lattice=1, depth=3),
+    "terrain192_d2": dict(scene="terrain_192", width=160, height=90, spp=4, lattice=1),
+}
+
+
+def generate(name: str, cfg: dict, scene_cache: dict) -> None:
+    scene_name = cfg["scene"]
+    if scene_name not in scene_cache:
+        d = tempfile.mkdtemp(prefix="prt_golden_%s_" % scene_name)
+        s = scenes.make_scene(scene_name)
+        scenes.write_obj(s, d, "scene.obj")
+        scene_cache[scene_name] = (s, d)
+    s, d = scene_cache[scene_name]
+    seed = cfg.get("seed", 1234)
+    t0 = time.time()
+    want_dump = s.n_tris <= 100000
+    ref = orc.run_reference(d, "scene.obj", cfg["width"], cfg["height"], cfg["spp"], seed, s.camera_position,
+                            s.camera_facing, s.fov, bounce_depth=cfg.get("depth", 2),
+                            reflection_samples=cfg.get("rs", 1), spec_samples=cfg.get("ss", 1),
+                            lattice=cfg["lattice"], light_mode=cfg.get("light_mode", 0), dump_scene=want_dump,
+                            timeout=6 * 3600)
+    st = ref["stats"]
+    out = dict(
+        scene=scene_name, width=cfg["width"], height=cfg["height"], spp=cfg["spp"], lattice=cfg["lattice"],
+        bounce_depth=cfg.get("depth", 2), light_mode=cfg.get("light_mode", 0), reflection_samples=cfg.get("rs", 1),
+        spec_samples=cfg.get("ss", 1), seed=seed,
+        camera_position=np.array(s.camera_position, dtype=np.float64), camera_facing=np.array(s.camera_facing, dtype=np.float64),
+        fov=float(s.fov),
+        rgb=ref["pixels"][:, :, :3].copy(),
+        ray_count=np.uint64(st["ray_count"]), sphere_check_count=np.uint64(st["sphere_check_count"]),
+        mesh_check_count=np.uint64(st["mesh_check_count"]), triangles=st["triangles"], groups=st["groups"],
+        reference_render_seconds=st["render_seconds"], reference_hierarchy_seconds=st["hierarchy_seconds"],
+    )
+    assert np.all(ref["pixels"][:, :, 3] == 1.0)
+    if want_dump:
+        sc = ref["scene"]
+        out["spheres"] = np.frombuffer(sc["spheres"], dtype=np.float32).reshape(-1, 4).copy()
+        out["sphere_children"] = np.frombuffer(sc["sphere_children"], dtype=np.uint32).reshape(-1, 2).copy()
+        out["sphere_group"] = np.frombuffer(sc["sphere_group"], dtype=np.int32).copy()
+        out["group_index_counts"] = np.frombuffer(sc["group_index_counts"], dtype=np.uint32).copy()
+        # loader check without storing the whole mesh: exact byte sums of what the reference parsed
+        for k in ("positions", "texcoords", "normals", "idx_positions", "idx_texcoords", "idx_normals", "group_materials"):
+            a = np.frombuffer(sc[k], dtype=np.uint8)
+            out["sum_" + k] = np.array([a.size, int(a.astype(np.uint64).sum()),
+                                        int((a.astype(np.uint64) * (np.arange(a.size, dtype=np.uint64) % 251 + 1)).sum() % (1 << 62))],
+                                       dtype=np.uint64)
+    os.makedirs(GOLDEN, exist_ok=True)
+    np.savez_compressed(os.path.join(GOLDEN, name + ".npz"), **out)
+    print("%-28s %7d tris  %dx%d spp %d lattice %d  rays %d  ref %.1fs  (total %.1fs)" % (
+        name, st["triangles"], cfg["width"], cfg["height"], cfg["spp"], cfg["lattice"], st["ray_count"],
+        st["render_seconds"], time.time() - t0), flush=True)
+
+
+def generate_kat(scene_cache: dict) -> None:
+    s = scenes.make_scene("sphere_plane")
+    d = tempfile.mkdtemp(prefix="prt_golden_kat_")
+    scenes.write_obj(s, d, "scene.obj")
+    ref = orc.run_reference(d, "scene.obj", 256, 256, 1, 1234, s.camera_position, s.camera_facing, s.fov,
+                            render=False, kat=True)
+    k = ref["kat"]
+    u64 = ("rng_seed", "rng_state", "rng_next", "key_1234")
+    out = {}
+    for name, raw in k.items():
+        out[name] = np.frombuffer(raw, dtype=np.uint64 if name in u64 else np.float32).copy()
+    np.savez_compressed(os.path.join(GOLDEN, "kat.npz"), **out)
+    print("kat.npz: %s" % ", ".join(sorted(out)))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", nargs="*", default=None)
+    args = ap.parse_args()
+    if not orc.have_reference():
+        raise SystemExit("oracle/_ref/ref_harness missing: run `make -C oracle ref` in the build container")
+    cache = {}
+    names = args.only if args.only else ["kat"] + list(FIXTURES)
+    for n in names:
+        if n == "kat":
+            generate_kat(cache)
+        else:
+            generate(n, FIXTURES[n], cache)
+
+
+if __name__ == "__main__":
+    main()

@@ -139,25 +139,51 @@ class Renderer:
                                          out.ctypes.data_as(C.c_void_p), C.byref(counters)), "prt_render")
         return out, counters
 
-    def render_device(self, cam, params, width, height, start_idx, end_idx, d_ptr: int, stream: int = 0,
+    def render_pixels(self, cam: PrtCamera, params: PrtParams, width: int, height: int, pixel_ids) -> Tuple[np.ndarray, PrtCounters]:
+        ids = np.ascontiguousarray(pixel_ids, dtype=np.uint32).reshape(-1)
+        out = np.empty((ids.size, 4), dtype=np.float32)
+        counters = PrtCounters()
+        self._check(self._lib.prt_render_pixel_list(self._ctx, C.byref(cam), C.byref(params), width, height,
+                                                    ids.ctypes.data_as(C.c_void_p), ids.size,
+                                                    out.ctypes.data_as(C.c_void_p), C.byref(counters)), "prt_render_pixel_list")
+        return out, counters
+
+    def render_lattice(self, cam, params, width: int, height: int, lattice: int) -> Tuple[np.ndarray, PrtCounters]:
+        """Pixels (x % lattice == 0, y % lattice == 0), returned as [lh, lw, 4] like the oracle's lattice output."""
+        xs = np.arange(0, width, lattice, dtype=np.uint32)
+        ys = np.arange(0, height, lattice, dtype=np.uint32)
+        ids = (ys[:, None] * np.uint32(width) + xs[None, :]).reshape(-1)
+        out, ctr = self.render_pixels(cam, params, width, height, ids)
+        return out.reshape(len(ys), len(xs), 4), ctr
+
+    def render_device(self, cam, params, width, height, start_idx, end_idx, d_ptr: int,
                       want_counters: bool = True) -> Optional[PrtCounters]:
         counters = PrtCounters() if want_counters else None
         self._check(self._lib.prt_render_device(self._ctx, C.byref(cam), C.byref(params), width, height, start_idx,
-                                                end_idx, C.c_void_p(d_ptr), C.c_void_p(stream),
+                                                end_idx, C.c_void_p(d_ptr),
                                                 C.byref(counters) if want_counters else None), "prt_render_device")
         return counters
 
     def shard_rows(self, height: int, block_rows: int, rank: int, nranks: int) -> int:
         return int(self._lib.prt_shard_rows(height, block_rows, rank, nranks))
 
-    def render_shard_device(self, cam, params, width, height, block_rows, rank, nranks, d_ptr: int, stream: int = 0,
+    def render_shard_device(self, cam, params, width, height, block_rows, rank, nranks, d_ptr: int,
                             want_counters: bool = True) -> Optional[PrtCounters]:
         counters = PrtCounters() if want_counters else None
         self._check(self._lib.prt_render_shard_device(self._ctx, C.byref(cam), C.byref(params), width, height,
-                                                      block_rows, rank, nranks, C.c_void_p(d_ptr), C.c_void_p(stream),
+                                                      block_rows, rank, nranks, C.c_void_p(d_ptr),
                                                       C.byref(counters) if want_counters else None),
                     "prt_render_shard_device")
         return counters
+
+    def render_shard(self, cam, params, width, height, block_rows, rank, nranks) -> Tuple[np.ndarray, PrtCounters]:
+        rows = self.shard_rows(height, block_rows, rank, nranks)
+        out = np.empty((rows, width, 4), dtype=np.float32)
+        counters = PrtCounters()
+        self._check(self._lib.prt_render_shard(self._ctx, C.byref(cam), C.byref(params), width, height, block_rows,
+                                               rank, nranks, out.ctypes.data_as(C.c_void_p), C.byref(counters)),
+                    "prt_render_shard")
+        return out, counters
 
     def close(self):
         if self._ctx:

@@ -1,0 +1,256 @@
+// bvh_build.cpp - binned surface-area-heuristic BVH2 builder (host, multi-threaded over subtrees).
+#include "bvh_build.h"
+
+#include <algorithm>
+#include <atomic>
+#include <cfloat>
+#include <cmath>
+#include <cstring>
+#include <thread>
+
+namespace prt {
+namespace {
+
+struct Box {
+    float lo[3], hi[3];
+    void reset() { for (int a = 0; a < 3; ++a) { lo[a] = FLT_MAX; hi[a] = -FLT_MAX; } }
+    void grow(const Box & b) { for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], b.lo[a]); hi[a] = std::max(hi[a], b.hi[a]); } }
+    void grow(const float * p) { for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], p[a]); hi[a] = std::max(hi[a], p[a]); } }
+    float half_area() const {
+        float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+        if (dx < 0.0f) return 0.0f;
+        return dx * dy + dy * dz + dz * dx;
+    }
+};
+
+struct Prim {
+    Box box;
+    float c[3];
+    uint32_t id;
+};
+
+struct TmpNode {
+    Box box;
+    int32_t left, right;        // TmpNode indices, -1 for a leaf
+    uint32_t first, count;      // primitive range (leaf)
+    uint32_t depth;
+};
+
+enum { BINS = 16, MAX_FORCED_DEPTH = 56 };
+
+struct Builder {
+    std::vector<Prim> prims;
+    std::vector<TmpNode> pool;
+    std::atomic<uint32_t> next_node;
+    std::atomic<uint32_t> max_depth;
+    std::atomic<int> threads_free;
+    uint32_t leaf_max;
+
+    uint32_t alloc() { return next_node.fetch_add(1); }
+
+    // Builds the subtree over prims[first, first+count) into node `me`.
+    void build(uint32_t me, uint32_t first, uint32_t count, uint32_t depth) {
+        TmpNode & n = pool[me];
+        n.depth = depth;
+        Box bounds, cbounds;
+        bounds.reset();
+        cbounds.reset();
+        for (uint32_t i = first; i < first + count; ++i) {
+            bounds.grow(prims[i].box);
+            cbounds.grow(prims[i].c);
+        }
+        n.box = bounds;
+        n.left = n.right = -1;
+        n.first = first;
+        n.count = count;
+
+        auto make_leaf = [&]() {
+            uint32_t d = max_depth.load();
+            while (depth > d && !max_depth.compare_exchange_weak(d, depth)) {}
+        };
+        if (count == 1) { make_leaf(); return; }
+
+        // --- binned SAH over the three axes
+        int best_axis = -1, best_split = -1;
+        float best_cost = FLT_MAX;
+        float parent_area = bounds.half_area();
+        if (depth < MAX_FORCED_DEPTH) {
+            for (int axis = 0; axis < 3; ++axis) {
+                float cmin = cbounds.lo[axis], cmax = cbounds.hi[axis];
+                if (!(cmax > cmin)) continue;
+                float scale = (float)BINS / (cmax - cmin);
+                Box bin_box[BINS];
+                uint32_t bin_n[BINS];
+                for (int b = 0; b < BINS; ++b) { bin_box[b].reset(); bin_n[b] = 0; }
+                for (uint32_t i = first; i < first + count; ++i) {
+                    int b = (int)((prims[i].c[axis] - cmin) * scale);
+                    b = b < 0 ? 0 : (b >= BINS ? BINS - 1 : b);
+                    bin_box[b].grow(prims[i].box);
+                    bin_n[b]++;
+                }
+                float right_area[BINS];
+                uint32_t right_n[BINS];
+                Box acc;
+                acc.reset();
+                uint32_t cnt = 0;
+                for (int b = BINS - 1; b > 0; --b) {
+                    acc.grow(bin_box[b]);
+                    cnt += bin_n[b];
+                    right_area[b] = acc.half_area();
+                    right_n[b] = cnt;
+                }
+                acc.reset();
+                cnt = 0;
+                for (int b = 0; b < BINS - 1; ++b) {
+                    acc.grow(bin_box[b]);
+                    cnt += bin_n[b];
+                    if (cnt == 0 || right_n[b + 1] == 0) continue;
+                    float cost = acc.half_area() * (float)cnt + right_area[b + 1] * (float)right_n[b + 1];
+                    if (cost < best_cost) { best_cost = cost; best_axis = axis; best_split = b; }
+                }
+            }
+        }
+
+        // leaf if allowed and cheaper than splitting (traversal step cost 1, triangle test cost 1)
+        if (count <= leaf_max) {
+            float split_cost = (best_axis >= 0 && parent_area > 0.0f) ? 1.0f + best_cost / parent_area : FLT_MAX;
+            if ((float)count <= split_cost) { make_leaf(); return; }
+        }
+
+        uint32_t mid;
+        if (best_axis >= 0) {
+            float cmin = cbounds.lo[best_axis];
+            float scale = (float)BINS / (cbounds.hi[best_axis] - cmin);
+            Prim * b = &prims[first];
+            Prim * e = b + count;
+            Prim * m = std::partition(b, e, [&](const Prim & p) {
+                int bin = (int)((p.c[best_axis] - cmin) * scale);
+                bin = bin < 0 ? 0 : (bin >= BINS ? BINS - 1 : bin);
+                return bin <= best_split;
+            });
+            mid = first + (uint32_t)(m - b);
+        } else {
+            mid = first;
+        }
+        if (mid == first || mid == first + count) {
+            // coincident centroids (or forced depth): median split along the widest centroid axis
+            int axis = 0;
+            float ext = -1.0f;
+            for (int a = 0; a < 3; ++a) {
+                float e = cbounds.hi[a] - cbounds.lo[a];
+                if (e > ext) { ext = e; axis = a; }
+            }
+            mid = first + count / 2;
+            std::nth_element(prims.begin() + first, prims.begin() + mid, prims.begin() + first + count,
+                             [axis](const Prim & a, const Prim & b) { return a.c[axis] < b.c[axis]; });
+        }
+
+        uint32_t l = alloc(), r = alloc();
+        pool[me].left = (int32_t)l;
+        pool[me].right = (int32_t)r;
+        uint32_t lcount = mid - first, rcount = count - lcount;
+        bool spawn = lcount > 32768 && rcount > 32768 && threads_free.fetch_sub(1) > 0;
+        if (spawn) {
+            std::thread t([this, l, first, lcount, depth]() { build(l, first, lcount, depth + 1); });
+            build(r, mid, rcount, depth + 1);
+            t.join();
+            threads_free.fetch_add(1);
+        } else {
+            if (lcount > 32768 && rcount > 32768) threads_free.fetch_add(1);   // undo the failed reservation
+            build(l, first, lcount, depth + 1);
+            build(r, mid, rcount, depth + 1);
+        }
+    }
+};
+
+inline float int_bits(int32_t v) {
+    float f;
+    memcpy(&f, &v, 4);
+    return f;
+}
+
+}  // namespace
+
+void build_bvh2(const float * verts, uint32_t n_tris, uint32_t leaf_max, uint32_t threads, BvhResult * out) {
+    *out = BvhResult();
+    if (leaf_max < 1) leaf_max = 1;
+    if (leaf_max > 4) leaf_max = 4;
+    Builder b;
+    b.leaf_max = leaf_max;
+    b.prims.resize(n_tris);
+    Box scene;
+    scene.reset();
+    for (uint32_t i = 0; i < n_tris; ++i) {
+        Prim & p = b.prims[i];
+        p.box.reset();
+        p.box.grow(verts + 9 * (size_t)i);
+        p.box.grow(verts + 9 * (size_t)i + 3);
+        p.box.grow(verts + 9 * (size_t)i + 6);
+        for (int a = 0; a < 3; ++a) p.c[a] = 0.5f * p.box.lo[a] + 0.5f * p.box.hi[a];
+        p.id = i;
+        scene.grow(p.box);
+    }
+    for (int a = 0; a < 3; ++a) { out->scene_lo[a] = n_tris ? scene.lo[a] : 0.0f; out->scene_hi[a] = n_tris ? scene.hi[a] : 0.0f; }
+
+    b.pool.resize(n_tris ? 2 * (size_t)n_tris : 1);
+    b.next_node = 1;
+    b.max_depth = 0;
+    b.threads_free = (int)(threads > 1 ? threads - 1 : 0);
+    if (n_tris) b.build(0, 0, n_tris, 0);
+
+    out->tri_order.resize(n_tris);
+    for (uint32_t i = 0; i < n_tris; ++i) out->tri_order[i] = b.prims[i].id;
+    out->max_depth = b.max_depth.load() + 1;
+
+    // --- emit the device layout.  Internal nodes are numbered in DFS preorder (node 0 = root, a left child
+    // directly follows its parent).  Leaves live only as links.  The root is always an internal node: a scene
+    // of <= leaf_max triangles becomes a root whose two links name the same leaf (testing a triangle twice
+    // cannot change a closest hit: equal t and equal rank never replace), and an empty scene a root over one
+    // all-zero dummy triangle, which the test always rejects (d = 0).
+    auto leaf_link = [&](const TmpNode & n) -> int32_t { return ~(int32_t)((n.first << 2) | (n.count - 1)); };
+    auto emit = [&](uint32_t slot, const Box & b0, int32_t l0, const Box & b1, int32_t l1) {
+        float * n = &out->nodes[16 * (size_t)slot];
+        n[0] = b0.lo[0]; n[1] = b0.hi[0]; n[2] = b0.lo[1]; n[3] = b0.hi[1];
+        n[4] = b1.lo[0]; n[5] = b1.hi[0]; n[6] = b1.lo[1]; n[7] = b1.hi[1];
+        n[8] = b0.lo[2]; n[9] = b0.hi[2]; n[10] = b1.lo[2]; n[11] = b1.hi[2];
+        n[12] = int_bits(l0); n[13] = int_bits(l1); n[14] = 0.0f; n[15] = 0.0f;
+    };
+
+    if (n_tris == 0 || b.pool[0].left < 0) {
+        out->nodes.assign(16, 0.0f);
+        out->node_count = 1;
+        Box zero = { { 0, 0, 0 }, { 0, 0, 0 } };
+        if (n_tris == 0) emit(0, zero, ~0, zero, ~0);
+        else emit(0, b.pool[0].box, leaf_link(b.pool[0]), b.pool[0].box, leaf_link(b.pool[0]));
+        out->max_depth = 1;
+        return;
+    }
+
+    // count internal nodes, assign preorder slots
+    std::vector<int32_t> slot_of(b.next_node.load(), -1);
+    std::vector<uint32_t> stack;
+    uint32_t n_internal = 0;
+    stack.push_back(0);
+    while (!stack.empty()) {
+        uint32_t t = stack.back();
+        stack.pop_back();
+        const TmpNode & n = b.pool[t];
+        if (n.left < 0) continue;
+        slot_of[t] = (int32_t)n_internal++;
+        stack.push_back((uint32_t)n.right);
+        stack.push_back((uint32_t)n.left);
+    }
+    out->node_count = n_internal;
+    out->nodes.assign(16 * (size_t)n_internal, 0.0f);
+    for (uint32_t t = 0; t < slot_of.size(); ++t) {
+        if (slot_of[t] < 0) continue;
+        const TmpNode & n = b.pool[t];
+        const TmpNode & l = b.pool[n.left];
+        const TmpNode & r = b.pool[n.right];
+        int32_t ll = l.left < 0 ? leaf_link(l) : slot_of[n.left];
+        int32_t rl = r.left < 0 ? leaf_link(r) : slot_of[n.right];
+        emit((uint32_t)slot_of[t], l.box, ll, r.box, rl);
+    }
+}
+
+}  // namespace prt

@@ -1,0 +1,25 @@
+// bvh_build.h - host-side per-triangle BVH2 builder for the HIP traversal kernels.
+//
+// The reference's acceleration structure is a sphere tree over whole OBJ groups with brute force inside
+// each leaf (bsphere.cpp:379-444, raytracer.cpp:136-154).  Its RESULT is the exact closest front-facing
+// hit over all triangles, so any conservative structure gives the same answer; the
+// device uses a binned-SAH binary BVH with <= 4 triangles per leaf.
+#pragma once
+
+#include <cstdint>
+#include <vector>
+
+namespace prt {
+
+struct BvhResult {
+    std::vector<float> nodes;          // 16 floats (64 B) per internal node, layout in dev_scene.h
+    std::vector<uint32_t> tri_order;   // tri_order[i] = input triangle stored at leaf-order slot i
+    uint32_t node_count = 0;
+    uint32_t max_depth = 0;            // deepest leaf; bounds the traversal stack
+    float scene_lo[3] = { 0, 0, 0 }, scene_hi[3] = { 0, 0, 0 };
+};
+
+// verts: 9 floats per triangle (a, b, c).  leaf_max <= 4 (2 bits in the leaf link).
+void build_bvh2(const float * verts, uint32_t n_tris, uint32_t leaf_max, uint32_t threads, BvhResult * out);
+
+}  // namespace prt

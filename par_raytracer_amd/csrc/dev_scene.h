@@ -1,0 +1,106 @@
+// dev_scene.h - how the scene lies in HBM, and the kernel-side view of it.
+//
+// The reference walks a pointer graph (Scene -> SceneObject -> MeshGroup -> index buffers -> positions,
+// scene.h:22-36, mesh.h:40-57).  For the device everything is flattened at upload into dense,
+// 16-byte-aligned records that one lane fetches with dwordx4 loads and no dependent indirection:
+//
+//   nodes      BVH2, 64 B per node = 4 x float4 (Aila-Laine layout): both children's boxes + both child
+//              links, so one node visit = one 64 B fetch that decides about two subtrees
+//                n0 = (c0.lo.x, c0.hi.x, c0.lo.y, c0.hi.y)   n1 = (c1.lo.x, c1.hi.x, c1.lo.y, c1.hi.y)
+//                n2 = (c0.lo.z, c0.hi.z, c1.lo.z, c1.hi.z)   n3 = (link0, link1, -, -) as int bits
+//              link >= 0: internal node index; link < 0: leaf, ~link = (first_tri << 2) | (count - 1)
+//   tris       48 B per triangle = 3 x float4, in BVH leaf order, un-indexed and pre-differenced:
+//                (a.xyz, ab.x) (ab.yz, ac.xy) (ac.z, n.xyz)   with ab = b-a, ac = c-a, n = Cross(ab, ac)
+//              computed on the host with the reference's float expressions (raytracer.cpp:85-91), so the
+//              device test consumes the same bits the CPU test would compute per call
+//   shade      64 B per triangle = 4 x float4, same order: the three vertex normals, the three texcoords
+//              and the material index - fetched once per shaded hit, not per test
+//   tri_rank   u32 per triangle: position in the reference's own visit order (sphere tree DFS with c1
+//              first, then ascending index inside a group; raytracer.cpp:136, 208-209).  Only read when
+//              two hits have bit-equal t, to keep the reference's "first hit wins" (strict <, :149, :220)
+//   materials  64 B each; lights 48 B each; diffuse_dirs 1024 x float4 (the Hammersley set of
+//              raytracer.cpp:519-521 pushed through cosf/sinf/sqrtf on the HOST, so no device
+//              transcendental ever feeds a direction); spec_dirs [material][spec_samples] likewise.
+#pragma once
+
+#include "dev_math.h"
+
+namespace prt {
+
+struct DevMaterial {          // 64 B
+    float ambient[3];
+    float specular_intensity;
+    float diffuse[3];
+    float index_of_refraction;
+    float specular[3];
+    float alpha;
+    int flags;
+    int pad[3];
+};
+
+struct DevLight {             // 48 B
+    float color[3];
+    int type;
+    float position[3];
+    float falloff;
+    float facing[3];
+    float pad;
+};
+
+struct DevScene {
+    const float4 * nodes;
+    const float4 * tris;
+    const float4 * shade;
+    const unsigned int * tri_rank;
+    const DevMaterial * materials;
+    const DevLight * lights;
+    const float4 * diffuse_dirs;
+    const float4 * spec_dirs;
+    unsigned int light_count;
+    unsigned int spec_samples;
+    unsigned int tri_count;
+    unsigned int node_count;
+};
+
+struct DevCamera {            // Camera (main.cpp:133-143) with the loop invariants of MakeCameraRay hoisted
+    f3 position;
+    f3 forward;
+    f3 right_scaled;          // (camera_right * tan_a2) * aspect    main.cpp:170
+    f3 up_scaled;             // camera_up * tan_a2                  main.cpp:171
+    float inv_width, inv_height;
+};
+
+struct DevParams {
+    float ray_bias;
+    unsigned int reflection_samples, spec_samples, bounce_depth;
+    f3 background;
+    unsigned int spp;
+    unsigned long long seed;
+    unsigned int width, height;
+    float box_pad;            // outward padding of every BVH box, world units (dev_trace.h)
+    // which pixels this launch renders: local pixel lp (0 .. n_pixels) -> linear image pixel.
+    //   shard_nranks == 1: first_pixel + lp                       (RenderTask's [start_idx, end_idx), main.cpp:273)
+    //   otherwise: row-blocks of shard_block_rows rows, block b of this rank = image block b*nranks + rank
+    unsigned int first_pixel, shard_block_rows, shard_rank, shard_nranks;
+    const unsigned int * pixel_list;   // explicit pixel ids (prt_render_pixel_list) or NULL
+};
+
+PRT_HD unsigned int pixel_of_local(const DevParams & P, unsigned int lp) {
+    if (P.pixel_list) return P.pixel_list[lp];
+    if (P.shard_nranks <= 1) return P.first_pixel + lp;
+    const unsigned int row = lp / P.width, x = lp - row * P.width;
+    const unsigned int blk = row / P.shard_block_rows, r = row - blk * P.shard_block_rows;
+    const unsigned int y = (blk * P.shard_nranks + P.shard_rank) * P.shard_block_rows + r;
+    return y * P.width + x;
+}
+
+struct DevCounters {          // device-side accumulators (atomics, one add per wave)
+    unsigned long long ray_count;
+    unsigned long long node_visits;
+    unsigned long long tri_tests;
+    unsigned long long shaded_hits;
+};
+
+enum { BVH_LEAF_MAX = 4 };
+
+}  // namespace prt

@@ -1,0 +1,169 @@
+// dev_trace.h - TraceRay for the device: BVH2 traversal + the reference's triangle test.
+//
+// Replaces TraceRay / IntersectRaySphere / IntersectRayMesh / IntersectRayTriangle
+// (raytracer.cpp:32-60, 82-232).  What must be preserved is the RESULT of the reference's traversal:
+// the closest hit over all front-facing triangles under ITS float arithmetic, first-visited wins on
+// equal t.  So
+//   * the triangle test is the reference's, operation for operation (no FMA: -ffp-contract=off), on
+//     host-precomputed ab / ac / n which are the same bits the CPU computes per call;
+//   * the culling structure only has to be conservative: every BVH box is widened by `pad` (world units,
+//     2^-16 of the scene + camera extent, >= 100x the rounding of the slab arithmetic and of the triangle
+//     test's acceptance region) by shifting the ray origin per plane side, so a slab test with plain
+//     float rounding can never cull a triangle the reference would accept;
+//   * ties in t are broken by the triangle's rank in the reference's visit order.
+// The early reject `t > best*d` (raytracer.cpp:104) is kept in the same form; like in the reference it
+// can differ by an ulp from the final `t*ood < best` test for two nearly coincident hits, the one place
+// where visit order is observable (SURVEY.md §7.2 "Tie-breaking").
+//
+// Traversal stack: per-lane column of a workgroup LDS array (entry e of lane l at stack[e*BLOCK + l],
+// so a wave's push/pop of one level is one conflict-free ds_write/ds_read_b32).
+#pragma once
+
+#include "dev_scene.h"
+
+namespace prt {
+
+struct HitRec {
+    float t;        // distance along the (biased-origin) ray; FLT_MAX when nothing was hit
+    float v, w;     // bw.y, bw.z (raytracer.cpp:118-119)
+    int tri;        // leaf-order triangle index, -1 = miss
+};
+
+enum { TRACE_CLOSEST = 0, TRACE_ANY = 1 };
+
+struct TraceStats {
+    unsigned int nodes, tris;
+};
+
+PRT_D float as_f(int v) { return __int_as_float(v); }
+PRT_D int as_i(float v) { return __float_as_int(v); }
+
+// Reference triangle test on pre-differenced data.  Returns true and updates (best_t, v, w) when the
+// reference's IntersectRayTriangle would return true AND IntersectRayMesh would keep it (strict <).
+// `equal_t` reports a bit-equal t so the caller can consult the visit rank.
+PRT_D bool tri_test(f3 o, f3 d, f3 qp, f3 a, f3 ab, f3 ac, f3 n, float best_t, float & out_t, float & out_v, float & out_w,
+                    bool & equal_t) {
+    equal_t = false;
+    float dd = dot3(qp, n);
+    if (dd <= 0.0f) return false;
+    f3 ap = o - a;
+    float t = dot3(ap, n);
+    if (t < 0.0f) return false;
+    if (t > best_t * dd) return false;
+    f3 e = cross3(qp, ap);
+    float v = dot3(ac, e);
+    if (v < 0.0f || v > dd) return false;
+    float w = -dot3(ab, e);
+    if (w < 0.0f || (v + w) > dd) return false;
+    float ood = 1.0f / dd;
+    float th = t * ood;
+    if (th < best_t) {
+        out_t = th;
+        out_v = v * ood;
+        out_w = w * ood;
+        return true;
+    }
+    equal_t = (th == best_t);
+    if (equal_t) {
+        out_t = th;
+        out_v = v * ood;
+        out_w = w * ood;
+    }
+    return false;
+}
+
+// o: ray origin ALREADY biased by direction * ray_bias (raytracer.cpp:163).  stack: this lane's LDS column.
+template <int BLOCK, bool COUNT>
+PRT_D HitRec trace_ray(const DevScene & sc, f3 o, f3 d, int kind, float pad, int * stack, TraceStats & st) {
+    const f3 qp = o - (o + d);                       // raytracer.cpp:88-89, not bitwise -d
+    // slab setup: direction components are clamped away from 0 so no inf/NaN enters the box test
+    const float tiny = 1e-30f;
+    float dx = fabsf(d.x) < tiny ? (d.x < 0.0f ? -tiny : tiny) : d.x;
+    float dy = fabsf(d.y) < tiny ? (d.y < 0.0f ? -tiny : tiny) : d.y;
+    float dz = fabsf(d.z) < tiny ? (d.z < 0.0f ? -tiny : tiny) : d.z;
+    const float ix = 1.0f / dx, iy = 1.0f / dy, iz = 1.0f / dz;
+    // widened boxes: lo plane seen from o + pad, hi plane from o - pad
+    const float olx = o.x + pad, oly = o.y + pad, olz = o.z + pad;
+    const float ohx = o.x - pad, ohy = o.y - pad, ohz = o.z - pad;
+
+    HitRec best;
+    best.t = 3.402823466e+38f;
+    best.v = best.w = 0.0f;
+    best.tri = -1;
+    unsigned int best_rank = 0xFFFFFFFFu;
+
+    int sp = 0;
+    int node = 0;
+    for (;;) {
+        if (node >= 0) {
+            const float4 * np = sc.nodes + 4 * (size_t)node;
+            const float4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
+            if (COUNT) st.nodes++;
+            // child 0
+            float ax = (n0.x - olx) * ix, bx = (n0.y - ohx) * ix;
+            float ay = (n0.z - oly) * iy, by = (n0.w - ohy) * iy;
+            float az = (n2.x - olz) * iz, bz = (n2.y - ohz) * iz;
+            float tmin0 = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
+            float tmax0 = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), best.t));
+            // child 1
+            float cx = (n1.x - olx) * ix, ex = (n1.y - ohx) * ix;
+            float cy = (n1.z - oly) * iy, ey = (n1.w - ohy) * iy;
+            float cz = (n2.z - olz) * iz, ez = (n2.w - ohz) * iz;
+            float tmin1 = fmaxf(fmaxf(fminf(cx, ex), fminf(cy, ey)), fmaxf(fminf(cz, ez), 0.0f));
+            float tmax1 = fminf(fminf(fmaxf(cx, ex), fmaxf(cy, ey)), fminf(fmaxf(cz, ez), best.t));
+            const bool h0 = tmin0 <= tmax0, h1 = tmin1 <= tmax1;
+            int l0 = as_i(n3.x), l1 = as_i(n3.y);
+            if (h0 && h1) {
+                if (tmin1 < tmin0) { int tmp = l0; l0 = l1; l1 = tmp; }
+                stack[sp * BLOCK] = l1;
+                sp++;
+                node = l0;
+            } else if (h0) {
+                node = l0;
+            } else if (h1) {
+                node = l1;
+            } else {
+                if (sp == 0) break;
+                sp--;
+                node = stack[sp * BLOCK];
+            }
+        } else {
+            const unsigned int leaf = (unsigned int)~node;
+            const unsigned int first = leaf >> 2, count = (leaf & 3u) + 1u;
+            bool done = false;
+            for (unsigned int i = 0; i < count; ++i) {
+                const unsigned int ti = first + i;
+                const float4 * tp = sc.tris + 3 * (size_t)ti;
+                const float4 r0 = tp[0], r1 = tp[1], r2 = tp[2];
+                if (COUNT) st.tris++;
+                float t, v, w;
+                bool eq;
+                bool hit = tri_test(o, d, qp, mk3(r0.x, r0.y, r0.z), mk3(r0.w, r1.x, r1.y), mk3(r1.z, r1.w, r2.x),
+                                    mk3(r2.y, r2.z, r2.w), best.t, t, v, w, eq);
+                if (eq && best.tri >= 0 && (int)ti != best.tri) {
+                    // bit-equal t: the reference keeps whichever it visited first
+                    unsigned int rk = sc.tri_rank[ti];
+                    if (best_rank == 0xFFFFFFFFu) best_rank = sc.tri_rank[best.tri];
+                    hit = rk < best_rank;
+                    if (hit) best_rank = rk;
+                } else if (hit) {
+                    best_rank = 0xFFFFFFFFu;
+                }
+                if (hit) {
+                    best.t = t;
+                    best.v = v;
+                    best.w = w;
+                    best.tri = (int)ti;
+                    if (kind == TRACE_ANY) { done = true; break; }
+                }
+            }
+            if (done) break;
+            if (sp == 0) break;
+            sp--;
+            node = stack[sp * BLOCK];
+        }
+    }
+    return best;
+}
+
+}  // namespace prt

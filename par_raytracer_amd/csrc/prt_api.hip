@@ -1,0 +1,584 @@
+// prt_api.hip - implementation of the C ABI in include/prt.h: context, scene upload, render dispatch.
+//
+// One prt_ctx = one HIP device + one stream + one resident scene.  Upload flattens the scene into the
+// records of dev_scene.h and builds the per-triangle BVH on the host (bvh_build.cpp).  Render launches
+// the selected pipeline on the context's stream; nothing in the render path allocates when the
+// workspace from a previous call is large enough.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/prt.h"
+#include "bvh_build.h"
+#include "dev_scene.h"
+#include "kernels_mega.h"
+
+using namespace prt;
+
+namespace {
+
+std::string g_create_error;
+
+#define HIP_TRY(ctx, call)                                                                                   \
+    do {                                                                                                     \
+        hipError_t e_ = (call);                                                                              \
+        if (e_ != hipSuccess) {                                                                              \
+            (ctx)->error = std::string(#call) + ": " + hipGetErrorString(e_);                                \
+            return -10;                                                                                      \
+        }                                                                                                    \
+    } while (0)
+
+template <typename T>
+struct DevBuf {
+    T * p = nullptr;
+    size_t n = 0;
+    hipError_t ensure(size_t count) {
+        if (count <= n && p) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+        hipError_t e = hipMalloc((void **)&p, std::max<size_t>(count, 1) * sizeof(T));
+        if (e == hipSuccess) n = count;
+        return e;
+    }
+    hipError_t upload(const std::vector<T> & v) {
+        hipError_t e = ensure(v.size());
+        if (e != hipSuccess || v.empty()) return e;
+        return hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+    size_t bytes() const { return n * sizeof(T); }
+};
+
+}  // namespace
+
+struct prt_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[4] = { nullptr, nullptr, nullptr, nullptr };
+    std::string error;
+    bool has_scene = false;
+
+    DevBuf<float4> nodes, tris, shade, diffuse_dirs, spec_dirs;
+    DevBuf<unsigned int> tri_rank;
+    DevBuf<DevMaterial> materials;
+    DevBuf<DevLight> lights;
+    DevScene scene;
+    prt_scene_info info;
+    float scene_abs_max = 0.0f;
+    bool any_translucent = false;
+    std::vector<float> material_ns;      // for rebuilding spec_dirs when spec_samples changes
+    unsigned int spec_table_samples = 0;
+
+    // render workspace
+    DevBuf<float4> sample_rgb;
+    DevBuf<float4> frame_out;
+    DevBuf<DevCounters> counters;
+    DevBuf<unsigned long long> ring_ws;
+    DevBuf<unsigned int> pixel_list;
+};
+
+namespace {
+
+f3 ld3(const float * p) { return mk3(p[0], p[1], p[2]); }
+
+// raytracer.cpp:273-288 on the host.
+float radical_inverse_vdc(uint32_t bits) {
+    bits = (bits << 16u) | (bits >> 16u);
+    bits = ((bits & 0x55555555u) << 1u) | ((bits & 0xAAAAAAAAu) >> 1u);
+    bits = ((bits & 0x33333333u) << 2u) | ((bits & 0xCCCCCCCCu) >> 2u);
+    bits = ((bits & 0x0F0F0F0Fu) << 4u) | ((bits & 0xF0F0F0F0u) >> 4u);
+    bits = ((bits & 0x00FF00FFu) << 8u) | ((bits & 0xFF00FF00u) >> 8u);
+    return (float)(bits * 2.3283064365386963e-10);
+}
+
+const float kPi32 = 3.1415927f;
+
+// Tangent-space direction of GetDiffuseReflectionRay for Xi = Hammersley(i, 1024) (raytracer.cpp:322-328).
+// Host libm: the same cosf / sinf the reference's CPU path calls.
+float4 diffuse_tangent_dir(uint32_t i) {
+    float xi_x = (float)i / (float)1024u;
+    float xi_y = radical_inverse_vdc(i);
+    float phi = xi_y * 2.0f * kPi32;
+    float cp = cosf(phi);
+    float sp = sinf(phi);
+    float ct = sqrtf(1.0f - xi_x);
+    float st = sqrtf(1.0f - ct * ct);
+    return make_float4(cp * st, sp * st, ct, 0.0f);
+}
+
+// ImportanceSamplePhong(Hammersley(samp, count), e) (raytracer.cpp:290-300).
+float4 phong_tangent_dir(uint32_t samp, uint32_t count, float e) {
+    float xi_x = (float)samp / (float)count;
+    float xi_y = radical_inverse_vdc(samp);
+    float phi = 2.0f * kPi32 * xi_x;
+    float cp = cosf(phi);
+    float sp = sinf(phi);
+    float ct = powf(1.0f - xi_y, 1.0f / (e + 1.0f));
+    float st = sqrtf(1.0f - (ct * ct));
+    return make_float4(cp * st, sp * st, ct, 0.0f);
+}
+
+// Worst-case RNG draws of one sample: 2 jitter draws + the bounce tree (raytracer.cpp:416-417, 520).
+uint64_t max_rng_draws(uint32_t depth, uint32_t refl, uint32_t spec) {
+    // node(i): draws inside a surviving invocation with iters = i, child(i) = 1 roulette draw + node(i)
+    uint64_t node = 0;                                // iters = 0: no children
+    for (uint32_t i = 1; i <= depth; ++i) {
+        uint64_t child = 1 + node;
+        node = (uint64_t)refl * (1 + child) + (uint64_t)spec * child;
+        if (node > (1ull << 40)) break;
+    }
+    return 2 + node;
+}
+
+int build_spec_table(prt_ctx * ctx, unsigned int spec_samples) {
+    unsigned int n = std::max(1u, spec_samples);
+    std::vector<float4> table(ctx->material_ns.size() * (size_t)n);
+    for (size_t m = 0; m < ctx->material_ns.size(); ++m)
+        for (unsigned int s = 0; s < n; ++s) table[m * n + s] = phong_tangent_dir(s, n, ctx->material_ns[m]);
+    HIP_TRY(ctx, ctx->spec_dirs.upload(table));
+    ctx->spec_table_samples = n;
+    ctx->scene.spec_dirs = ctx->spec_dirs.p;
+    ctx->scene.spec_samples = n;
+    return 0;
+}
+
+struct PixelSet {
+    uint32_t n_pixels;
+    uint32_t first_pixel;                      // contiguous range when nranks <= 1
+    uint32_t block_rows, rank, nranks;         // interleaved row blocks otherwise
+    const unsigned int * d_pixel_list;         // explicit list (device pointer) or NULL
+};
+
+template <int MAXLEV, bool RING>
+void launch_mega(prt_ctx * ctx, bool count, unsigned int grid, size_t lds, const DevCamera & cam, const DevParams & P,
+                 unsigned int n_samples) {
+    constexpr int BLOCK = 256;
+    if (count)
+        hipLaunchKernelGGL((k_render_mega<BLOCK, MAXLEV, RING, true>), dim3(grid), dim3(BLOCK), lds, ctx->stream, ctx->scene, cam, P,
+                           n_samples, ctx->sample_rgb.p, ctx->counters.p, ctx->ring_ws.p);
+    else
+        hipLaunchKernelGGL((k_render_mega<BLOCK, MAXLEV, RING, false>), dim3(grid), dim3(BLOCK), lds, ctx->stream, ctx->scene, cam, P,
+                           n_samples, ctx->sample_rgb.p, ctx->counters.p, ctx->ring_ws.p);
+}
+
+// Renders the pixel set into d_out (device, float4 per pixel, packed in local pixel order).  Synchronous.
+int render_pixels(prt_ctx * ctx, const prt_camera * cam_in, const prt_params * params, uint32_t width, uint32_t height,
+                  const PixelSet & px, float4 * d_out, prt_counters * counters) {
+    if (!ctx->has_scene) { ctx->error = "prt_render: no scene uploaded"; return -2; }
+    if (!cam_in || !params || !width || !height) { ctx->error = "prt_render: null camera / params or empty image"; return -1; }
+    if (params->spp == 0 || params->spp > 65535) { ctx->error = "prt_render: spp must be in 1..65535 (prt_key.h packs the sample in 16 bits)"; return -1; }
+    if (params->bounce_depth > 16) { ctx->error = "prt_render: bounce_depth > 16 not supported"; return -1; }
+    if ((uint64_t)width * height >= (1ull << 32)) { ctx->error = "prt_render: image has 2^32 pixels or more"; return -1; }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t stream = ctx->stream;
+
+    if (std::max(1u, params->spec_samples) != ctx->spec_table_samples) {
+        HIP_TRY(ctx, hipStreamSynchronize(stream));
+        int rc = build_spec_table(ctx, params->spec_samples);
+        if (rc) return rc;
+    }
+
+    DevCamera cam;
+    cam.position = ld3(cam_in->position);
+    cam.forward = ld3(cam_in->forward);
+    cam.right_scaled = ld3(cam_in->right) * cam_in->tan_a2 * cam_in->aspect;      // main.cpp:170
+    cam.up_scaled = ld3(cam_in->up) * cam_in->tan_a2;                              // main.cpp:171
+    cam.inv_width = cam_in->inv_width;
+    cam.inv_height = cam_in->inv_height;
+
+    DevParams P;
+    P.ray_bias = params->ray_bias;
+    P.reflection_samples = params->reflection_samples;
+    P.spec_samples = params->spec_samples;
+    P.bounce_depth = params->bounce_depth;
+    P.background = mk3(params->background_color[0], params->background_color[1], params->background_color[2]);
+    P.spp = params->spp;
+    P.seed = params->seed;
+    P.width = width;
+    P.height = height;
+    float extent = ctx->scene_abs_max;
+    for (int a = 0; a < 3; ++a) extent = std::max(extent, fabsf(cam_in->position[a]));
+    P.box_pad = extent * (1.0f / 65536.0f);
+    P.first_pixel = px.first_pixel;
+    P.shard_block_rows = std::max(1u, px.block_rows);
+    P.shard_rank = px.rank;
+    P.shard_nranks = std::max(1u, px.nranks);
+    P.pixel_list = px.d_pixel_list;
+
+    const bool count_visits = (params->pipeline & PRT_FLAG_COUNT_VISITS) != 0;
+    const bool ring = ctx->any_translucent || max_rng_draws(P.bounce_depth, P.reflection_samples, P.spec_samples) > 15;
+    const int levels = (int)P.bounce_depth + 1;
+
+    const size_t n_samples64 = (size_t)px.n_pixels * P.spp;
+    if (n_samples64 > 0x7FFFFFFFull) { ctx->error = "prt_render: more than 2^31 samples in one call; split the pixel range"; return -1; }
+    const unsigned int n_samples = (unsigned int)n_samples64;
+    HIP_TRY(ctx, ctx->sample_rgb.ensure(n_samples64));
+    HIP_TRY(ctx, ctx->counters.ensure(1));
+    if (ring) HIP_TRY(ctx, ctx->ring_ws.ensure(n_samples64 * 16));
+
+    // LDS traversal stack: one int per BVH level per lane
+    constexpr int BLOCK = 256;
+    const unsigned int stack_entries = ctx->info.bvh_max_depth + 1;
+    const size_t lds = (size_t)stack_entries * BLOCK * sizeof(int);
+    if (lds > 64 * 1024) { ctx->error = "prt_render: BVH too deep for the LDS traversal stack"; return -3; }
+
+    HIP_TRY(ctx, hipMemsetAsync(ctx->counters.p, 0, sizeof(DevCounters), stream));
+    HIP_TRY(ctx, hipEventRecord(ctx->ev[0], stream));
+    unsigned int launches = 0;
+    if (n_samples) {
+        const unsigned int grid = (n_samples + BLOCK - 1) / BLOCK;
+        HIP_TRY(ctx, hipEventRecord(ctx->ev[2], stream));
+        if (!ring && levels <= 3) launch_mega<3, false>(ctx, count_visits, grid, lds, cam, P, n_samples);
+        else if (levels <= 9) launch_mega<9, true>(ctx, count_visits, grid, lds, cam, P, n_samples);
+        else launch_mega<17, true>(ctx, count_visits, grid, lds, cam, P, n_samples);
+        HIP_TRY(ctx, hipGetLastError());
+        HIP_TRY(ctx, hipEventRecord(ctx->ev[3], stream));
+        hipLaunchKernelGGL(k_resolve, dim3((px.n_pixels + 255) / 256), dim3(256), 0, stream, ctx->sample_rgb.p, d_out, px.n_pixels, P.spp);
+        HIP_TRY(ctx, hipGetLastError());
+        launches = 1;
+    }
+    HIP_TRY(ctx, hipEventRecord(ctx->ev[1], stream));
+    HIP_TRY(ctx, hipEventSynchronize(ctx->ev[1]));
+
+    if (counters) {
+        DevCounters h;
+        HIP_TRY(ctx, hipMemcpy(&h, ctx->counters.p, sizeof(h), hipMemcpyDeviceToHost));
+        float ms = 0.0f, trace_ms = 0.0f;
+        HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
+        if (launches) HIP_TRY(ctx, hipEventElapsedTime(&trace_ms, ctx->ev[2], ctx->ev[3]));
+        memset(counters, 0, sizeof(*counters));
+        counters->ray_count = h.ray_count;
+        counters->node_visits = h.node_visits;
+        counters->tri_tests = h.tri_tests;
+        counters->shaded_hits = h.shaded_hits;
+        counters->render_ms = ms;
+        counters->trace_kernel_ms = trace_ms;
+        counters->trace_kernel_launches = launches;
+    }
+    return 0;
+}
+
+}  // namespace
+
+// =============================================================================================================
+extern "C" {
+
+int prt_abi_version(void) { return PRT_ABI_VERSION; }
+
+const char * prt_last_error(const prt_ctx * ctx) { return ctx ? ctx->error.c_str() : g_create_error.c_str(); }
+
+prt_ctx * prt_create(int device_id) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        g_create_error = std::string("prt_create: no HIP device available (") + hipGetErrorString(e) + ")";
+        return nullptr;
+    }
+    if (device_id < 0 || device_id >= n) {
+        g_create_error = "prt_create: device ordinal out of range";
+        return nullptr;
+    }
+    if ((e = hipSetDevice(device_id)) != hipSuccess) {
+        g_create_error = std::string("prt_create: hipSetDevice: ") + hipGetErrorString(e);
+        return nullptr;
+    }
+    prt_ctx * ctx = new prt_ctx;
+    ctx->device = device_id;
+    memset(&ctx->scene, 0, sizeof(ctx->scene));
+    memset(&ctx->info, 0, sizeof(ctx->info));
+    e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    for (int i = 0; i < 4 && e == hipSuccess; ++i) e = hipEventCreate(&ctx->ev[i]);
+    if (e != hipSuccess) {
+        g_create_error = std::string("prt_create: stream/event creation: ") + hipGetErrorString(e);
+        delete ctx;
+        return nullptr;
+    }
+    return ctx;
+}
+
+void prt_destroy(prt_ctx * ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    ctx->nodes.release(); ctx->tris.release(); ctx->shade.release(); ctx->diffuse_dirs.release(); ctx->spec_dirs.release();
+    ctx->tri_rank.release(); ctx->materials.release(); ctx->lights.release();
+    ctx->sample_rgb.release(); ctx->frame_out.release(); ctx->counters.release(); ctx->ring_ws.release(); ctx->pixel_list.release();
+    for (int i = 0; i < 4; ++i) if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+int prt_upload_scene(prt_ctx * ctx, const prt_scene_desc * s) {
+    if (!ctx) return -1;
+    if (!s || (s->index_count % 3) != 0) { ctx->error = "prt_upload_scene: null scene or index_count not a multiple of 3"; return -1; }
+    if (s->material_count == 0) { ctx->error = "prt_upload_scene: at least one material is required"; return -1; }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->has_scene = false;
+    const uint32_t n_tris = s->index_count / 3;
+    if (n_tris >= (1u << 29)) { ctx->error = "prt_upload_scene: more than 2^29 triangles"; return -1; }
+
+    // per-triangle group / material lookup + validation of every index the kernels will follow
+    std::vector<int32_t> tri_material(n_tris, 0);
+    std::vector<uint8_t> covered(n_tris, 0);
+    for (uint32_t g = 0; g < s->group_count; ++g) {
+        const prt_group & pg = s->groups[g];
+        if (pg.first_index % 3 || pg.index_count % 3 || (uint64_t)pg.first_index + pg.index_count > s->index_count) {
+            ctx->error = "prt_upload_scene: group index range is not a whole run of triangles inside the index buffers";
+            return -1;
+        }
+        if (pg.material < 0 || (uint32_t)pg.material >= s->material_count) { ctx->error = "prt_upload_scene: group material out of range"; return -1; }
+        for (uint32_t t = pg.first_index / 3; t < (pg.first_index + pg.index_count) / 3; ++t) { tri_material[t] = pg.material; covered[t] = 1; }
+    }
+    for (uint32_t t = 0; t < n_tris; ++t)
+        if (!covered[t]) { ctx->error = "prt_upload_scene: triangle not covered by any group"; return -1; }
+    for (uint32_t i = 0; i < s->index_count; ++i) {
+        if (s->idx_positions[i] >= s->position_count || s->idx_normals[i] >= s->normal_count ||
+            s->idx_texcoords[i] >= s->texcoord_count) {
+            ctx->error = "prt_upload_scene: vertex index out of range (the reference would read out of bounds here)";
+            return -1;
+        }
+    }
+    for (uint32_t m = 0; m < s->material_count; ++m) {
+        const prt_material & pm = s->materials[m];
+        if (pm.ambient_texture >= 0 || pm.diffuse_texture >= 0 || pm.specular_texture >= 0 || pm.alpha_texture >= 0 || pm.bump_texture >= 0) {
+            ctx->error = "prt_upload_scene: textured materials are not supported yet (SURVEY.md §8f N1)";
+            return -4;
+        }
+    }
+
+    // ---- BVH over un-indexed triangles
+    auto t0 = std::chrono::steady_clock::now();
+    std::vector<float> verts((size_t)n_tris * 9);
+    for (uint32_t t = 0; t < n_tris; ++t)
+        for (int c = 0; c < 3; ++c) memcpy(&verts[(size_t)t * 9 + 3 * c], s->positions + 3 * (size_t)s->idx_positions[3 * t + c], 12);
+    BvhResult bvh;
+    unsigned int hw = std::max(1u, std::thread::hardware_concurrency());
+    build_bvh2(verts.data(), n_tris, BVH_LEAF_MAX, std::min(hw, 16u), &bvh);
+    double build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+
+    // ---- reference visit rank: leaves of the sphere tree in the order TraceRay pops them (c1 first)
+    std::vector<uint32_t> rank_of_input(n_tris);
+    {
+        std::vector<uint32_t> group_base(s->group_count, 0);
+        bool ranked = false;
+        if (s->spheres && s->sphere_group && s->sphere_count) {
+            std::vector<uint32_t> stack(1, 0u);
+            std::vector<uint8_t> seen(s->group_count, 0);
+            uint32_t next = 0, visited = 0;
+            bool ok = true;
+            while (!stack.empty() && ok) {
+                uint32_t i = stack.back();
+                stack.pop_back();
+                if (i >= s->sphere_count || ++visited > 2 * s->sphere_count) { ok = false; break; }
+                const prt_bsphere & bs = s->spheres[i];
+                if (bs.c0 && bs.c1) {
+                    stack.push_back(bs.c0);
+                    stack.push_back(bs.c1);
+                } else {
+                    int32_t g = s->sphere_group[i];
+                    if (g < 0 || (uint32_t)g >= s->group_count || seen[g]) { ok = false; break; }
+                    seen[g] = 1;
+                    group_base[g] = next;
+                    next += s->groups[g].index_count / 3;
+                }
+            }
+            ranked = ok && next == n_tris;
+        }
+        if (ranked) {
+            for (uint32_t g = 0; g < s->group_count; ++g) {
+                uint32_t first = s->groups[g].first_index / 3, cnt = s->groups[g].index_count / 3;
+                for (uint32_t k = 0; k < cnt; ++k) rank_of_input[first + k] = group_base[g] + k;
+            }
+        } else {
+            for (uint32_t t = 0; t < n_tris; ++t) rank_of_input[t] = t;
+        }
+    }
+
+    // ---- device records in BVH leaf order
+    const uint32_t n_rec = std::max(1u, n_tris);
+    std::vector<float4> tris((size_t)n_rec * 3, make_float4(0, 0, 0, 0)), shade((size_t)n_rec * 4, make_float4(0, 0, 0, 0));
+    std::vector<unsigned int> rank(n_rec, 0);
+    float abs_max = 0.0f;
+    for (uint32_t slot = 0; slot < n_tris; ++slot) {
+        const uint32_t t = bvh.tri_order[slot];
+        const f3 a = ld3(&verts[(size_t)t * 9]), b = ld3(&verts[(size_t)t * 9 + 3]), c = ld3(&verts[(size_t)t * 9 + 6]);
+        const f3 ab = b - a, ac = c - a;                          // raytracer.cpp:85-86
+        const f3 n = cross3(ab, ac);                              // raytracer.cpp:91
+        tris[(size_t)slot * 3 + 0] = make_float4(a.x, a.y, a.z, ab.x);
+        tris[(size_t)slot * 3 + 1] = make_float4(ab.y, ab.z, ac.x, ac.y);
+        tris[(size_t)slot * 3 + 2] = make_float4(ac.z, n.x, n.y, n.z);
+        const float * n0 = s->normals + 3 * (size_t)s->idx_normals[3 * t + 0];
+        const float * n1 = s->normals + 3 * (size_t)s->idx_normals[3 * t + 1];
+        const float * n2 = s->normals + 3 * (size_t)s->idx_normals[3 * t + 2];
+        const float * u0 = s->texcoords + 2 * (size_t)s->idx_texcoords[3 * t + 0];
+        const float * u1 = s->texcoords + 2 * (size_t)s->idx_texcoords[3 * t + 1];
+        const float * u2 = s->texcoords + 2 * (size_t)s->idx_texcoords[3 * t + 2];
+        float mbits;
+        int32_t mi = tri_material[t];
+        memcpy(&mbits, &mi, 4);
+        shade[(size_t)slot * 4 + 0] = make_float4(n0[0], n0[1], n0[2], n1[0]);
+        shade[(size_t)slot * 4 + 1] = make_float4(n1[1], n1[2], n2[0], n2[1]);
+        shade[(size_t)slot * 4 + 2] = make_float4(n2[2], u0[0], u0[1], u1[0]);
+        shade[(size_t)slot * 4 + 3] = make_float4(u1[1], u2[0], u2[1], mbits);
+        rank[slot] = rank_of_input[t];
+        for (int k = 0; k < 9; ++k) abs_max = std::max(abs_max, fabsf(verts[(size_t)t * 9 + k]));
+    }
+
+    std::vector<DevMaterial> mats(s->material_count);
+    ctx->material_ns.resize(s->material_count);
+    ctx->any_translucent = false;
+    for (uint32_t m = 0; m < s->material_count; ++m) {
+        const prt_material & pm = s->materials[m];
+        DevMaterial & d = mats[m];
+        memset(&d, 0, sizeof(d));
+        for (int k = 0; k < 3; ++k) { d.ambient[k] = pm.ambient_color[k]; d.diffuse[k] = pm.diffuse_color[k]; d.specular[k] = pm.specular_color[k]; }
+        d.specular_intensity = pm.specular_intensity;
+        d.index_of_refraction = pm.index_of_refraction;
+        d.alpha = pm.alpha;
+        ctx->material_ns[m] = pm.specular_intensity;
+        if (!(pm.alpha >= 1.0f)) ctx->any_translucent = true;      // alpha < 1 (or NaN): continuation rays, unbounded draws
+    }
+    std::vector<DevLight> lights(std::max(1u, s->light_count));
+    memset(lights.data(), 0, lights.size() * sizeof(DevLight));
+    for (uint32_t l = 0; l < s->light_count; ++l) {
+        const prt_light & pl = s->lights[l];
+        DevLight & d = lights[l];
+        d.type = pl.type;
+        for (int k = 0; k < 3; ++k) { d.color[k] = pl.color[k]; d.position[k] = pl.position[k]; d.facing[k] = pl.facing[k]; }
+        d.falloff = pl.falloff;
+    }
+    std::vector<float4> ddirs(1024);
+    for (uint32_t i = 0; i < 1024; ++i) ddirs[i] = diffuse_tangent_dir(i);
+
+    std::vector<float4> nodes4(bvh.nodes.size() / 4);
+    memcpy(nodes4.data(), bvh.nodes.data(), bvh.nodes.size() * sizeof(float));
+
+    HIP_TRY(ctx, ctx->nodes.upload(nodes4));
+    HIP_TRY(ctx, ctx->tris.upload(tris));
+    HIP_TRY(ctx, ctx->shade.upload(shade));
+    HIP_TRY(ctx, ctx->tri_rank.upload(rank));
+    HIP_TRY(ctx, ctx->materials.upload(mats));
+    HIP_TRY(ctx, ctx->lights.upload(lights));
+    HIP_TRY(ctx, ctx->diffuse_dirs.upload(ddirs));
+
+    DevScene & sc = ctx->scene;
+    sc.nodes = ctx->nodes.p;
+    sc.tris = ctx->tris.p;
+    sc.shade = ctx->shade.p;
+    sc.tri_rank = ctx->tri_rank.p;
+    sc.materials = ctx->materials.p;
+    sc.lights = ctx->lights.p;
+    sc.diffuse_dirs = ctx->diffuse_dirs.p;
+    sc.light_count = s->light_count;
+    sc.tri_count = n_tris;
+    sc.node_count = bvh.node_count;
+    ctx->spec_table_samples = 0;
+    int rc = build_spec_table(ctx, 1);
+    if (rc) return rc;
+
+    ctx->scene_abs_max = abs_max;
+    prt_scene_info & info = ctx->info;
+    info.triangle_count = n_tris;
+    info.bvh_node_count = bvh.node_count;
+    info.bvh_max_depth = bvh.max_depth;
+    info.bvh_node_bytes = 64;
+    info.tri_record_bytes = 48;
+    info.shade_record_bytes = 64;
+    info.device_bytes = ctx->nodes.bytes() + ctx->tris.bytes() + ctx->shade.bytes() + ctx->tri_rank.bytes() +
+                        ctx->materials.bytes() + ctx->lights.bytes() + ctx->diffuse_dirs.bytes() + ctx->spec_dirs.bytes();
+    info.bvh_build_ms = build_ms;
+    ctx->has_scene = true;
+    return 0;
+}
+
+int prt_get_scene_info(const prt_ctx * ctx, prt_scene_info * info) {
+    if (!ctx || !info) return -1;
+    if (!ctx->has_scene) return -2;
+    *info = ctx->info;
+    return 0;
+}
+
+int prt_render_device(prt_ctx * ctx, const prt_camera * cam, const prt_params * params, uint32_t width, uint32_t height,
+                      uint32_t start_idx, uint32_t end_idx, void * d_rgba_out, prt_counters * counters) {
+    if (!ctx) return -1;
+    if (!d_rgba_out || end_idx < start_idx || (uint64_t)end_idx > (uint64_t)width * height) {
+        ctx->error = "prt_render: bad output pointer or pixel range";
+        return -1;
+    }
+    PixelSet px = { end_idx - start_idx, start_idx, 1, 0, 1, nullptr };
+    return render_pixels(ctx, cam, params, width, height, px, (float4 *)d_rgba_out, counters);
+}
+
+int prt_render(prt_ctx * ctx, const prt_camera * cam, const prt_params * params, uint32_t width, uint32_t height,
+               uint32_t start_idx, uint32_t end_idx, float * rgba_out, prt_counters * counters) {
+    if (!ctx) return -1;
+    if (!rgba_out || end_idx < start_idx) { ctx->error = "prt_render: bad output pointer or pixel range"; return -1; }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t n = end_idx - start_idx;
+    HIP_TRY(ctx, ctx->frame_out.ensure(n));
+    int rc = prt_render_device(ctx, cam, params, width, height, start_idx, end_idx, ctx->frame_out.p, counters);
+    if (rc) return rc;
+    if (n) HIP_TRY(ctx, hipMemcpy(rgba_out, ctx->frame_out.p, n * sizeof(float4), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+uint32_t prt_shard_rows(uint32_t height, uint32_t block_rows, uint32_t rank, uint32_t nranks) {
+    if (!block_rows || !nranks || rank >= nranks) return 0;
+    uint32_t rows = 0;
+    for (uint64_t b = rank; b * block_rows < height; b += nranks) rows += std::min<uint64_t>(block_rows, height - b * block_rows);
+    return rows;
+}
+
+int prt_render_shard_device(prt_ctx * ctx, const prt_camera * cam, const prt_params * params, uint32_t width, uint32_t height,
+                            uint32_t block_rows, uint32_t rank, uint32_t nranks, void * d_rgba_out, prt_counters * counters) {
+    if (!ctx) return -1;
+    if (!d_rgba_out || !block_rows || !nranks || rank >= nranks) { ctx->error = "prt_render_shard: bad arguments"; return -1; }
+    PixelSet px = { prt_shard_rows(height, block_rows, rank, nranks) * width, 0, block_rows, rank, nranks, nullptr };
+    if (nranks == 1) { px.block_rows = 1; }
+    return render_pixels(ctx, cam, params, width, height, px, (float4 *)d_rgba_out, counters);
+}
+
+int prt_render_shard(prt_ctx * ctx, const prt_camera * cam, const prt_params * params, uint32_t width, uint32_t height,
+                     uint32_t block_rows, uint32_t rank, uint32_t nranks, float * rgba_out, prt_counters * counters) {
+    if (!ctx) return -1;
+    if (!rgba_out) { ctx->error = "prt_render_shard: null output"; return -1; }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t n = (size_t)prt_shard_rows(height, block_rows, rank, nranks) * width;
+    HIP_TRY(ctx, ctx->frame_out.ensure(n));
+    int rc = prt_render_shard_device(ctx, cam, params, width, height, block_rows, rank, nranks, ctx->frame_out.p, counters);
+    if (rc) return rc;
+    if (n) HIP_TRY(ctx, hipMemcpy(rgba_out, ctx->frame_out.p, n * sizeof(float4), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int prt_render_pixel_list(prt_ctx * ctx, const prt_camera * cam, const prt_params * params, uint32_t width, uint32_t height,
+                          const uint32_t * pixel_ids, uint32_t n_pixels, float * rgba_out, prt_counters * counters) {
+    if (!ctx) return -1;
+    if (!pixel_ids || !rgba_out) { ctx->error = "prt_render_pixel_list: null pixel list or output"; return -1; }
+    for (uint32_t i = 0; i < n_pixels; ++i)
+        if ((uint64_t)pixel_ids[i] >= (uint64_t)width * height) { ctx->error = "prt_render_pixel_list: pixel id outside the image"; return -1; }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, ctx->pixel_list.ensure(n_pixels));
+    HIP_TRY(ctx, ctx->frame_out.ensure(n_pixels));
+    if (n_pixels) HIP_TRY(ctx, hipMemcpy(ctx->pixel_list.p, pixel_ids, (size_t)n_pixels * 4, hipMemcpyHostToDevice));
+    PixelSet px = { n_pixels, 0, 1, 0, 1, ctx->pixel_list.p };
+    int rc = render_pixels(ctx, cam, params, width, height, px, ctx->frame_out.p, counters);
+    if (rc) return rc;
+    if (n_pixels) HIP_TRY(ctx, hipMemcpy(rgba_out, ctx->frame_out.p, (size_t)n_pixels * sizeof(float4), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+}  // extern "C"
