@@ -1,0 +1,265 @@
+#!/usr/bin/env python3
+"""bench.py - Mrays/s of the HIP ray-trace hot path on BASELINE.json's headline config.
+
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+
+Workload (config C4): synthetic 1,002,528-triangle height-field OBJ in 1,024 groups, written
+to disk and loaded through the host OBJ loader, 1920x1080, 8 spp, bounce depth 2, seed 1234, the reference's
+single directional light.  One "step" = one frame: ray generation -> traversal -> shading -> resolved float4
+framebuffer, all on the device with the scene already resident in HBM; for N > 1 the frame is sharded in
+interleaved 8-row blocks, one rank per GPU, and a step ends after the RCCL gather of the shards to rank 0
+and their de-interleave on GPU 0.  Excluded, as in the reference's TIME_BLOCK("Render, sync")
+(main.cpp:327): OBJ parse, hierarchy/BVH build, upload, tone map, PNG.
+
+A ray is one TraceRay call (raytracer.cpp:161): primary, shadow, bounce.  value = rays of all ranks / time.
+Total work is fixed as N grows -> "scaling": "strong".
+
+Extra objects on the JSON line:
+  roofline      dominant kernel (k_render_mega): SURVEY.md §8d algorithmic bytes of one launch / its mean
+                duration measured with HIP events on the kernel's own stream inside the timed region.
+  cpu_baseline  the CPU oracle ("port", oracle/prt_oracle.cpp, proven bit-identical to the compiled
+                reference) timed on this host's cores on a sparse pixel lattice of the SAME frame; rank 0,
+                N = 1 only.  The same lattice is the parity check of the GPU frame (max |dRGB|, ray counts).
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (scene generator, width, height, spp, bounce_depth, description)
+    "C4": ("terrain_1m", 1920, 1080, 8, 2,
+           "C4: synthetic 1,002,528-triangle terrain OBJ (1,024 groups), 1920x1080, 8 spp, bounce_depth 2"),
+    "C3": ("icosphere_l6", 1920, 1080, 8, 2, "C3: displaced icosphere L6 (81,922 triangles, 65 groups), 1920x1080, 8 spp"),
+    "C2": ("cornell_box", 512, 512, 4, 2, "C2: Cornell-box-style 12-triangle OBJ, 512x512, 4 spp"),
+    "C5": ("terrain_1m", 3840, 2160, 64, 8, "C5: 1M-triangle terrain, 3840x2160, 64 spp, bounce_depth 8"),
+    "tiny": ("terrain_64", 320, 180, 2, 2, "tiny: 8,192-triangle terrain, 320x180, 2 spp (plumbing check)"),
+}
+SHARD_BLOCK_ROWS = 8
+SEED = 1234
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s HBM3E spec peak
+# SURVEY.md §8d algorithmic bytes per unit, with this build's record sizes
+B_RAY, B_NODE, B_TRI, B_SHADE, B_PIXEL = 52, 64, 48, 144, 16
+
+
+def log(msg):
+    if int(os.environ.get("RANK", "0")) == 0:
+        print("[bench] " + msg, file=sys.stderr, flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="C4", choices=sorted(WORKLOADS))
+    ap.add_argument("--pipeline", type=int, default=0)
+    ap.add_argument("--cpu-lattice", type=int, default=0, help="lattice stride of the CPU baseline (0 = auto)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs one rank per GPU: launch with python -m torch.distributed.run "
+                             "--nnodes=1 --nproc-per-node %d bench.py --gpus %d ..." % (args.gpus, args.gpus, args.gpus))
+        raise SystemExit("WORLD_SIZE=%d but --gpus %d" % (world, args.gpus))
+
+    import torch
+    import torch.distributed as dist
+
+    from par_raytracer_amd import api, capi, scenes
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    scene_name, width, height, spp, depth, descr = WORKLOADS[args.workload]
+
+    # ---- scene: rank 0 writes the OBJ once, every rank loads it (as every MPI rank of the reference does)
+    t0 = time.time()
+    if rank == 0:
+        scene = scenes.make_scene(scene_name)
+        obj_dir = tempfile.mkdtemp(prefix="prt_bench_%s_" % scene_name)
+        scenes.write_obj(scene, obj_dir, "scene.obj")
+        meta = [obj_dir, list(scene.camera_position), list(scene.camera_facing), float(scene.fov)]
+    else:
+        meta = [None, None, None, None]
+    if world > 1:
+        dist.broadcast_object_list(meta, src=0)
+    obj_dir, cam_pos, cam_dir, fov = meta
+    t1 = time.time()
+    hs = api.HostScene(obj_dir, "scene.obj", 0, cam_pos)
+    t2 = time.time()
+    r = api.Renderer(local_rank)
+    info = r.upload(hs)
+    t3 = time.time()
+    log("scene %s: %d triangles; OBJ write %.1fs, parse %.2fs + hierarchy %.2fs, upload+BVH %.2fs (%d nodes, depth %d, %.1f MB resident)" % (
+        scene_name, info.triangle_count, t1 - t0, hs.parse_seconds, hs.hierarchy_seconds, t3 - t2, info.bvh_node_count,
+        info.bvh_max_depth, info.device_bytes / 1e6))
+
+    cam = api.make_camera(fov, width, height, cam_pos, cam_dir)
+    params = api.default_params(spp, SEED, bounce_depth=depth, pipeline=args.pipeline)
+
+    # ---- output buffers (device).  Shards are padded to the largest shard so the gather has equal sizes.
+    my_rows = r.shard_rows(height, SHARD_BLOCK_ROWS, rank, world)
+    max_rows = max(r.shard_rows(height, SHARD_BLOCK_ROWS, k, world) for k in range(world))
+    shard = torch.zeros((max_rows, width, 4), dtype=torch.float32, device=dev)
+    frame = None
+    gather_list = None
+    row_index = None
+    if world > 1 and rank == 0:
+        gather_list = [torch.empty_like(shard) for _ in range(world)]
+        frame = torch.empty((height, width, 4), dtype=torch.float32, device=dev)
+        # destination row of every (rank, local row) slot; padded slots point at a scratch row `height`
+        idx = np.full((world, max_rows), height, dtype=np.int64)
+        for k in range(world):
+            row = 0
+            b = k
+            while b * SHARD_BLOCK_ROWS < height:
+                y0 = b * SHARD_BLOCK_ROWS
+                rows = min(SHARD_BLOCK_ROWS, height - y0)
+                idx[k, row:row + rows] = np.arange(y0, y0 + rows)
+                row += rows
+                b += world
+        row_index = torch.from_numpy(idx.reshape(-1)).to(dev)
+        frame_pad = torch.empty((height + 1, width, 4), dtype=torch.float32, device=dev)
+
+    def step(want_counters=True):
+        """One frame.  Returns this rank's counters."""
+        if world == 1:
+            c = r.render_device(cam, params, width, height, 0, width * height, shard.data_ptr(), want_counters)
+        else:
+            c = r.render_shard_device(cam, params, width, height, SHARD_BLOCK_ROWS, rank, world, shard.data_ptr(), want_counters)
+            dist.gather(shard, gather_list, dst=0)
+            if rank == 0:
+                frame_pad.index_copy_(0, row_index, torch.cat(gather_list, dim=0))
+        return c
+
+    def sync_all():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ---- warmup, then EXACTLY K timed steps
+    for _ in range(args.warmup):
+        step()
+    sync_all()
+    t_start = time.perf_counter()
+    rays_local = 0
+    trace_ms = []
+    render_ms = []
+    for _ in range(args.steps):
+        c = step()
+        rays_local += c.ray_count
+        trace_ms.append(c.trace_kernel_ms)
+        render_ms.append(c.render_ms)
+    sync_all()
+    elapsed = time.perf_counter() - t_start
+
+    t = torch.tensor([elapsed, float(rays_local)], dtype=torch.float64, device=dev)
+    if world > 1:
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tsum = t.clone()
+        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        elapsed = float(tmax[0].item())
+        rays_total = float(tsum[1].item())
+    else:
+        rays_total = float(rays_local)
+    ms_per_step = elapsed * 1e3 / args.steps
+    value = rays_total / elapsed / 1e6
+
+    # ---- roofline of the dominant kernel: one extra, untimed render with visit counting (identical pixels)
+    pcount = api.default_params(spp, SEED, bounce_depth=depth, pipeline=args.pipeline | capi.FLAG_COUNT_VISITS)
+    if world == 1:
+        cc = r.render_device(cam, pcount, width, height, 0, width * height, shard.data_ptr(), True)
+    else:
+        cc = r.render_shard_device(cam, pcount, width, height, SHARD_BLOCK_ROWS, rank, world, shard.data_ptr(), True)
+    n_px_local = my_rows * width if world > 1 else width * height
+    alg_bytes = (cc.ray_count * B_RAY + cc.node_visits * B_NODE + cc.tri_tests * B_TRI + cc.shaded_hits * B_SHADE +
+                 n_px_local * B_PIXEL)
+    kernel_ms = float(np.mean(trace_ms))
+    achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.workload)
+    if os.path.exists(tpath) and world == 1:
+        try:
+            with open(tpath) as f:
+                traffic = json.load(f).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    roofline = {"bound": "hbm", "kernel": "k_render_mega", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                "algorithmic_bytes_per_launch": int(alg_bytes), "kernel_ms": round(kernel_ms, 4),
+                "per_launch": {"rays": int(cc.ray_count), "node_visits": int(cc.node_visits), "tri_tests": int(cc.tri_tests),
+                               "shaded_hits": int(cc.shaded_hits), "pixels": int(n_px_local)},
+                "bytes_per_unit": {"ray": B_RAY, "node": B_NODE, "tri_test": B_TRI, "shaded_hit": B_SHADE, "pixel": B_PIXEL}}
+
+    # ---- CPU baseline + parity on a sparse lattice of the same frame (rank 0, N = 1 only)
+    cpu_baseline = None
+    parity = None
+    if world == 1 and not args.no_cpu_baseline:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import oracle_py as orc
+        cores = max(1, min(len(os.sched_getaffinity(0)), 64))
+        lattice = args.cpu_lattice
+        if lattice <= 0:
+            # aim at ~20 s of CPU work: probe a very sparse lattice first, then scale
+            probe = max(8, int(round((width * height / 200.0) ** 0.5)))
+            _, pc = orc.render(hs.desc, cam, params, width, height, probe, cores)
+            per_px = pc.render_seconds * cores / max(1, ((width + probe - 1) // probe) * ((height + probe - 1) // probe))
+            want_px = 20.0 / max(per_px, 1e-9)
+            lattice = int(max(1, min(probe, round((width * height / want_px) ** 0.5))))
+        cpu_img, octr = orc.render(hs.desc, cam, params, width, height, lattice, cores)
+        gpu_img, gctr = r.render_lattice(cam, params, width, height, lattice)
+        diff = np.abs(gpu_img[:, :, :3] - cpu_img[:, :, :3])
+        cpu_mrays = octr.ray_count / octr.render_seconds / 1e6
+        cpu_baseline = {"value": round(cpu_mrays, 4), "unit": "Mrays/s", "cores": cores, "kind": "port",
+                        "sample": "every %dth pixel in x and y of the same %dx%d x %d spp frame (%d pixels, %d rays, %.1f s wall on %d threads)" % (
+                            lattice, width, height, spp, cpu_img.shape[0] * cpu_img.shape[1], octr.ray_count, octr.render_seconds, cores),
+                        "speedup_gpu_over_cpu": round(value / cpu_mrays, 1) if cpu_mrays > 0 else None}
+        parity = {"pixels": int(cpu_img.shape[0] * cpu_img.shape[1]), "max_abs_diff_rgb": float(diff.max()),
+                  "pixels_over_1e-4": int((diff.max(axis=2) > 1e-4).sum()),
+                  "ray_count_gpu": int(gctr.ray_count), "ray_count_cpu": int(octr.ray_count),
+                  "ray_count_equal": bool(gctr.ray_count == octr.ray_count)}
+
+    if rank == 0:
+        out = {
+            "metric": "Mrays/s at 1920x1080x8spp, 1M-tri OBJ" if args.workload == "C4" else "Mrays/s (%s)" % args.workload,
+            "value": round(value, 3), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": descr, "seed": SEED, "triangles": int(info.triangle_count), "width": width, "height": height,
+                       "spp": spp, "bounce_depth": depth, "rays_per_frame": int(rays_total / args.steps),
+                       "parallelism": "pixel rows sharded in %d-row blocks over %d GPU(s)%s" % (
+                           SHARD_BLOCK_ROWS, world, ", RCCL gather to rank 0" if world > 1 else ""),
+                       "pipeline": "megakernel"},
+            "render_ms_device": round(float(np.mean(render_ms)), 4),
+            "roofline": roofline, "cpu_baseline": cpu_baseline, "parity": parity,
+        }
+        print(json.dumps(out), flush=True)
+    r.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
