@@ -92,10 +92,15 @@ PRT_D HitRec trace_ray(const DevScene & sc, f3 o, f3 d, int kind, float pad, int
     best.tri = -1;
     unsigned int best_rank = 0xFFFFFFFFu;
 
-    int sp = 0;
+    // "while-while" traversal (Aila & Laine): every lane first walks internal nodes until it holds a leaf
+    // (or runs out of work), and only then does the wave run the triangle code.  With 64 lanes a fused
+    // node-or-leaf loop would execute the (4x longer) leaf body in almost every iteration.
+    const int SENTINEL = (int)0x80000000;            // never a valid leaf link (first_tri < 2^29)
+    stack[0] = SENTINEL;
+    int sp = 1;
     int node = 0;
     for (;;) {
-        if (node >= 0) {
+        while (node >= 0) {
             const float4 * np = sc.nodes + 4 * (size_t)node;
             const float4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
             if (COUNT) st.nodes++;
@@ -123,11 +128,12 @@ PRT_D HitRec trace_ray(const DevScene & sc, f3 o, f3 d, int kind, float pad, int
             } else if (h1) {
                 node = l1;
             } else {
-                if (sp == 0) break;
                 sp--;
                 node = stack[sp * BLOCK];
             }
-        } else {
+        }
+        if (node == SENTINEL) break;
+        {
             const unsigned int leaf = (unsigned int)~node;
             const unsigned int first = leaf >> 2, count = (leaf & 3u) + 1u;
             bool done = false;
@@ -158,7 +164,6 @@ PRT_D HitRec trace_ray(const DevScene & sc, f3 o, f3 d, int kind, float pad, int
                 }
             }
             if (done) break;
-            if (sp == 0) break;
             sp--;
             node = stack[sp * BLOCK];
         }

@@ -230,7 +230,7 @@ int render_pixels(prt_ctx * ctx, const prt_camera * cam_in, const prt_params * p
 
     // LDS traversal stack: one int per BVH level per lane
     constexpr int BLOCK = 256;
-    const unsigned int stack_entries = ctx->info.bvh_max_depth + 1;
+    const unsigned int stack_entries = ctx->info.bvh_max_depth + 2;   // + sentinel
     const size_t lds = (size_t)stack_entries * BLOCK * sizeof(int);
     if (lds > 64 * 1024) { ctx->error = "prt_render: BVH too deep for the LDS traversal stack"; return -3; }
 
