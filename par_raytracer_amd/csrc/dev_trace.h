@@ -72,103 +72,125 @@ PRT_D bool tri_test(f3 o, f3 d, f3 qp, f3 a, f3 ab, f3 ac, f3 n, float best_t, f
     return false;
 }
 
-// o: ray origin ALREADY biased by direction * ray_bias (raytracer.cpp:163).  stack: this lane's LDS column.
-template <int BLOCK, bool COUNT>
-PRT_D HitRec trace_ray(const DevScene & sc, f3 o, f3 d, int kind, float pad, int * stack, TraceStats & st) {
-    const f3 qp = o - (o + d);                       // raytracer.cpp:88-89, not bitwise -d
-    // slab setup: direction components are clamped away from 0 so no inf/NaN enters the box test
+// Per-lane traversal registers.  A ray can be suspended and resumed at any node boundary (the persistent
+// kernel does so when it leaves the traversal loop to refill idle lanes).
+struct TravRay {
+    f3 o, d;                          // origin ALREADY biased by direction * ray_bias (raytracer.cpp:163), direction
+    float ix, iy, iz;                 // 1 / direction, components clamped away from 0
+    float olx, oly, olz;              // o + pad: the lo planes of the widened boxes are seen from here
+    float ohx, ohy, ohz;              // o - pad: the hi planes
+    HitRec best;
+    unsigned int best_rank;
+    int node, sp, kind;
+};
+
+enum { TRAV_SENTINEL = (int)0x80000000 };   // bottom-of-stack marker; never a valid leaf link (first_tri < 2^29)
+
+template <int BLOCK>
+PRT_D void trav_init(TravRay & r, f3 o, f3 d, int kind, float pad, int * stack) {
+    r.o = o;
+    r.d = d;
+    // direction components are clamped away from 0 so no inf/NaN enters the box test
     const float tiny = 1e-30f;
     float dx = fabsf(d.x) < tiny ? (d.x < 0.0f ? -tiny : tiny) : d.x;
     float dy = fabsf(d.y) < tiny ? (d.y < 0.0f ? -tiny : tiny) : d.y;
     float dz = fabsf(d.z) < tiny ? (d.z < 0.0f ? -tiny : tiny) : d.z;
-    const float ix = 1.0f / dx, iy = 1.0f / dy, iz = 1.0f / dz;
-    // widened boxes: lo plane seen from o + pad, hi plane from o - pad
-    const float olx = o.x + pad, oly = o.y + pad, olz = o.z + pad;
-    const float ohx = o.x - pad, ohy = o.y - pad, ohz = o.z - pad;
+    r.ix = 1.0f / dx; r.iy = 1.0f / dy; r.iz = 1.0f / dz;
+    r.olx = o.x + pad; r.oly = o.y + pad; r.olz = o.z + pad;
+    r.ohx = o.x - pad; r.ohy = o.y - pad; r.ohz = o.z - pad;
+    r.best.t = 3.402823466e+38f;
+    r.best.v = r.best.w = 0.0f;
+    r.best.tri = -1;
+    r.best_rank = 0xFFFFFFFFu;
+    r.kind = kind;
+    stack[0] = TRAV_SENTINEL;
+    r.sp = 1;
+    r.node = 0;
+}
 
-    HitRec best;
-    best.t = 3.402823466e+38f;
-    best.v = best.w = 0.0f;
-    best.tri = -1;
-    unsigned int best_rank = 0xFFFFFFFFu;
+// One internal node: fetch 64 B, test both child boxes, descend into the nearer hit child, push the other.
+template <int BLOCK, bool COUNT>
+PRT_D void trav_node_step(const DevScene & sc, TravRay & r, int * stack, TraceStats & st) {
+    const float4 * np = sc.nodes + 4 * (size_t)r.node;
+    const float4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
+    if (COUNT) st.nodes++;
+    float ax = (n0.x - r.olx) * r.ix, bx = (n0.y - r.ohx) * r.ix;
+    float ay = (n0.z - r.oly) * r.iy, by = (n0.w - r.ohy) * r.iy;
+    float az = (n2.x - r.olz) * r.iz, bz = (n2.y - r.ohz) * r.iz;
+    float tmin0 = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
+    float tmax0 = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), r.best.t));
+    float cx = (n1.x - r.olx) * r.ix, ex = (n1.y - r.ohx) * r.ix;
+    float cy = (n1.z - r.oly) * r.iy, ey = (n1.w - r.ohy) * r.iy;
+    float cz = (n2.z - r.olz) * r.iz, ez = (n2.w - r.ohz) * r.iz;
+    float tmin1 = fmaxf(fmaxf(fminf(cx, ex), fminf(cy, ey)), fmaxf(fminf(cz, ez), 0.0f));
+    float tmax1 = fminf(fminf(fmaxf(cx, ex), fmaxf(cy, ey)), fminf(fmaxf(cz, ez), r.best.t));
+    const bool h0 = tmin0 <= tmax0, h1 = tmin1 <= tmax1;
+    int l0 = as_i(n3.x), l1 = as_i(n3.y);
+    if (h0 && h1) {
+        if (tmin1 < tmin0) { int tmp = l0; l0 = l1; l1 = tmp; }
+        stack[r.sp * BLOCK] = l1;
+        r.sp++;
+        r.node = l0;
+    } else if (h0) {
+        r.node = l0;
+    } else if (h1) {
+        r.node = l1;
+    } else {
+        r.sp--;
+        r.node = stack[r.sp * BLOCK];
+    }
+}
 
-    // "while-while" traversal (Aila & Laine): every lane first walks internal nodes until it holds a leaf
-    // (or runs out of work), and only then does the wave run the triangle code.  With 64 lanes a fused
-    // node-or-leaf loop would execute the (4x longer) leaf body in almost every iteration.
-    const int SENTINEL = (int)0x80000000;            // never a valid leaf link (first_tri < 2^29)
-    stack[0] = SENTINEL;
-    int sp = 1;
-    int node = 0;
-    for (;;) {
-        while (node >= 0) {
-            const float4 * np = sc.nodes + 4 * (size_t)node;
-            const float4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
-            if (COUNT) st.nodes++;
-            // child 0
-            float ax = (n0.x - olx) * ix, bx = (n0.y - ohx) * ix;
-            float ay = (n0.z - oly) * iy, by = (n0.w - ohy) * iy;
-            float az = (n2.x - olz) * iz, bz = (n2.y - ohz) * iz;
-            float tmin0 = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
-            float tmax0 = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), best.t));
-            // child 1
-            float cx = (n1.x - olx) * ix, ex = (n1.y - ohx) * ix;
-            float cy = (n1.z - oly) * iy, ey = (n1.w - ohy) * iy;
-            float cz = (n2.z - olz) * iz, ez = (n2.w - ohz) * iz;
-            float tmin1 = fmaxf(fmaxf(fminf(cx, ex), fminf(cy, ey)), fmaxf(fminf(cz, ez), 0.0f));
-            float tmax1 = fminf(fminf(fmaxf(cx, ex), fmaxf(cy, ey)), fminf(fmaxf(cz, ez), best.t));
-            const bool h0 = tmin0 <= tmax0, h1 = tmin1 <= tmax1;
-            int l0 = as_i(n3.x), l1 = as_i(n3.y);
-            if (h0 && h1) {
-                if (tmin1 < tmin0) { int tmp = l0; l0 = l1; l1 = tmp; }
-                stack[sp * BLOCK] = l1;
-                sp++;
-                node = l0;
-            } else if (h0) {
-                node = l0;
-            } else if (h1) {
-                node = l1;
-            } else {
-                sp--;
-                node = stack[sp * BLOCK];
-            }
+// The leaf in r.node: test its triangles, then pop.  Returns true when an any-hit ray found its hit.
+template <int BLOCK, bool COUNT>
+PRT_D bool trav_leaf(const DevScene & sc, TravRay & r, int * stack, TraceStats & st) {
+    const f3 qp = r.o - (r.o + r.d);                 // raytracer.cpp:88-89, not bitwise -d
+    const unsigned int leaf = (unsigned int)~r.node;
+    const unsigned int first = leaf >> 2, count = (leaf & 3u) + 1u;
+    for (unsigned int i = 0; i < count; ++i) {
+        const unsigned int ti = first + i;
+        const float4 * tp = sc.tris + 3 * (size_t)ti;
+        const float4 r0 = tp[0], r1 = tp[1], r2 = tp[2];
+        if (COUNT) st.tris++;
+        float t, v, w;
+        bool eq;
+        bool hit = tri_test(r.o, r.d, qp, mk3(r0.x, r0.y, r0.z), mk3(r0.w, r1.x, r1.y), mk3(r1.z, r1.w, r2.x),
+                            mk3(r2.y, r2.z, r2.w), r.best.t, t, v, w, eq);
+        if (eq && r.best.tri >= 0 && (int)ti != r.best.tri) {
+            // bit-equal t: the reference keeps whichever it visited first
+            unsigned int rk = sc.tri_rank[ti];
+            if (r.best_rank == 0xFFFFFFFFu) r.best_rank = sc.tri_rank[r.best.tri];
+            hit = rk < r.best_rank;
+            if (hit) r.best_rank = rk;
+        } else if (hit) {
+            r.best_rank = 0xFFFFFFFFu;
         }
-        if (node == SENTINEL) break;
-        {
-            const unsigned int leaf = (unsigned int)~node;
-            const unsigned int first = leaf >> 2, count = (leaf & 3u) + 1u;
-            bool done = false;
-            for (unsigned int i = 0; i < count; ++i) {
-                const unsigned int ti = first + i;
-                const float4 * tp = sc.tris + 3 * (size_t)ti;
-                const float4 r0 = tp[0], r1 = tp[1], r2 = tp[2];
-                if (COUNT) st.tris++;
-                float t, v, w;
-                bool eq;
-                bool hit = tri_test(o, d, qp, mk3(r0.x, r0.y, r0.z), mk3(r0.w, r1.x, r1.y), mk3(r1.z, r1.w, r2.x),
-                                    mk3(r2.y, r2.z, r2.w), best.t, t, v, w, eq);
-                if (eq && best.tri >= 0 && (int)ti != best.tri) {
-                    // bit-equal t: the reference keeps whichever it visited first
-                    unsigned int rk = sc.tri_rank[ti];
-                    if (best_rank == 0xFFFFFFFFu) best_rank = sc.tri_rank[best.tri];
-                    hit = rk < best_rank;
-                    if (hit) best_rank = rk;
-                } else if (hit) {
-                    best_rank = 0xFFFFFFFFu;
-                }
-                if (hit) {
-                    best.t = t;
-                    best.v = v;
-                    best.w = w;
-                    best.tri = (int)ti;
-                    if (kind == TRACE_ANY) { done = true; break; }
-                }
-            }
-            if (done) break;
-            sp--;
-            node = stack[sp * BLOCK];
+        if (hit) {
+            r.best.t = t;
+            r.best.v = v;
+            r.best.w = w;
+            r.best.tri = (int)ti;
+            if (r.kind == TRACE_ANY) return true;
         }
     }
-    return best;
+    r.sp--;
+    r.node = stack[r.sp * BLOCK];
+    return false;
+}
+
+// Whole-ray traversal, "while-while" (Aila & Laine): every lane first walks internal nodes until it holds
+// a leaf (or runs out of work), and only then does the wave run the triangle code.  With 64 lanes a fused
+// node-or-leaf loop would execute the (4x longer) leaf body in almost every iteration.
+template <int BLOCK, bool COUNT>
+PRT_D HitRec trace_ray(const DevScene & sc, f3 o, f3 d, int kind, float pad, int * stack, TraceStats & st) {
+    TravRay r;
+    trav_init<BLOCK>(r, o, d, kind, pad, stack);
+    for (;;) {
+        while (r.node >= 0) trav_node_step<BLOCK, COUNT>(sc, r, stack, st);
+        if (r.node == TRAV_SENTINEL) break;
+        if (trav_leaf<BLOCK, COUNT>(sc, r, stack, st)) break;
+    }
+    return r.best;
 }
 
 }  // namespace prt

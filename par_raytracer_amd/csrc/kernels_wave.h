@@ -1,0 +1,448 @@
+// kernels_wave.h - the wavefront (ray-batched) pipeline: ray generation / persistent traversal / shading.
+//
+// Why: in the one-lane-per-sample kernel a wave lives as long as its unluckiest sample (1..14 rays, each
+// 5..100 traversal steps) and rocprof shows ~10x more VALU wave-instructions than one lane's average
+// work.  Here rays are independent work items in structure-of-arrays queues in HBM:
+//
+//   k_raygen   one lane per (pixel, sample): seed the RNG, jitter, camera ray -> closest-hit queue
+//   k_trace    PERSISTENT waves pull rays (closest-hit and shadow rays mixed) from the queues through one
+//              atomic head; a lane that finishes its ray goes idle, and when fewer than KEEP_MIN lanes of a
+//              wave are still traversing, the wave leaves the loop, compacts its idle lanes with
+//              ballot / mbcnt and refills them with the next rays.  Traversal state (node, stack pointer,
+//              best hit) stays in registers + the per-lane LDS stack column across refills.
+//   k_shade    one lane per closest-hit result: runs the sample's bounce-tree state machine until the next
+//              ray, appends it (and the shadow rays of the hit) to the next round's queues with one
+//              wave-aggregated atomic per queue.
+//
+// The reference consumes its RNG in depth-first order of the recursion (raytracer.cpp:413-577), so a
+// sample has at most one closest-hit ray in flight; shadow rays use no RNG and ride along in the same
+// round.  Radiance is accumulated in throughput form: a frame contributes T * (ambient*0.1 + direct*Kd*w_d
+// + spec*Ks) and scales its children by T * Kd*w_d*weight / T * Ks*weight - the same polynomial as
+// raytracer.cpp:543-552 with the products distributed (differences ~1e-7 relative, tolerance 1e-4;
+// control flow - hits, roulette, directions - is bit exact and ray counts are equal).  Frames that still
+// have children to spawn wait in a per-sample, per-level slot (64 B) and a bitmask of pending levels
+// travels with the ray.
+#pragma once
+
+#include "../../include/prt_key.h"
+#include "dev_shade.h"
+
+namespace prt {
+
+enum { WF_KIND_CLOSEST = 0, WF_KIND_SHADOW_ANY = 1, WF_KIND_SHADOW_DIST = 2 };
+enum { WF_STAGE_REFL = 0, WF_STAGE_SPEC = 1, WF_STAGE_ALPHA = 2, WF_STAGE_DONE = 3 };
+
+struct WaveBuffers {
+    float4 * accum;              // [N] per-sample radiance (xyz)
+    ulonglong2 * rng;            // [N] (chain, prev)
+    ulonglong2 * rng_aux;        // [N] (seed0, k)            RING only
+    u64 * ring;                  // [16][N]                   RING only
+    float4 * frames;             // [levels][FR4][N] pending frames
+    float4 * rq_o[2];            // closest-hit queues, double buffered: (o.xyz, sample)
+    float4 * rq_d[2];            //                                      (d.xyz, level | pending_mask << 8)
+    float4 * rq_t[2];            //                                      (throughput.xyz, -)
+    float4 * hits;               // [N] (t, v, w, tri) by queue position
+    float4 * sq_o;               // shadow queue: (o.xyz, sample)
+    float4 * sq_d;               //               (d.xyz, kind)
+    float4 * sq_c;               //               (radiance if unoccluded .xyz, light distance^2)
+    unsigned int * counts;       // [0] next closest count, [1] next shadow count, [2] trace fetch head
+    unsigned int n_samples;
+};
+
+PRT_D unsigned int lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+
+// Wave-aggregated queue append: one atomic per wave, slots handed out by rank among the appending lanes.
+PRT_D unsigned int wave_append(unsigned int * counter, bool pred) {
+    const unsigned long long mask = __ballot(pred);
+    if (mask == 0ull) return 0u;
+    const unsigned int n = (unsigned int)__popcll(mask);
+    const unsigned int prefix = __builtin_amdgcn_mbcnt_hi((unsigned int)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)mask, 0u));
+    const int leader = __ffsll((long long)mask) - 1;
+    unsigned int base = 0;
+    if ((int)lane_id() == leader) base = atomicAdd(counter, n);
+    base = (unsigned int)__shfl((int)base, leader);
+    return base + prefix;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+template <bool RING>
+__global__ __launch_bounds__(256) void k_raygen(DevCamera cam, DevParams P, WaveBuffers B) {
+    const unsigned int sid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (sid >= B.n_samples) return;
+    const unsigned int pixel = pixel_of_local(P, sid / P.spp);
+    const unsigned int samp = sid % P.spp;
+    SampleState S;
+    Frame cur;
+    u64 * ring = RING ? B.ring + sid : nullptr;
+    sample_begin<RING>(cam, P, pixel, samp, S, cur, ring, B.n_samples);
+    B.rng[sid] = make_ulonglong2(S.rng.chain, S.rng.prev);
+    if (RING) B.rng_aux[sid] = make_ulonglong2(S.rng.seed0, (u64)S.rng.k);
+    B.accum[sid] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    B.rq_o[0][sid] = make_float4(cur.ray_o.x, cur.ray_o.y, cur.ray_o.z, as_f((int)sid));
+    B.rq_d[0][sid] = make_float4(cur.ray_d.x, cur.ray_d.y, cur.ray_d.z, as_f(0));
+    B.rq_t[0][sid] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Persistent traversal.  grid = resident blocks; dynamic LDS = stack_entries * BLOCK * 4.
+template <int BLOCK, bool COUNT>
+__global__ __launch_bounds__(BLOCK) void k_trace(DevScene sc, DevParams P, WaveBuffers B, int cur, unsigned int n_closest,
+                                                  unsigned int n_shadow, int keep_min, int multi_light, DevCounters * ctr) {
+    extern __shared__ int s_stack[];
+    int * stack = s_stack + threadIdx.x;
+    const unsigned int total = n_closest + n_shadow;
+    const unsigned int lane = lane_id();
+    const float4 * rq_o = B.rq_o[cur];
+    const float4 * rq_d = B.rq_d[cur];
+    unsigned int * head = B.counts + 2;
+
+    TravRay r;
+    r.node = TRAV_SENTINEL; r.sp = 0; r.kind = 0;
+    int ray = -1;                        // index into the combined [closest | shadow] ray space, -1 = idle
+    float4 payload = make_float4(0, 0, 0, 0);
+    int sample = 0;
+    bool exhausted = false;              // wave-uniform: the queue has no more rays to hand out
+    TraceStats st;
+    st.nodes = st.tris = 0;
+
+    for (;;) {
+        // ---- refill idle lanes
+        const unsigned long long idle = __ballot(ray < 0);
+        if (!exhausted && idle != 0ull) {
+            const unsigned int n = (unsigned int)__popcll(idle);
+            unsigned int base = 0;
+            if (lane == 0) base = atomicAdd(head, n);
+            base = (unsigned int)__shfl((int)base, 0);
+            if (base + n >= total) exhausted = true;
+            if (ray < 0) {
+                const unsigned int prefix = __builtin_amdgcn_mbcnt_hi((unsigned int)(idle >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)idle, 0u));
+                const unsigned int idx = base + prefix;
+                if (idx < total) {
+                    float4 ro, rd;
+                    int kind;
+                    if (idx < n_closest) {
+                        ro = rq_o[idx];
+                        rd = rq_d[idx];
+                        kind = WF_KIND_CLOSEST;
+                    } else {
+                        const unsigned int j = idx - n_closest;
+                        ro = B.sq_o[j];
+                        rd = B.sq_d[j];
+                        payload = B.sq_c[j];
+                        kind = as_i(rd.w);
+                    }
+                    sample = as_i(ro.w);
+                    const f3 d = mk3(rd.x, rd.y, rd.z);
+                    const f3 ob = mk3(ro.x, ro.y, ro.z) + d * P.ray_bias;          // raytracer.cpp:163
+                    trav_init<BLOCK>(r, ob, d, kind == WF_KIND_SHADOW_ANY ? TRACE_ANY : TRACE_CLOSEST, P.box_pad, stack);
+                    r.kind = kind == WF_KIND_SHADOW_ANY ? TRACE_ANY : TRACE_CLOSEST;
+                    payload.w = kind == WF_KIND_CLOSEST ? 0.0f : (kind == WF_KIND_SHADOW_ANY ? -1.0f : payload.w);
+                    ray = (int)idx;
+                }
+            }
+        }
+        if (__ballot(ray >= 0) == 0ull) break;
+
+        // ---- traverse until fewer than `leave_below` lanes of the wave are still busy
+        const int leave_below = exhausted ? 1 : keep_min;
+        while (ray >= 0) {
+            while (r.node >= 0) trav_node_step<BLOCK, COUNT>(sc, r, stack, st);
+            bool fin = r.node == TRAV_SENTINEL;
+            if (!fin) fin = trav_leaf<BLOCK, COUNT>(sc, r, stack, st);
+            if (fin) {
+                if ((unsigned int)ray < n_closest) {
+                    B.hits[ray] = make_float4(r.best.t, r.best.v, r.best.w, as_f(r.best.tri));
+                } else {
+                    // shadow ray: add the precomputed radiance when unoccluded.  payload.w < 0: directional light
+                    // (boolean only, raytracer.cpp:385); otherwise the point light's inverted distance test (:396)
+                    const bool lit = r.best.tri < 0 || (payload.w >= 0.0f && r.best.t * r.best.t <= payload.w);
+                    if (lit) {
+                        if (multi_light) {
+                            atomicAdd(&B.accum[sample].x, payload.x);
+                            atomicAdd(&B.accum[sample].y, payload.y);
+                            atomicAdd(&B.accum[sample].z, payload.z);
+                        } else {
+                            float4 a = B.accum[sample];
+                            a.x += payload.x; a.y += payload.y; a.z += payload.z;
+                            B.accum[sample] = a;
+                        }
+                    }
+                }
+                ray = -1;
+                break;
+            }
+            if (__popcll(__ballot(true)) < leave_below) break;
+        }
+    }
+    if (COUNT) {
+        atomicAdd(&ctr->node_visits, (unsigned long long)st.nodes);
+        atomicAdd(&ctr->tri_tests, (unsigned long long)st.tris);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Pending frame record: FR4 float4 per (level, sample).
+//   f0 = (hit_p.xyz, mat)  f1 = (hit_n.xyz, stage | idx << 8)  f2 = (ray_d.xyz, alpha)  f3 = (T_in.xyz, w_diffuse)
+//   f4 = (hit_pos.xyz, -)   only when translucent materials exist (alpha continuation, raytracer.cpp:547-552)
+struct WFrame {
+    f3 hit_p, hit_n, ray_d, T_in, hit_pos;
+    float alpha, w_diffuse;
+    int mat, stage, idx;
+};
+
+template <bool RING>
+PRT_D void wframe_save(const WaveBuffers & B, int level, unsigned int s, const WFrame & f) {
+    constexpr int FR4 = RING ? 5 : 4;
+    float4 * p = B.frames + ((size_t)level * FR4) * B.n_samples + s;
+    p[0] = make_float4(f.hit_p.x, f.hit_p.y, f.hit_p.z, as_f(f.mat));
+    p[(size_t)B.n_samples] = make_float4(f.hit_n.x, f.hit_n.y, f.hit_n.z, as_f(f.stage | (f.idx << 8)));
+    p[(size_t)B.n_samples * 2] = make_float4(f.ray_d.x, f.ray_d.y, f.ray_d.z, f.alpha);
+    p[(size_t)B.n_samples * 3] = make_float4(f.T_in.x, f.T_in.y, f.T_in.z, f.w_diffuse);
+    if (RING) p[(size_t)B.n_samples * 4] = make_float4(f.hit_pos.x, f.hit_pos.y, f.hit_pos.z, 0.0f);
+}
+
+template <bool RING>
+PRT_D void wframe_load(const WaveBuffers & B, int level, unsigned int s, WFrame & f) {
+    constexpr int FR4 = RING ? 5 : 4;
+    const float4 * p = B.frames + ((size_t)level * FR4) * B.n_samples + s;
+    const float4 a = p[0], b = p[(size_t)B.n_samples], c = p[(size_t)B.n_samples * 2], d = p[(size_t)B.n_samples * 3];
+    f.hit_p = mk3(a.x, a.y, a.z); f.mat = as_i(a.w);
+    f.hit_n = mk3(b.x, b.y, b.z); f.stage = as_i(b.w) & 0xFF; f.idx = as_i(b.w) >> 8;
+    f.ray_d = mk3(c.x, c.y, c.z); f.alpha = c.w;
+    f.T_in = mk3(d.x, d.y, d.z); f.w_diffuse = d.w;
+    if (RING) {
+        const float4 e = p[(size_t)B.n_samples * 4];
+        f.hit_pos = mk3(e.x, e.y, e.z);
+    } else {
+        f.hit_pos = f.hit_p;
+    }
+}
+
+// One lane per closest-hit result of queue `cur`; appends to queue `cur ^ 1` and to the shadow queue.
+template <bool RING>
+__global__ __launch_bounds__(256) void k_shade(DevScene sc, DevParams P, WaveBuffers B, int cur, unsigned int n_closest,
+                                               DevCounters * ctr) {
+    const unsigned int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = i < n_closest;
+    const int depth = (int)P.bounce_depth;
+    const int nxt = cur ^ 1;
+
+    unsigned int s = 0;
+    int level = 0;
+    unsigned int pending = 0;
+    f3 ray_o = mk3(0, 0, 0), ray_d = mk3(0, 0, 1), T = mk3(0, 0, 0);
+    HitRec hit;
+    hit.t = 0.0f; hit.v = hit.w = 0.0f; hit.tri = -1;
+    Rng rng;
+    rng.chain = rng.prev = rng.seed0 = 0; rng.k = 0;
+    if (live) {
+        const float4 ro = B.rq_o[cur][i], rd = B.rq_d[cur][i], rt = B.rq_t[cur][i], h = B.hits[i];
+        s = (unsigned int)as_i(ro.w);
+        level = as_i(rd.w) & 0xFF;
+        pending = ((unsigned int)as_i(rd.w)) >> 8;
+        ray_o = mk3(ro.x, ro.y, ro.z);
+        ray_d = mk3(rd.x, rd.y, rd.z);
+        T = mk3(rt.x, rt.y, rt.z);
+        hit.t = h.x; hit.v = h.y; hit.w = h.z; hit.tri = as_i(h.w);
+        const ulonglong2 rs = B.rng[s];
+        rng.chain = rs.x; rng.prev = rs.y;
+        if (RING) { const ulonglong2 ra = B.rng_aux[s]; rng.seed0 = ra.x; rng.k = (u32)ra.y; }
+    }
+    u64 * ring = RING ? B.ring + s : nullptr;
+    const size_t ring_stride = B.n_samples;
+
+    f3 add = mk3(0.0f, 0.0f, 0.0f);          // radiance this invocation adds to the sample
+    bool emit_closest = false;
+    f3 next_o = ray_o, next_d = ray_d, next_T = T;
+    int next_level = 0;
+    unsigned int shaded = 0;
+
+    // ---- step 1: the hit (or miss) of the ray that just came back ----------------------------------------
+    enum { M_NEXT_CHILD, M_ENTER, M_RETURN_UP, M_DONE };
+    int mode = M_DONE;
+    WFrame f;
+    f.hit_p = f.hit_n = f.ray_d = f.T_in = f.hit_pos = mk3(0, 0, 0);
+    f.alpha = 1.0f; f.w_diffuse = 0.0f; f.mat = 0; f.stage = WF_STAGE_DONE; f.idx = 0;
+    bool want_shadow = false;
+    bool f_held = false;
+    f3 T_own = T;
+    DevMaterial mat = sc.materials[0];
+    if (live) {
+        if (hit.tri < 0) {                                                         // raytracer.cpp:573-575
+            add = add + T * P.background;
+            mode = M_RETURN_UP;
+        } else {
+            shaded = 1;
+            const f3 ob = ray_o + ray_d * P.ray_bias;                               // raytracer.cpp:163
+            const f3 pos = ob + ray_d * hit.t;                                      // raytracer.cpp:121
+            const float4 r2 = sc.tris[3 * (size_t)hit.tri + 2];
+            const f3 gn = normalize3(mk3(r2.y, r2.z, r2.w));                        // raytracer.cpp:122
+            const float4 * sp = sc.shade + 4 * (size_t)hit.tri;
+            const float4 s0 = sp[0], s1 = sp[1], s2 = sp[2], s3 = sp[3];
+            const int m = as_i(s3.w);
+            mat = sc.materials[m];
+            const float alpha = mat.alpha;
+            if (mat.alpha <= 1.0f && alpha <= 0.05f) {                              // raytracer.cpp:443-453
+                next_o = pos + ray_d * P.ray_bias * 2.0f;
+                next_d = ray_d;
+                next_T = T;
+                next_level = level;
+                mode = M_ENTER;
+            } else {
+                const float bwy = hit.v, bwz = hit.w;
+                const float bwx = 1.0f - bwy - bwz;                                 // raytracer.cpp:120
+                f3 interp = mk3(0.0f, 0.0f, 0.0f);                                  // raytracer.cpp:464-467
+                interp = interp + mk3(s0.x, s0.y, s0.z) * bwx;
+                interp = interp + mk3(s0.w, s1.x, s1.y) * bwy;
+                interp = interp + mk3(s1.z, s1.w, s2.x) * bwz;
+                f.hit_n = normalize3(interp);
+                f.hit_pos = pos;
+                f.hit_p = pos + gn * P.ray_bias;                                    // raytracer.cpp:425
+                f.ray_d = ray_d;
+                f.T_in = T;
+                f.alpha = alpha;
+                f.mat = m;
+                const float object_reflectivity = 0.04f;                            // raytracer.cpp:538-541
+                const float fresnel = fresnel_amount(1.0f, mat.index_of_refraction, f.hit_n, ray_d);
+                const float w_reflect = (object_reflectivity + (1.0f - object_reflectivity) * fresnel);
+                f.w_diffuse = 1.0f - w_reflect;
+                f.stage = WF_STAGE_REFL;
+                f.idx = 0;
+                T_own = alpha < 1.0f ? T * alpha : T;                               // raytracer.cpp:551
+                add = add + T_own * (mk3(mat.ambient[0], mat.ambient[1], mat.ambient[2]) * 0.1f);   // raytracer.cpp:543
+                want_shadow = true;
+                mode = M_NEXT_CHILD;
+            }
+        }
+    }
+
+    // ---- shadow rays of this hit (raytracer.cpp:507-511, 378-411): radiance-if-unoccluded rides with the ray
+    for (unsigned int li = 0; li < sc.light_count; ++li) {
+        f3 so = mk3(0, 0, 0), sd = mk3(0, 0, 1), contrib = mk3(0, 0, 0);
+        float dist_sq = -1.0f;
+        int kind = WF_KIND_SHADOW_ANY;
+        if (want_shadow) {
+            const DevLight L = sc.lights[li];
+            f3 light_color = mk3(L.color[0], L.color[1], L.color[2]);
+            f3 light_vector;
+            if (L.type == 0) {
+                light_vector = mk3(L.facing[0], L.facing[1], L.facing[2]) * -1.0f;
+            } else {
+                const f3 lp = mk3(L.position[0], L.position[1], L.position[2]);
+                light_vector = normalize3(lp - f.hit_p);
+                const f3 dv = lp - f.hit_p;
+                dist_sq = dot3(dv, dv);
+                const float falloff_denom = (sqrtf(dist_sq) / L.falloff) + 1.0f;
+                light_color = light_color * (1.0f / (falloff_denom * falloff_denom));
+                kind = WF_KIND_SHADOW_DIST;
+            }
+            const float spec_cos = dot3(f.ray_d * -1.0f, reflect3(light_vector, f.hit_n));
+            const f3 dd = light_color * 2.0f * ref_max(0.0f, dot3(f.hit_n, light_vector));
+            const f3 ds = light_color * powf(ref_max(0.0f, spec_cos), mat.specular_intensity);
+            contrib = T_own * (dd * mk3(mat.diffuse[0], mat.diffuse[1], mat.diffuse[2]) * f.w_diffuse +
+                               ds * mk3(mat.specular[0], mat.specular[1], mat.specular[2]));
+            so = f.hit_p;
+            sd = light_vector;
+        }
+        const unsigned int slot = wave_append(B.counts + 1, want_shadow);
+        if (want_shadow) {
+            B.sq_o[slot] = make_float4(so.x, so.y, so.z, as_f((int)s));
+            B.sq_d[slot] = make_float4(sd.x, sd.y, sd.z, as_f(kind));
+            B.sq_c[slot] = make_float4(contrib.x, contrib.y, contrib.z, dist_sq);
+        }
+    }
+
+    // ---- step 2: walk the bounce tree in depth-first order until the next ray or the end of the sample ----
+    while (mode != M_DONE) {
+        if (mode == M_NEXT_CHILD) {                       // frame f at `level` spawns its next child, if any
+            const int iters = depth - level;
+            const DevMaterial fm = sc.materials[f.mat];
+            const f3 own = f.alpha < 1.0f ? f.T_in * f.alpha : f.T_in;
+            bool spawned = false;
+            if (f.stage == WF_STAGE_REFL) {                                         // raytracer.cpp:516-526
+                if (iters > 0 && (unsigned int)f.idx < P.reflection_samples) {
+                    const unsigned int series_i = (unsigned int)(rng_next<RING>(rng, ring, ring_stride) % 1024ull);
+                    const float4 ts = sc.diffuse_dirs[series_i];
+                    next_d = tangent_to_world(f.hit_n, mk3(ts.x, ts.y, ts.z));
+                    const float cw = ref_max(0.0f, dot3(f.hit_n, next_d));
+                    next_T = own * (mk3(fm.diffuse[0], fm.diffuse[1], fm.diffuse[2]) * f.w_diffuse * cw);
+                    next_o = f.hit_p;
+                    f.idx++;
+                    spawned = true;
+                } else {
+                    f.stage = WF_STAGE_SPEC;
+                    f.idx = 0;
+                }
+            }
+            if (!spawned && f.stage == WF_STAGE_SPEC) {                             // raytracer.cpp:528-535
+                if (iters > 0 && (unsigned int)f.idx < P.spec_samples) {
+                    const float4 ts = sc.spec_dirs[(size_t)f.mat * sc.spec_samples + (unsigned int)f.idx];
+                    next_d = tangent_to_world(f.hit_n, mk3(ts.x, ts.y, ts.z));
+                    const float cw = ref_max(0.0f, dot3(next_d, f.ray_d * -1.0f));
+                    next_T = own * (mk3(fm.specular[0], fm.specular[1], fm.specular[2]) * cw);
+                    next_o = f.hit_p;
+                    f.idx++;
+                    spawned = true;
+                } else {
+                    f.stage = WF_STAGE_ALPHA;
+                }
+            }
+            if (!spawned && f.stage == WF_STAGE_ALPHA) {                            // raytracer.cpp:547-552
+                f.stage = WF_STAGE_DONE;
+                if (f.alpha < 1.0f) {
+                    next_o = f.hit_pos + f.ray_d * P.ray_bias * 2.0f;
+                    next_d = f.ray_d;
+                    next_T = f.T_in * (1.0f - f.alpha);
+                    spawned = true;
+                }
+            }
+            if (!spawned) { f_held = false; mode = M_RETURN_UP; continue; }
+            f_held = true;                                // f (at `level`) stays in registers until the child's fate is known
+            next_level = level + 1;
+            mode = M_ENTER;
+        } else if (mode == M_ENTER) {                     // TraceRayColor entry (raytracer.cpp:415-420) for (next_*, next_level)
+            const int iters = depth - next_level;
+            bool dead = iters < 0;
+            if (!dead && next_level != 0) dead = rng_float01<RING>(rng, ring, ring_stride) < 0.5f;
+            if (!dead) {
+                // the child flies: park its parent frame if that still has children to spawn afterwards
+                if (f_held && f.stage != WF_STAGE_DONE) {
+                    wframe_save<RING>(B, level, s, f);
+                    pending |= 1u << level;
+                }
+                emit_closest = true;
+                mode = M_DONE;
+            } else if (f_held) {
+                mode = M_NEXT_CHILD;                      // that invocation returned black; same frame, next child
+            } else {
+                mode = M_RETURN_UP;
+            }
+        } else {                                          // M_RETURN_UP: resume the deepest parked frame
+            if (pending == 0u) { mode = M_DONE; break; }
+            level = 31 - __clz((int)pending);
+            pending &= ~(1u << level);
+            wframe_load<RING>(B, level, s, f);
+            mode = M_NEXT_CHILD;
+        }
+    }
+
+    // ---- outputs ------------------------------------------------------------------------------------------
+    if (live) {
+        if (add.x != 0.0f || add.y != 0.0f || add.z != 0.0f) {
+            float4 a = B.accum[s];
+            a.x += add.x; a.y += add.y; a.z += add.z;
+            B.accum[s] = a;
+        }
+        B.rng[s] = make_ulonglong2(rng.chain, rng.prev);
+        if (RING) B.rng_aux[s] = make_ulonglong2(rng.seed0, (u64)rng.k);
+    }
+    const unsigned int slot = wave_append(B.counts + 0, emit_closest);
+    if (emit_closest) {
+        B.rq_o[nxt][slot] = make_float4(next_o.x, next_o.y, next_o.z, as_f((int)s));
+        B.rq_d[nxt][slot] = make_float4(next_d.x, next_d.y, next_d.z, as_f(next_level | (int)(pending << 8)));
+        B.rq_t[nxt][slot] = make_float4(next_T.x, next_T.y, next_T.z, 0.0f);
+    }
+    atomicAdd(&ctr->shaded_hits, (unsigned long long)shaded);
+}
+
+}  // namespace prt

@@ -19,6 +19,7 @@
 #include "bvh_build.h"
 #include "dev_scene.h"
 #include "kernels_mega.h"
+#include "kernels_wave.h"
 
 using namespace prt;
 
@@ -87,6 +88,11 @@ struct prt_ctx {
     DevBuf<DevCounters> counters;
     DevBuf<unsigned long long> ring_ws;
     DevBuf<unsigned int> pixel_list;
+    // wavefront pipeline workspace
+    DevBuf<float4> wf_f4;                 // one slab carved into the float4 arrays of WaveBuffers
+    DevBuf<ulonglong2> wf_rng;
+    DevBuf<unsigned int> wf_counts;
+    int cu_count = 0;
 };
 
 namespace {
@@ -173,6 +179,97 @@ void launch_mega(prt_ctx * ctx, bool count, unsigned int grid, size_t lds, const
                            n_samples, ctx->sample_rgb.p, ctx->counters.p, ctx->ring_ws.p);
 }
 
+// The wavefront pipeline (kernels_wave.h): raygen, then rounds of {persistent trace, shade} until no ray is
+// left.  Queue sizes come back to the host once per round (8 bytes): they size the next launches, end the
+// loop and sum to ray_count (every queued ray is one TraceRay call, raytracer.cpp:161).
+int render_wavefront(prt_ctx * ctx, const DevCamera & cam, const DevParams & P, bool ring, bool count_visits,
+                     unsigned int n_samples, size_t lds, unsigned long long * ray_count, float * trace_ms, unsigned int * launches) {
+    hipStream_t stream = ctx->stream;
+    constexpr int BLOCK = 256;
+    const size_t N = n_samples;
+    const unsigned int levels = std::max(1u, P.bounce_depth);
+    const unsigned int fr4 = ring ? 5u : 4u;
+    const unsigned int n_lights = std::max(1u, ctx->scene.light_count);
+    // float4 slab: accum(aliases sample_rgb) is separate; frames + 2x3 closest queues + hits + 3 shadow arrays
+    const size_t f4_total = (size_t)levels * fr4 * N + 6 * N + N + 3 * N * n_lights;
+    HIP_TRY(ctx, ctx->wf_f4.ensure(f4_total));
+    HIP_TRY(ctx, ctx->wf_rng.ensure(ring ? 2 * N : N));
+    HIP_TRY(ctx, ctx->wf_counts.ensure(16));
+
+    WaveBuffers B;
+    memset(&B, 0, sizeof(B));
+    B.n_samples = n_samples;
+    B.accum = ctx->sample_rgb.p;
+    B.rng = ctx->wf_rng.p;
+    B.rng_aux = ring ? ctx->wf_rng.p + N : nullptr;
+    B.ring = ring ? ctx->ring_ws.p : nullptr;
+    float4 * f = ctx->wf_f4.p;
+    B.frames = f; f += (size_t)levels * fr4 * N;
+    for (int q = 0; q < 2; ++q) { B.rq_o[q] = f; f += N; B.rq_d[q] = f; f += N; B.rq_t[q] = f; f += N; }
+    B.hits = f; f += N;
+    B.sq_o = f; f += N * n_lights;
+    B.sq_d = f; f += N * n_lights;
+    B.sq_c = f; f += N * n_lights;
+    B.counts = ctx->wf_counts.p;
+
+    // persistent grid: as many blocks as are resident
+    int per_cu = 0;
+    hipError_t oe = count_visits ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace<BLOCK, true>, BLOCK, lds)
+                                 : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace<BLOCK, false>, BLOCK, lds);
+    if (oe != hipSuccess || per_cu < 1) per_cu = 2;
+    per_cu = std::min(per_cu, 8);
+    const unsigned int max_blocks = (unsigned int)per_cu * (unsigned int)ctx->cu_count;
+    const int keep_min = 40;
+    const int multi_light = ctx->scene.light_count > 1 ? 1 : 0;
+
+    const unsigned int gen_grid = (n_samples + 255) / 256;
+    if (ring) hipLaunchKernelGGL(k_raygen<true>, dim3(gen_grid), dim3(256), 0, stream, cam, P, B);
+    else hipLaunchKernelGGL(k_raygen<false>, dim3(gen_grid), dim3(256), 0, stream, cam, P, B);
+    HIP_TRY(ctx, hipGetLastError());
+
+    unsigned int n_closest = n_samples, n_shadow = 0;
+    unsigned long long rays = 0;
+    int cur = 0;
+    unsigned int n_launch = 0;
+    *trace_ms = 0.0f;
+    for (unsigned int round = 0; n_closest + n_shadow > 0; ++round) {
+        if (round > 100000) { ctx->error = "prt_render: wavefront loop did not terminate"; return -5; }
+        rays += (unsigned long long)n_closest + n_shadow;
+        HIP_TRY(ctx, hipMemsetAsync(B.counts, 0, 16, stream));
+        const unsigned int total = n_closest + n_shadow;
+        const unsigned int grid = std::max(1u, std::min(max_blocks, (total + BLOCK - 1) / BLOCK));
+        HIP_TRY(ctx, hipEventRecord(ctx->ev[2], stream));
+        if (count_visits)
+            hipLaunchKernelGGL((k_trace<BLOCK, true>), dim3(grid), dim3(BLOCK), lds, stream, ctx->scene, P, B, cur, n_closest, n_shadow,
+                               keep_min, multi_light, ctx->counters.p);
+        else
+            hipLaunchKernelGGL((k_trace<BLOCK, false>), dim3(grid), dim3(BLOCK), lds, stream, ctx->scene, P, B, cur, n_closest, n_shadow,
+                               keep_min, multi_light, ctx->counters.p);
+        HIP_TRY(ctx, hipGetLastError());
+        HIP_TRY(ctx, hipEventRecord(ctx->ev[3], stream));
+        n_launch++;
+        if (n_closest) {
+            const unsigned int sgrid = (n_closest + 255) / 256;
+            if (ring) hipLaunchKernelGGL(k_shade<true>, dim3(sgrid), dim3(256), 0, stream, ctx->scene, P, B, cur, n_closest, ctx->counters.p);
+            else hipLaunchKernelGGL(k_shade<false>, dim3(sgrid), dim3(256), 0, stream, ctx->scene, P, B, cur, n_closest, ctx->counters.p);
+            HIP_TRY(ctx, hipGetLastError());
+        }
+        unsigned int h[2] = { 0, 0 };
+        HIP_TRY(ctx, hipMemcpyAsync(h, B.counts, 8, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(ctx, hipStreamSynchronize(stream));
+        float ms = 0.0f;
+        HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3]));
+        *trace_ms += ms;
+        n_closest = n_closest ? h[0] : 0;
+        n_shadow = h[1];
+        if (n_closest > n_samples || n_shadow > n_samples * n_lights) { ctx->error = "prt_render: wavefront queue overflow"; return -6; }
+        cur ^= 1;
+    }
+    *ray_count = rays;
+    *launches = n_launch;
+    return 0;
+}
+
 // Renders the pixel set into d_out (device, float4 per pixel, packed in local pixel order).  Synchronous.
 int render_pixels(prt_ctx * ctx, const prt_camera * cam_in, const prt_params * params, uint32_t width, uint32_t height,
                   const PixelSet & px, float4 * d_out, prt_counters * counters) {
@@ -228,16 +325,22 @@ int render_pixels(prt_ctx * ctx, const prt_camera * cam_in, const prt_params * p
     HIP_TRY(ctx, ctx->counters.ensure(1));
     if (ring) HIP_TRY(ctx, ctx->ring_ws.ensure(n_samples64 * 16));
 
-    // LDS traversal stack: one int per BVH level per lane
+    // LDS traversal stack: one int per BVH level per lane (+ sentinel)
     constexpr int BLOCK = 256;
-    const unsigned int stack_entries = ctx->info.bvh_max_depth + 2;   // + sentinel
+    const unsigned int stack_entries = ctx->info.bvh_max_depth + 2;
     const size_t lds = (size_t)stack_entries * BLOCK * sizeof(int);
     if (lds > 64 * 1024) { ctx->error = "prt_render: BVH too deep for the LDS traversal stack"; return -3; }
+
+    unsigned int pipeline = params->pipeline & PRT_PIPELINE_MASK;
+    if (pipeline == PRT_PIPELINE_DEFAULT) pipeline = PRT_PIPELINE_WAVEFRONT;
+    if (pipeline != PRT_PIPELINE_MEGAKERNEL && pipeline != PRT_PIPELINE_WAVEFRONT) { ctx->error = "prt_render: unknown pipeline"; return -1; }
 
     HIP_TRY(ctx, hipMemsetAsync(ctx->counters.p, 0, sizeof(DevCounters), stream));
     HIP_TRY(ctx, hipEventRecord(ctx->ev[0], stream));
     unsigned int launches = 0;
-    if (n_samples) {
+    unsigned long long host_ray_count = 0;
+    float trace_ms_accum = 0.0f;
+    if (n_samples && pipeline == PRT_PIPELINE_MEGAKERNEL) {
         const unsigned int grid = (n_samples + BLOCK - 1) / BLOCK;
         HIP_TRY(ctx, hipEventRecord(ctx->ev[2], stream));
         if (!ring && levels <= 3) launch_mega<3, false>(ctx, count_visits, grid, lds, cam, P, n_samples);
@@ -248,6 +351,11 @@ int render_pixels(prt_ctx * ctx, const prt_camera * cam_in, const prt_params * p
         hipLaunchKernelGGL(k_resolve, dim3((px.n_pixels + 255) / 256), dim3(256), 0, stream, ctx->sample_rgb.p, d_out, px.n_pixels, P.spp);
         HIP_TRY(ctx, hipGetLastError());
         launches = 1;
+    } else if (n_samples) {
+        int rc = render_wavefront(ctx, cam, P, ring, count_visits, n_samples, lds, &host_ray_count, &trace_ms_accum, &launches);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_resolve, dim3((px.n_pixels + 255) / 256), dim3(256), 0, stream, ctx->sample_rgb.p, d_out, px.n_pixels, P.spp);
+        HIP_TRY(ctx, hipGetLastError());
     }
     HIP_TRY(ctx, hipEventRecord(ctx->ev[1], stream));
     HIP_TRY(ctx, hipEventSynchronize(ctx->ev[1]));
@@ -257,7 +365,12 @@ int render_pixels(prt_ctx * ctx, const prt_camera * cam_in, const prt_params * p
         HIP_TRY(ctx, hipMemcpy(&h, ctx->counters.p, sizeof(h), hipMemcpyDeviceToHost));
         float ms = 0.0f, trace_ms = 0.0f;
         HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
-        if (launches) HIP_TRY(ctx, hipEventElapsedTime(&trace_ms, ctx->ev[2], ctx->ev[3]));
+        if (pipeline == PRT_PIPELINE_MEGAKERNEL) {
+            if (launches) HIP_TRY(ctx, hipEventElapsedTime(&trace_ms, ctx->ev[2], ctx->ev[3]));
+        } else {
+            trace_ms = trace_ms_accum;
+            h.ray_count = host_ray_count;
+        }
         memset(counters, 0, sizeof(*counters));
         counters->ray_count = h.ray_count;
         counters->node_visits = h.node_visits;
@@ -296,6 +409,11 @@ prt_ctx * prt_create(int device_id) {
     }
     prt_ctx * ctx = new prt_ctx;
     ctx->device = device_id;
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) ctx->cu_count = prop.multiProcessorCount;
+        if (ctx->cu_count <= 0) ctx->cu_count = 256;
+    }
     memset(&ctx->scene, 0, sizeof(ctx->scene));
     memset(&ctx->info, 0, sizeof(ctx->info));
     e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
@@ -314,7 +432,7 @@ void prt_destroy(prt_ctx * ctx) {
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     ctx->nodes.release(); ctx->tris.release(); ctx->shade.release(); ctx->diffuse_dirs.release(); ctx->spec_dirs.release();
     ctx->tri_rank.release(); ctx->materials.release(); ctx->lights.release();
-    ctx->sample_rgb.release(); ctx->frame_out.release(); ctx->counters.release(); ctx->ring_ws.release(); ctx->pixel_list.release();
+    ctx->sample_rgb.release(); ctx->frame_out.release(); ctx->counters.release(); ctx->ring_ws.release(); ctx->pixel_list.release(); ctx->wf_f4.release(); ctx->wf_rng.release(); ctx->wf_counts.release();
     for (int i = 0; i < 4; ++i) if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;

@@ -28,9 +28,13 @@ def _render_fixture(gpu_renderer_factory, name, pipeline=0):
     return g, img, ctr
 
 
+PIPELINES = {"megakernel": 1, "wavefront": 2}
+
+
+@pytest.mark.parametrize("pipeline", sorted(PIPELINES))
 @pytest.mark.parametrize("name", SMALL + BIG)
-def test_matches_reference_golden(gpu_renderer_factory, name):
-    g, img, ctr = _render_fixture(gpu_renderer_factory, name)
+def test_matches_reference_golden(gpu_renderer_factory, name, pipeline):
+    g, img, ctr = _render_fixture(gpu_renderer_factory, name, PIPELINES[pipeline])
     ref = g["rgb"]
     assert img.shape[:2] == ref.shape[:2]
     assert np.all(img[:, :, 3] == 1.0)
