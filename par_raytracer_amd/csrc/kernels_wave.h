@@ -64,6 +64,29 @@ PRT_D unsigned int wave_append(unsigned int * counter, bool pred) {
     return base + prefix;
 }
 
+// Workgroup-aggregated append: ONE atomic per workgroup and queue.  Same-address atomics retire at ~90 per
+// microsecond chip-wide (MI355X_MICROARCH.md "dequeue"), so per-wave appends from 260k waves cost
+// milliseconds; per-workgroup appends from 1024-thread groups cost ~0.2 ms.  Every thread of the block must
+// call this (no early exits).  NW = waves per block.
+template <int NW>
+PRT_D unsigned int block_append(unsigned int * counter, bool pred, unsigned int * s_cnt /* [NW + 1] LDS */) {
+    const unsigned long long mask = __ballot(pred);
+    const unsigned int n = (unsigned int)__popcll(mask);
+    const unsigned int prefix = __builtin_amdgcn_mbcnt_hi((unsigned int)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)mask, 0u));
+    const unsigned int wave = threadIdx.x >> 6;
+    if (lane_id() == 0) s_cnt[wave] = n;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned int total = 0;
+        for (int w = 0; w < NW; ++w) { const unsigned int c = s_cnt[w]; s_cnt[w] = total; total += c; }
+        s_cnt[NW] = total ? atomicAdd(counter, total) : 0u;
+    }
+    __syncthreads();
+    const unsigned int slot = s_cnt[NW] + s_cnt[wave] + prefix;
+    __syncthreads();
+    return slot;
+}
+
 // ---------------------------------------------------------------------------------------------------------
 template <bool RING>
 __global__ __launch_bounds__(256) void k_raygen(DevCamera cam, DevParams P, WaveBuffers B) {
@@ -87,7 +110,8 @@ __global__ __launch_bounds__(256) void k_raygen(DevCamera cam, DevParams P, Wave
 // Persistent traversal.  grid = resident blocks; dynamic LDS = stack_entries * BLOCK * 4.
 template <int BLOCK, bool COUNT>
 __global__ __launch_bounds__(BLOCK) void k_trace(DevScene sc, DevParams P, WaveBuffers B, int cur, unsigned int n_closest,
-                                                  unsigned int n_shadow, int keep_min, int multi_light, DevCounters * ctr) {
+                                                  unsigned int n_shadow, int keep_min, unsigned int chunk, int multi_light,
+                                                  DevCounters * ctr) {
     extern __shared__ int s_stack[];
     int * stack = s_stack + threadIdx.x;
     const unsigned int total = n_closest + n_shadow;
@@ -105,19 +129,30 @@ __global__ __launch_bounds__(BLOCK) void k_trace(DevScene sc, DevParams P, WaveB
     TraceStats st;
     st.nodes = st.tris = 0;
 
+    unsigned int chunk_next = 0, chunk_end = 0;      // wave-uniform: rays reserved for this wave, not yet handed out
     for (;;) {
-        // ---- refill idle lanes
+        // ---- refill idle lanes from the wave's reserved chunk; reserve a new chunk when it runs dry.
+        // One atomic per CHUNK rays, not per refill: the head word is a single address (~90 atomics/us chip-wide).
         const unsigned long long idle = __ballot(ray < 0);
-        if (!exhausted && idle != 0ull) {
-            const unsigned int n = (unsigned int)__popcll(idle);
-            unsigned int base = 0;
-            if (lane == 0) base = atomicAdd(head, n);
-            base = (unsigned int)__shfl((int)base, 0);
-            if (base + n >= total) exhausted = true;
-            if (ray < 0) {
+        if (idle != 0ull && !(exhausted && chunk_next == chunk_end)) {
+            if (chunk_next == chunk_end) {
+                unsigned int base = 0;
+                if (lane == 0) base = atomicAdd(head, chunk);
+                base = (unsigned int)__shfl((int)base, 0);
+                if (base >= total) {
+                    exhausted = true;
+                } else {
+                    chunk_next = base;
+                    chunk_end = base + chunk < total ? base + chunk : total;
+                }
+            }
+            const unsigned int avail = chunk_end - chunk_next;
+            if (avail) {
                 const unsigned int prefix = __builtin_amdgcn_mbcnt_hi((unsigned int)(idle >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)idle, 0u));
-                const unsigned int idx = base + prefix;
-                if (idx < total) {
+                const unsigned int n_idle = (unsigned int)__popcll(idle);
+                const unsigned int take = n_idle < avail ? n_idle : avail;
+                if (ray < 0 && prefix < take) {
+                    const unsigned int idx = chunk_next + prefix;
                     float4 ro, rd;
                     int kind;
                     if (idx < n_closest) {
@@ -135,16 +170,16 @@ __global__ __launch_bounds__(BLOCK) void k_trace(DevScene sc, DevParams P, WaveB
                     const f3 d = mk3(rd.x, rd.y, rd.z);
                     const f3 ob = mk3(ro.x, ro.y, ro.z) + d * P.ray_bias;          // raytracer.cpp:163
                     trav_init<BLOCK>(r, ob, d, kind == WF_KIND_SHADOW_ANY ? TRACE_ANY : TRACE_CLOSEST, P.box_pad, stack);
-                    r.kind = kind == WF_KIND_SHADOW_ANY ? TRACE_ANY : TRACE_CLOSEST;
                     payload.w = kind == WF_KIND_CLOSEST ? 0.0f : (kind == WF_KIND_SHADOW_ANY ? -1.0f : payload.w);
                     ray = (int)idx;
                 }
+                chunk_next += take;
             }
         }
         if (__ballot(ray >= 0) == 0ull) break;
 
         // ---- traverse until fewer than `leave_below` lanes of the wave are still busy
-        const int leave_below = exhausted ? 1 : keep_min;
+        const int leave_below = (exhausted && chunk_next == chunk_end) ? 1 : keep_min;
         while (ray >= 0) {
             while (r.node >= 0) trav_node_step<BLOCK, COUNT>(sc, r, stack, st);
             bool fin = r.node == TRAV_SENTINEL;
@@ -219,10 +254,11 @@ PRT_D void wframe_load(const WaveBuffers & B, int level, unsigned int s, WFrame 
 }
 
 // One lane per closest-hit result of queue `cur`; appends to queue `cur ^ 1` and to the shadow queue.
-template <bool RING>
-__global__ __launch_bounds__(256) void k_shade(DevScene sc, DevParams P, WaveBuffers B, int cur, unsigned int n_closest,
-                                               DevCounters * ctr) {
-    const unsigned int i = blockIdx.x * blockDim.x + threadIdx.x;
+template <bool RING, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, DevParams P, WaveBuffers B, int cur, unsigned int n_closest,
+                                                 DevCounters * ctr) {
+    __shared__ unsigned int s_cnt[BLOCK / 64 + 1];
+    const unsigned int i = blockIdx.x * BLOCK + threadIdx.x;
     const bool live = i < n_closest;
     const int depth = (int)P.bounce_depth;
     const int nxt = cur ^ 1;
@@ -344,7 +380,7 @@ __global__ __launch_bounds__(256) void k_shade(DevScene sc, DevParams P, WaveBuf
             so = f.hit_p;
             sd = light_vector;
         }
-        const unsigned int slot = wave_append(B.counts + 1, want_shadow);
+        const unsigned int slot = block_append<BLOCK / 64>(B.counts + 1, want_shadow, s_cnt);
         if (want_shadow) {
             B.sq_o[slot] = make_float4(so.x, so.y, so.z, as_f((int)s));
             B.sq_d[slot] = make_float4(sd.x, sd.y, sd.z, as_f(kind));
@@ -436,13 +472,23 @@ __global__ __launch_bounds__(256) void k_shade(DevScene sc, DevParams P, WaveBuf
         B.rng[s] = make_ulonglong2(rng.chain, rng.prev);
         if (RING) B.rng_aux[s] = make_ulonglong2(rng.seed0, (u64)rng.k);
     }
-    const unsigned int slot = wave_append(B.counts + 0, emit_closest);
+    const unsigned int slot = block_append<BLOCK / 64>(B.counts + 0, emit_closest, s_cnt);
     if (emit_closest) {
         B.rq_o[nxt][slot] = make_float4(next_o.x, next_o.y, next_o.z, as_f((int)s));
         B.rq_d[nxt][slot] = make_float4(next_d.x, next_d.y, next_d.z, as_f(next_level | (int)(pending << 8)));
         B.rq_t[nxt][slot] = make_float4(next_T.x, next_T.y, next_T.z, 0.0f);
     }
-    atomicAdd(&ctr->shaded_hits, (unsigned long long)shaded);
+    // shaded-hit count: one atomic per workgroup
+    {
+        const unsigned int n = (unsigned int)__popcll(__ballot(shaded != 0));
+        if (lane_id() == 0) s_cnt[threadIdx.x >> 6] = n;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned int total = 0;
+            for (int w = 0; w < BLOCK / 64; ++w) total += s_cnt[w];
+            if (total) atomicAdd(&ctr->shaded_hits, (unsigned long long)total);
+        }
+    }
 }
 
 }  // namespace prt

@@ -238,20 +238,24 @@ int render_wavefront(prt_ctx * ctx, const DevCamera & cam, const DevParams & P, 
         HIP_TRY(ctx, hipMemsetAsync(B.counts, 0, 16, stream));
         const unsigned int total = n_closest + n_shadow;
         const unsigned int grid = std::max(1u, std::min(max_blocks, (total + BLOCK - 1) / BLOCK));
+        // rays reserved per head atomic: ~1/8 of a wave's fair share, whole waves, 64..512
+        unsigned int chunk = total / (grid * (BLOCK / 64) * 8u);
+        chunk = std::max(64u, std::min(512u, (chunk / 64u) * 64u));
         HIP_TRY(ctx, hipEventRecord(ctx->ev[2], stream));
         if (count_visits)
             hipLaunchKernelGGL((k_trace<BLOCK, true>), dim3(grid), dim3(BLOCK), lds, stream, ctx->scene, P, B, cur, n_closest, n_shadow,
-                               keep_min, multi_light, ctx->counters.p);
+                               keep_min, chunk, multi_light, ctx->counters.p);
         else
             hipLaunchKernelGGL((k_trace<BLOCK, false>), dim3(grid), dim3(BLOCK), lds, stream, ctx->scene, P, B, cur, n_closest, n_shadow,
-                               keep_min, multi_light, ctx->counters.p);
+                               keep_min, chunk, multi_light, ctx->counters.p);
         HIP_TRY(ctx, hipGetLastError());
         HIP_TRY(ctx, hipEventRecord(ctx->ev[3], stream));
         n_launch++;
         if (n_closest) {
-            const unsigned int sgrid = (n_closest + 255) / 256;
-            if (ring) hipLaunchKernelGGL(k_shade<true>, dim3(sgrid), dim3(256), 0, stream, ctx->scene, P, B, cur, n_closest, ctx->counters.p);
-            else hipLaunchKernelGGL(k_shade<false>, dim3(sgrid), dim3(256), 0, stream, ctx->scene, P, B, cur, n_closest, ctx->counters.p);
+            constexpr int SB = 1024;
+            const unsigned int sgrid = (n_closest + SB - 1) / SB;
+            if (ring) hipLaunchKernelGGL((k_shade<true, SB>), dim3(sgrid), dim3(SB), 0, stream, ctx->scene, P, B, cur, n_closest, ctx->counters.p);
+            else hipLaunchKernelGGL((k_shade<false, SB>), dim3(sgrid), dim3(SB), 0, stream, ctx->scene, P, B, cur, n_closest, ctx->counters.p);
             HIP_TRY(ctx, hipGetLastError());
         }
         unsigned int h[2] = { 0, 0 };
