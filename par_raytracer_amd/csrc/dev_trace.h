@@ -77,8 +77,8 @@ PRT_D bool tri_test(f3 o, f3 d, f3 qp, f3 a, f3 ab, f3 ac, f3 n, float best_t, f
 struct TravRay {
     f3 o, d;                          // origin ALREADY biased by direction * ray_bias (raytracer.cpp:163), direction
     float ix, iy, iz;                 // 1 / direction, components clamped away from 0
-    float olx, oly, olz;              // o + pad: the lo planes of the widened boxes are seen from here
-    float ohx, ohy, ohz;              // o - pad: the hi planes
+    float plx, ply, plz;              // (o + pad) / direction: entry parameter offset of the widened lo planes
+    float phx, phy, phz;              // (o - pad) / direction: same for the hi planes
     HitRec best;
     unsigned int best_rank;
     int node, sp, kind;
@@ -96,8 +96,8 @@ PRT_D void trav_init(TravRay & r, f3 o, f3 d, int kind, float pad, int * stack) 
     float dy = fabsf(d.y) < tiny ? (d.y < 0.0f ? -tiny : tiny) : d.y;
     float dz = fabsf(d.z) < tiny ? (d.z < 0.0f ? -tiny : tiny) : d.z;
     r.ix = 1.0f / dx; r.iy = 1.0f / dy; r.iz = 1.0f / dz;
-    r.olx = o.x + pad; r.oly = o.y + pad; r.olz = o.z + pad;
-    r.ohx = o.x - pad; r.ohy = o.y - pad; r.ohz = o.z - pad;
+    r.plx = (o.x + pad) * r.ix; r.ply = (o.y + pad) * r.iy; r.plz = (o.z + pad) * r.iz;
+    r.phx = (o.x - pad) * r.ix; r.phy = (o.y - pad) * r.iy; r.phz = (o.z - pad) * r.iz;
     r.best.t = 3.402823466e+38f;
     r.best.v = r.best.w = 0.0f;
     r.best.tri = -1;
@@ -109,21 +109,23 @@ PRT_D void trav_init(TravRay & r, f3 o, f3 d, int kind, float pad, int * stack) 
 }
 
 // One internal node: fetch 64 B, test both child boxes, descend into the nearer hit child, push the other.
+// The slab test is the one place that uses FMA (plane * 1/d - origin/d in one rounding): it only has to be
+// conservative, and the boxes are widened by `pad` >> its rounding error.  6 FMA + 10 min/max per box.
 template <int BLOCK, bool COUNT>
 PRT_D void trav_node_step(const DevScene & sc, TravRay & r, int * stack, TraceStats & st) {
     const float4 * np = sc.nodes + 4 * (size_t)r.node;
     const float4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
     if (COUNT) st.nodes++;
-    float ax = (n0.x - r.olx) * r.ix, bx = (n0.y - r.ohx) * r.ix;
-    float ay = (n0.z - r.oly) * r.iy, by = (n0.w - r.ohy) * r.iy;
-    float az = (n2.x - r.olz) * r.iz, bz = (n2.y - r.ohz) * r.iz;
-    float tmin0 = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
-    float tmax0 = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), r.best.t));
-    float cx = (n1.x - r.olx) * r.ix, ex = (n1.y - r.ohx) * r.ix;
-    float cy = (n1.z - r.oly) * r.iy, ey = (n1.w - r.ohy) * r.iy;
-    float cz = (n2.z - r.olz) * r.iz, ez = (n2.w - r.ohz) * r.iz;
-    float tmin1 = fmaxf(fmaxf(fminf(cx, ex), fminf(cy, ey)), fmaxf(fminf(cz, ez), 0.0f));
-    float tmax1 = fminf(fminf(fmaxf(cx, ex), fmaxf(cy, ey)), fminf(fmaxf(cz, ez), r.best.t));
+    const float ax = __builtin_fmaf(n0.x, r.ix, -r.plx), bx = __builtin_fmaf(n0.y, r.ix, -r.phx);
+    const float ay = __builtin_fmaf(n0.z, r.iy, -r.ply), by = __builtin_fmaf(n0.w, r.iy, -r.phy);
+    const float az = __builtin_fmaf(n2.x, r.iz, -r.plz), bz = __builtin_fmaf(n2.y, r.iz, -r.phz);
+    const float tmin0 = fmaxf(fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz)), 0.0f);
+    const float tmax0 = fminf(fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz)), r.best.t);
+    const float cx = __builtin_fmaf(n1.x, r.ix, -r.plx), ex = __builtin_fmaf(n1.y, r.ix, -r.phx);
+    const float cy = __builtin_fmaf(n1.z, r.iy, -r.ply), ey = __builtin_fmaf(n1.w, r.iy, -r.phy);
+    const float cz = __builtin_fmaf(n2.z, r.iz, -r.plz), ez = __builtin_fmaf(n2.w, r.iz, -r.phz);
+    const float tmin1 = fmaxf(fmaxf(fmaxf(fminf(cx, ex), fminf(cy, ey)), fminf(cz, ez)), 0.0f);
+    const float tmax1 = fminf(fminf(fminf(fmaxf(cx, ex), fmaxf(cy, ey)), fmaxf(cz, ez)), r.best.t);
     const bool h0 = tmin0 <= tmax0, h1 = tmin1 <= tmax1;
     int l0 = as_i(n3.x), l1 = as_i(n3.y);
     if (h0 && h1) {
