@@ -253,4 +253,171 @@ void build_bvh2(const float * verts, uint32_t n_tris, uint32_t leaf_max, uint32_
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// 4-wide, quantised
+// ---------------------------------------------------------------------------------------------------------
+namespace {
+
+struct Wide {
+    uint32_t tmp[4];        // TmpNode indices of the children
+    uint32_t n;
+};
+
+inline uint32_t float_bits(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    return u;
+}
+
+}  // namespace
+
+void build_bvh4q(const float * verts, uint32_t n_tris, uint32_t leaf_max, uint32_t threads, Bvh4Result * out) {
+    *out = Bvh4Result();
+    if (leaf_max < 1) leaf_max = 1;
+    if (leaf_max > 4) leaf_max = 4;
+    Builder b;
+    b.leaf_max = leaf_max;
+    b.prims.resize(n_tris);
+    Box scene;
+    scene.reset();
+    for (uint32_t i = 0; i < n_tris; ++i) {
+        Prim & p = b.prims[i];
+        p.box.reset();
+        p.box.grow(verts + 9 * (size_t)i);
+        p.box.grow(verts + 9 * (size_t)i + 3);
+        p.box.grow(verts + 9 * (size_t)i + 6);
+        for (int a = 0; a < 3; ++a) p.c[a] = 0.5f * p.box.lo[a] + 0.5f * p.box.hi[a];
+        p.id = i;
+        scene.grow(p.box);
+    }
+    for (int a = 0; a < 3; ++a) { out->scene_lo[a] = n_tris ? scene.lo[a] : 0.0f; out->scene_hi[a] = n_tris ? scene.hi[a] : 0.0f; }
+    b.pool.resize(n_tris ? 2 * (size_t)n_tris : 1);
+    b.next_node = 1;
+    b.max_depth = 0;
+    b.threads_free = (int)(threads > 1 ? threads - 1 : 0);
+    if (n_tris) {
+        b.build(0, 0, n_tris, 0);
+    } else {
+        TmpNode & n = b.pool[0];
+        n.box.reset();
+        for (int a = 0; a < 3; ++a) n.box.lo[a] = n.box.hi[a] = 0.0f;
+        n.left = n.right = -1;
+        n.first = 0;
+        n.count = 1;          // the all-zero dummy triangle the uploader always allocates
+        n.depth = 0;
+    }
+    out->tri_order.resize(n_tris);
+    for (uint32_t i = 0; i < n_tris; ++i) out->tri_order[i] = b.prims[i].id;
+
+    auto is_leaf = [&](uint32_t t) { return b.pool[t].left < 0; };
+    auto leaf_link = [&](uint32_t t) -> int32_t { return ~(int32_t)((b.pool[t].first << 2) | (b.pool[t].count - 1)); };
+
+    // ---- collapse: each wide node adopts up to 4 binary-tree descendants, opening the largest box first
+    struct Item { uint32_t tmp; uint32_t slot; uint32_t depth; };
+    std::vector<Wide> wide;
+    std::vector<Item> work;
+    auto make_wide = [&](uint32_t root_tmp) -> Wide {
+        Wide w;
+        w.n = 0;
+        if (is_leaf(root_tmp)) { w.tmp[w.n++] = root_tmp; return w; }
+        w.tmp[w.n++] = (uint32_t)b.pool[root_tmp].left;
+        w.tmp[w.n++] = (uint32_t)b.pool[root_tmp].right;
+        while (w.n < 4) {
+            int best = -1;
+            float best_area = -1.0f;
+            for (uint32_t k = 0; k < w.n; ++k) {
+                if (is_leaf(w.tmp[k])) continue;
+                float a = b.pool[w.tmp[k]].box.half_area();
+                if (a > best_area) { best_area = a; best = (int)k; }
+            }
+            if (best < 0) break;
+            uint32_t t = w.tmp[best];
+            w.tmp[best] = (uint32_t)b.pool[t].left;
+            w.tmp[w.n++] = (uint32_t)b.pool[t].right;
+        }
+        return w;
+    };
+
+    // BFS numbering: the top of the tree is contiguous (cache / LDS friendly), children of a node are adjacent
+    std::vector<uint32_t> depth_of;
+    work.push_back(Item{ 0u, 0u, 1u });
+    wide.push_back(make_wide(0));
+    depth_of.push_back(1);
+    std::vector<int32_t> links;           // 4 per wide node
+    links.assign(4, 0);
+    uint32_t max_depth = 1;
+    for (size_t head = 0; head < work.size(); ++head) {
+        const Item it = work[head];
+        const Wide w = wide[it.slot];
+        for (uint32_t k = 0; k < 4; ++k) {
+            int32_t link;
+            if (k >= w.n) {
+                link = (int32_t)0x80000001;                  // empty slot (never a valid leaf or node)
+            } else if (is_leaf(w.tmp[k])) {
+                link = leaf_link(w.tmp[k]);
+            } else {
+                uint32_t slot = (uint32_t)wide.size();
+                wide.push_back(make_wide(w.tmp[k]));
+                links.resize(links.size() + 4, 0);
+                work.push_back(Item{ w.tmp[k], slot, it.depth + 1 });
+                if (it.depth + 1 > max_depth) max_depth = it.depth + 1;
+                link = (int32_t)slot;
+            }
+            links[(size_t)it.slot * 4 + k] = link;
+        }
+    }
+
+    // ---- quantise
+    const uint32_t n_nodes = (uint32_t)wide.size();
+    out->nodes.assign((size_t)n_nodes * 16, 0u);
+    for (uint32_t s = 0; s < n_nodes; ++s) {
+        const Wide & w = wide[s];
+        Box u;
+        u.reset();
+        for (uint32_t k = 0; k < w.n; ++k) u.grow(b.pool[w.tmp[k]].box);
+        uint32_t * d = &out->nodes[(size_t)s * 16];
+        uint32_t ebyte[3];
+        double scale[3];
+        for (int a = 0; a < 3; ++a) {
+            double ext = (double)u.hi[a] - (double)u.lo[a];
+            int e = -100;
+            if (ext > 0.0) {
+                e = (int)std::ceil(std::log2(ext / 255.0));
+                while (std::ldexp(255.0, e) < ext) ++e;
+                if (e < -100) e = -100;
+            }
+            if (e > 100) e = 100;
+            ebyte[a] = (uint32_t)(e + 127);
+            scale[a] = std::ldexp(1.0, e);
+            d[a] = float_bits(u.lo[a]);
+        }
+        d[3] = ebyte[0] | (ebyte[1] << 8) | (ebyte[2] << 16) | (w.n << 24);
+        for (uint32_t k = 0; k < 4; ++k) {
+            uint32_t qlo[3] = { 255, 255, 255 }, qhi[3] = { 0, 0, 0 };      // empty slot: inverted (and masked by its link)
+            if (k < w.n) {
+                const Box & cb = b.pool[w.tmp[k]].box;
+                for (int a = 0; a < 3; ++a) {
+                    double lo = std::floor(((double)cb.lo[a] - (double)u.lo[a]) / scale[a]);
+                    double hi = std::ceil(((double)cb.hi[a] - (double)u.lo[a]) / scale[a]);
+                    if (lo < 0.0) lo = 0.0;
+                    if (lo > 255.0) lo = 255.0;
+                    if (hi < 0.0) hi = 0.0;
+                    if (hi > 255.0) hi = 255.0;
+                    qlo[a] = (uint32_t)lo;
+                    qhi[a] = (uint32_t)hi;
+                }
+            }
+            for (int a = 0; a < 3; ++a) {
+                d[4 + a] |= qlo[a] << (8 * k);
+                d[7 + a] |= qhi[a] << (8 * k);
+            }
+            d[10 + k] = (uint32_t)links[(size_t)s * 4 + k];
+        }
+    }
+    out->node_count = n_nodes;
+    out->max_depth = max_depth;
+    out->stack_bound = 3 * max_depth + 2;
+}
+
 }  // namespace prt

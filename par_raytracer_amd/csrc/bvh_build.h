@@ -22,4 +22,17 @@ struct BvhResult {
 // verts: 9 floats per triangle (a, b, c).  leaf_max <= 4 (2 bits in the leaf link).
 void build_bvh2(const float * verts, uint32_t n_tris, uint32_t leaf_max, uint32_t threads, BvhResult * out);
 
+// 4-wide BVH with child boxes quantised to 8 bits per plane relative to the node's own box: 64 B per node
+// (layout in dev_scene.h).  Built by collapsing the binned-SAH binary tree (largest-area child first) and
+// rounding every child box OUTWARD onto the node's 2^e grid, so it stays conservative.
+struct Bvh4Result {
+    std::vector<uint32_t> nodes;       // 16 dwords (64 B) per node
+    std::vector<uint32_t> tri_order;
+    uint32_t node_count = 0;
+    uint32_t max_depth = 0;            // in 4-wide nodes
+    uint32_t stack_bound = 0;          // entries a traversal can ever hold: 3 per level + sentinel
+    float scene_lo[3] = { 0, 0, 0 }, scene_hi[3] = { 0, 0, 0 };
+};
+void build_bvh4q(const float * verts, uint32_t n_tris, uint32_t leaf_max, uint32_t threads, Bvh4Result * out);
+
 }  // namespace prt

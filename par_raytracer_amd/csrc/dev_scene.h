@@ -4,11 +4,16 @@
 // scene.h:22-36, mesh.h:40-57).  For the device everything is flattened at upload into dense,
 // 16-byte-aligned records that one lane fetches with dwordx4 loads and no dependent indirection:
 //
-//   nodes      BVH2, 64 B per node = 4 x float4 (Aila-Laine layout): both children's boxes + both child
-//              links, so one node visit = one 64 B fetch that decides about two subtrees
-//                n0 = (c0.lo.x, c0.hi.x, c0.lo.y, c0.hi.y)   n1 = (c1.lo.x, c1.hi.x, c1.lo.y, c1.hi.y)
-//                n2 = (c0.lo.z, c0.hi.z, c1.lo.z, c1.hi.z)   n3 = (link0, link1, -, -) as int bits
-//              link >= 0: internal node index; link < 0: leaf, ~link = (first_tri << 2) | (count - 1)
+//   nodes      4-wide BVH, 64 B per node = 16 dwords, child boxes quantised to 8 bits per plane on the
+//              node's own power-of-two grid (plane = origin + q * 2^e, rounded outward at build time):
+//                d0-2  origin xyz (float: lo corner of the union of the children)
+//                d3    e_x+127 | (e_y+127) << 8 | (e_z+127) << 16 | child_count << 24
+//                d4-6  lo planes x / y / z, one byte per child      d7-9  hi planes x / y / z
+//                d10-13 child links                                 d14-15 unused
+//              link >= 0: node index; link < 0: leaf, ~link = (first_tri << 2) | (count - 1).
+//              One node visit = one 64 B fetch that decides about four subtrees: half the bytes per ray of
+//              an uncompressed binary node with the same fetch size, and half the dependent fetches.
+//              Nodes are numbered breadth-first, so the top of the tree is one contiguous block.
 //   tris       48 B per triangle = 3 x float4, in BVH leaf order, un-indexed and pre-differenced:
 //                (a.xyz, ab.x) (ab.yz, ac.xy) (ac.z, n.xyz)   with ab = b-a, ac = c-a, n = Cross(ab, ac)
 //              computed on the host with the reference's float expressions (raytracer.cpp:85-91), so the
@@ -83,6 +88,9 @@ struct DevParams {
     //   otherwise: row-blocks of shard_block_rows rows, block b of this rank = image block b*nranks + rank
     unsigned int first_pixel, shard_block_rows, shard_rank, shard_nranks;
     const unsigned int * pixel_list;   // explicit pixel ids (prt_render_pixel_list) or NULL
+    // traversal stack: LDS entries per lane, then a global spill column per lane (dev_trace.h TravStack)
+    int * stack_spill;
+    unsigned int stack_lds_entries, stack_spill_stride;
 };
 
 PRT_HD unsigned int pixel_of_local(const DevParams & P, unsigned int lp) {

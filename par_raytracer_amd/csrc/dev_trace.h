@@ -1,4 +1,4 @@
-// dev_trace.h - TraceRay for the device: BVH2 traversal + the reference's triangle test.
+// dev_trace.h - TraceRay for the device: quantised 4-wide BVH traversal + the reference's triangle test.
 //
 // Replaces TraceRay / IntersectRaySphere / IntersectRayMesh / IntersectRayTriangle
 // (raytracer.cpp:32-60, 82-232).  What must be preserved is the RESULT of the reference's traversal:
@@ -16,7 +16,8 @@
 // where visit order is observable (SURVEY.md §7.2 "Tie-breaking").
 //
 // Traversal stack: per-lane column of a workgroup LDS array (entry e of lane l at stack[e*BLOCK + l],
-// so a wave's push/pop of one level is one conflict-free ds_write/ds_read_b32).
+// so a wave's push/pop of one level is one conflict-free ds_write/ds_read_b32), with a global spill column
+// behind it for the (never observed) case of a ray holding more entries than the LDS column has.
 #pragma once
 
 #include "dev_scene.h"
@@ -84,10 +85,31 @@ struct TravRay {
     int node, sp, kind;
 };
 
+// Stack access.  Entries [0, lds_entries) live in this lane's LDS column; a traversal that ever needs more
+// (3 pushes per level are possible, far more than any real ray uses) continues in a per-lane global spill
+// column, so the LDS footprint - which bounds occupancy - is sized for the common case, not the worst.
+struct TravStack {
+    int * lds;                 // this lane's column, stride BLOCK
+    int * spill;               // this lane's global column, stride spill_stride (may be null if never needed)
+    unsigned int lds_entries;
+    size_t spill_stride;
+};
+
+template <int BLOCK>
+PRT_D void stack_push(const TravStack & s, int sp, int v) {
+    if ((unsigned int)sp < s.lds_entries) s.lds[sp * BLOCK] = v;
+    else s.spill[(size_t)((unsigned int)sp - s.lds_entries) * s.spill_stride] = v;
+}
+template <int BLOCK>
+PRT_D int stack_pop(const TravStack & s, int sp) {
+    if ((unsigned int)sp < s.lds_entries) return s.lds[sp * BLOCK];
+    return s.spill[(size_t)((unsigned int)sp - s.lds_entries) * s.spill_stride];
+}
+
 enum { TRAV_SENTINEL = (int)0x80000000 };   // bottom-of-stack marker; never a valid leaf link (first_tri < 2^29)
 
 template <int BLOCK>
-PRT_D void trav_init(TravRay & r, f3 o, f3 d, int kind, float pad, int * stack) {
+PRT_D void trav_init(TravRay & r, f3 o, f3 d, int kind, float pad, const TravStack & stk) {
     r.o = o;
     r.d = d;
     // direction components are clamped away from 0 so no inf/NaN enters the box test
@@ -103,49 +125,72 @@ PRT_D void trav_init(TravRay & r, f3 o, f3 d, int kind, float pad, int * stack) 
     r.best.tri = -1;
     r.best_rank = 0xFFFFFFFFu;
     r.kind = kind;
-    stack[0] = TRAV_SENTINEL;
+    stk.lds[0] = TRAV_SENTINEL;
     r.sp = 1;
     r.node = 0;
 }
 
-// One internal node: fetch 64 B, test both child boxes, descend into the nearer hit child, push the other.
-// The slab test is the one place that uses FMA (plane * 1/d - origin/d in one rounding): it only has to be
-// conservative, and the boxes are widened by `pad` >> its rounding error.  6 FMA + 10 min/max per box.
+PRT_D void cswap(float & ka, float & kb, int & la, int & lb) {
+    const bool sw = kb < ka;
+    const float k0 = sw ? kb : ka, k1 = sw ? ka : kb;
+    const int l0 = sw ? lb : la, l1 = sw ? la : lb;
+    ka = k0; kb = k1; la = l0; lb = l1;
+}
+
+// One 4-wide node: fetch 64 B, dequantise + slab-test four child boxes, sort the hit children by entry
+// distance, descend into the nearest and push the others (farthest first).
+//   plane = origin + q * 2^e  =>  t = (plane - o -+ pad) / d = q * (2^e / d) + (origin / d - (o +- pad) / d)
+// so after 3 scale products and 6 FMAs per node every plane costs one byte->float convert and one FMA.
+// The slab test may use FMA: it only has to be conservative, and the boxes are widened by `pad`.
 template <int BLOCK, bool COUNT>
-PRT_D void trav_node_step(const DevScene & sc, TravRay & r, int * stack, TraceStats & st) {
-    const float4 * np = sc.nodes + 4 * (size_t)r.node;
-    const float4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
+PRT_D void trav_node_step(const DevScene & sc, TravRay & r, const TravStack & stk, TraceStats & st) {
+    const uint4 * np = reinterpret_cast<const uint4 *>(sc.nodes) + 4 * (size_t)r.node;
+    const uint4 w0 = np[0], w1 = np[1], w2 = np[2], w3 = np[3];
     if (COUNT) st.nodes++;
-    const float ax = __builtin_fmaf(n0.x, r.ix, -r.plx), bx = __builtin_fmaf(n0.y, r.ix, -r.phx);
-    const float ay = __builtin_fmaf(n0.z, r.iy, -r.ply), by = __builtin_fmaf(n0.w, r.iy, -r.phy);
-    const float az = __builtin_fmaf(n2.x, r.iz, -r.plz), bz = __builtin_fmaf(n2.y, r.iz, -r.phz);
-    const float tmin0 = fmaxf(fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz)), 0.0f);
-    const float tmax0 = fminf(fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz)), r.best.t);
-    const float cx = __builtin_fmaf(n1.x, r.ix, -r.plx), ex = __builtin_fmaf(n1.y, r.ix, -r.phx);
-    const float cy = __builtin_fmaf(n1.z, r.iy, -r.ply), ey = __builtin_fmaf(n1.w, r.iy, -r.phy);
-    const float cz = __builtin_fmaf(n2.z, r.iz, -r.plz), ez = __builtin_fmaf(n2.w, r.iz, -r.phz);
-    const float tmin1 = fmaxf(fmaxf(fmaxf(fminf(cx, ex), fminf(cy, ey)), fminf(cz, ez)), 0.0f);
-    const float tmax1 = fminf(fminf(fminf(fmaxf(cx, ex), fmaxf(cy, ey)), fmaxf(cz, ez)), r.best.t);
-    const bool h0 = tmin0 <= tmax0, h1 = tmin1 <= tmax1;
-    int l0 = as_i(n3.x), l1 = as_i(n3.y);
-    if (h0 && h1) {
-        if (tmin1 < tmin0) { int tmp = l0; l0 = l1; l1 = tmp; }
-        stack[r.sp * BLOCK] = l1;
-        r.sp++;
-        r.node = l0;
-    } else if (h0) {
-        r.node = l0;
-    } else if (h1) {
-        r.node = l1;
+    const float kx = __uint_as_float((w0.w & 0xFFu) << 23) * r.ix;
+    const float ky = __uint_as_float(((w0.w >> 8) & 0xFFu) << 23) * r.iy;
+    const float kz = __uint_as_float(((w0.w >> 16) & 0xFFu) << 23) * r.iz;
+    const unsigned int count = w0.w >> 24;
+    const float ox = __uint_as_float(w0.x), oy = __uint_as_float(w0.y), oz = __uint_as_float(w0.z);
+    const float clx = __builtin_fmaf(ox, r.ix, -r.plx), chx = __builtin_fmaf(ox, r.ix, -r.phx);
+    const float cly = __builtin_fmaf(oy, r.iy, -r.ply), chy = __builtin_fmaf(oy, r.iy, -r.phy);
+    const float clz = __builtin_fmaf(oz, r.iz, -r.plz), chz = __builtin_fmaf(oz, r.iz, -r.phz);
+    const unsigned int qlx = w1.x, qly = w1.y, qlz = w1.z, qhx = w1.w, qhy = w2.x, qhz = w2.y;
+    float key[4];
+    int link[4] = { (int)w2.z, (int)w2.w, (int)w3.x, (int)w3.y };
+    const float inf = __uint_as_float(0x7F800000u);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float ax = __builtin_fmaf((float)((qlx >> (8 * k)) & 0xFFu), kx, clx);
+        const float bx = __builtin_fmaf((float)((qhx >> (8 * k)) & 0xFFu), kx, chx);
+        const float ay = __builtin_fmaf((float)((qly >> (8 * k)) & 0xFFu), ky, cly);
+        const float by = __builtin_fmaf((float)((qhy >> (8 * k)) & 0xFFu), ky, chy);
+        const float az = __builtin_fmaf((float)((qlz >> (8 * k)) & 0xFFu), kz, clz);
+        const float bz = __builtin_fmaf((float)((qhz >> (8 * k)) & 0xFFu), kz, chz);
+        const float tmin = fmaxf(fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz)), 0.0f);
+        const float tmax = fminf(fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz)), r.best.t);
+        key[k] = ((unsigned int)k < count && tmin <= tmax) ? tmin : inf;
+    }
+    // sorting network for 4 keys, ascending; misses (inf) sink to the end
+    cswap(key[0], key[1], link[0], link[1]);
+    cswap(key[2], key[3], link[2], link[3]);
+    cswap(key[0], key[2], link[0], link[2]);
+    cswap(key[1], key[3], link[1], link[3]);
+    cswap(key[1], key[2], link[1], link[2]);
+    if (key[0] < inf) {
+        if (key[3] < inf) { stack_push<BLOCK>(stk, r.sp, link[3]); r.sp++; }
+        if (key[2] < inf) { stack_push<BLOCK>(stk, r.sp, link[2]); r.sp++; }
+        if (key[1] < inf) { stack_push<BLOCK>(stk, r.sp, link[1]); r.sp++; }
+        r.node = link[0];
     } else {
         r.sp--;
-        r.node = stack[r.sp * BLOCK];
+        r.node = stack_pop<BLOCK>(stk, r.sp);
     }
 }
 
 // The leaf in r.node: test its triangles, then pop.  Returns true when an any-hit ray found its hit.
 template <int BLOCK, bool COUNT>
-PRT_D bool trav_leaf(const DevScene & sc, TravRay & r, int * stack, TraceStats & st) {
+PRT_D bool trav_leaf(const DevScene & sc, TravRay & r, const TravStack & stk, TraceStats & st) {
     const f3 qp = r.o - (r.o + r.d);                 // raytracer.cpp:88-89, not bitwise -d
     const unsigned int leaf = (unsigned int)~r.node;
     const unsigned int first = leaf >> 2, count = (leaf & 3u) + 1u;
@@ -176,7 +221,7 @@ PRT_D bool trav_leaf(const DevScene & sc, TravRay & r, int * stack, TraceStats &
         }
     }
     r.sp--;
-    r.node = stack[r.sp * BLOCK];
+    r.node = stack_pop<BLOCK>(stk, r.sp);
     return false;
 }
 
@@ -184,13 +229,13 @@ PRT_D bool trav_leaf(const DevScene & sc, TravRay & r, int * stack, TraceStats &
 // a leaf (or runs out of work), and only then does the wave run the triangle code.  With 64 lanes a fused
 // node-or-leaf loop would execute the (4x longer) leaf body in almost every iteration.
 template <int BLOCK, bool COUNT>
-PRT_D HitRec trace_ray(const DevScene & sc, f3 o, f3 d, int kind, float pad, int * stack, TraceStats & st) {
+PRT_D HitRec trace_ray(const DevScene & sc, f3 o, f3 d, int kind, float pad, const TravStack & stk, TraceStats & st) {
     TravRay r;
-    trav_init<BLOCK>(r, o, d, kind, pad, stack);
+    trav_init<BLOCK>(r, o, d, kind, pad, stk);
     for (;;) {
-        while (r.node >= 0) trav_node_step<BLOCK, COUNT>(sc, r, stack, st);
+        while (r.node >= 0) trav_node_step<BLOCK, COUNT>(sc, r, stk, st);
         if (r.node == TRAV_SENTINEL) break;
-        if (trav_leaf<BLOCK, COUNT>(sc, r, stack, st)) break;
+        if (trav_leaf<BLOCK, COUNT>(sc, r, stk, st)) break;
     }
     return r.best;
 }

@@ -37,7 +37,11 @@ __global__ __launch_bounds__(BLOCK) void k_render_mega(DevScene sc, DevCamera ca
     extern __shared__ int s_stack[];
     const unsigned int sid = blockIdx.x * BLOCK + threadIdx.x;
     if (sid >= n_samples) return;
-    int * stack = s_stack + threadIdx.x;
+    TravStack stack;
+    stack.lds = s_stack + threadIdx.x;
+    stack.spill = P.stack_spill + sid;
+    stack.lds_entries = P.stack_lds_entries;
+    stack.spill_stride = P.stack_spill_stride;
     const unsigned int pixel = pixel_of_local(P, sid / P.spp);
     const unsigned int samp = sid % P.spp;
     u64 * ring = RING ? ring_ws + sid : nullptr;

@@ -113,7 +113,11 @@ __global__ __launch_bounds__(BLOCK) void k_trace(DevScene sc, DevParams P, WaveB
                                                   unsigned int n_shadow, int keep_min, unsigned int chunk, int multi_light,
                                                   DevCounters * ctr) {
     extern __shared__ int s_stack[];
-    int * stack = s_stack + threadIdx.x;
+    TravStack stack;
+    stack.lds = s_stack + threadIdx.x;
+    stack.spill = P.stack_spill + (blockIdx.x * BLOCK + threadIdx.x);
+    stack.lds_entries = P.stack_lds_entries;
+    stack.spill_stride = P.stack_spill_stride;
     const unsigned int total = n_closest + n_shadow;
     const unsigned int lane = lane_id();
     const float4 * rq_o = B.rq_o[cur];

@@ -93,6 +93,8 @@ struct prt_ctx {
     DevBuf<ulonglong2> wf_rng;
     DevBuf<unsigned int> wf_counts;
     int cu_count = 0;
+    unsigned int stack_bound = 0;
+    DevBuf<int> stack_spill;
 };
 
 namespace {
@@ -329,15 +331,31 @@ int render_pixels(prt_ctx * ctx, const prt_camera * cam_in, const prt_params * p
     HIP_TRY(ctx, ctx->counters.ensure(1));
     if (ring) HIP_TRY(ctx, ctx->ring_ws.ensure(n_samples64 * 16));
 
-    // LDS traversal stack: one int per BVH level per lane (+ sentinel)
+    // Traversal stack: LDS column of up to STACK_LDS_CAP entries per lane; the rest of the worst-case bound
+    // (3 pushes per 4-wide level + sentinel) is backed by a global spill column that real rays never reach.
     constexpr int BLOCK = 256;
-    const unsigned int stack_entries = ctx->info.bvh_max_depth + 2;
+    constexpr unsigned int STACK_LDS_CAP = 24;
+    const unsigned int stack_entries = std::min(ctx->stack_bound, STACK_LDS_CAP);
     const size_t lds = (size_t)stack_entries * BLOCK * sizeof(int);
-    if (lds > 64 * 1024) { ctx->error = "prt_render: BVH too deep for the LDS traversal stack"; return -3; }
+    P.stack_lds_entries = stack_entries;
+    P.stack_spill = nullptr;
+    P.stack_spill_stride = 0;
 
     unsigned int pipeline = params->pipeline & PRT_PIPELINE_MASK;
     if (pipeline == PRT_PIPELINE_DEFAULT) pipeline = PRT_PIPELINE_WAVEFRONT;
     if (pipeline != PRT_PIPELINE_MEGAKERNEL && pipeline != PRT_PIPELINE_WAVEFRONT) { ctx->error = "prt_render: unknown pipeline"; return -1; }
+
+    {
+        const unsigned int spill_entries = ctx->stack_bound > stack_entries ? ctx->stack_bound - stack_entries : 0;
+        const size_t spill_lanes = pipeline == PRT_PIPELINE_MEGAKERNEL ? ((n_samples64 + BLOCK - 1) / BLOCK) * BLOCK
+                                                                        : (size_t)8 * (size_t)ctx->cu_count * BLOCK;
+        if (spill_entries) {
+            if (spill_lanes >= (1ull << 32)) { ctx->error = "prt_render: too many lanes for the stack spill area"; return -1; }
+            HIP_TRY(ctx, ctx->stack_spill.ensure((size_t)spill_entries * spill_lanes));
+            P.stack_spill = ctx->stack_spill.p;
+            P.stack_spill_stride = (unsigned int)spill_lanes;
+        }
+    }
 
     HIP_TRY(ctx, hipMemsetAsync(ctx->counters.p, 0, sizeof(DevCounters), stream));
     HIP_TRY(ctx, hipEventRecord(ctx->ev[0], stream));
@@ -436,7 +454,7 @@ void prt_destroy(prt_ctx * ctx) {
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     ctx->nodes.release(); ctx->tris.release(); ctx->shade.release(); ctx->diffuse_dirs.release(); ctx->spec_dirs.release();
     ctx->tri_rank.release(); ctx->materials.release(); ctx->lights.release();
-    ctx->sample_rgb.release(); ctx->frame_out.release(); ctx->counters.release(); ctx->ring_ws.release(); ctx->pixel_list.release(); ctx->wf_f4.release(); ctx->wf_rng.release(); ctx->wf_counts.release();
+    ctx->sample_rgb.release(); ctx->frame_out.release(); ctx->counters.release(); ctx->ring_ws.release(); ctx->pixel_list.release(); ctx->wf_f4.release(); ctx->wf_rng.release(); ctx->wf_counts.release(); ctx->stack_spill.release();
     for (int i = 0; i < 4; ++i) if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -486,9 +504,11 @@ int prt_upload_scene(prt_ctx * ctx, const prt_scene_desc * s) {
     std::vector<float> verts((size_t)n_tris * 9);
     for (uint32_t t = 0; t < n_tris; ++t)
         for (int c = 0; c < 3; ++c) memcpy(&verts[(size_t)t * 9 + 3 * c], s->positions + 3 * (size_t)s->idx_positions[3 * t + c], 12);
-    BvhResult bvh;
+    for (size_t i = 0; i < verts.size(); ++i)
+        if (!(fabsf(verts[i]) < 1e18f)) { ctx->error = "prt_upload_scene: vertex coordinate is not finite or exceeds 1e18"; return -1; }
+    Bvh4Result bvh;
     unsigned int hw = std::max(1u, std::thread::hardware_concurrency());
-    build_bvh2(verts.data(), n_tris, BVH_LEAF_MAX, std::min(hw, 16u), &bvh);
+    build_bvh4q(verts.data(), n_tris, BVH_LEAF_MAX, std::min(hw, 16u), &bvh);
     double build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
 
     // ---- reference visit rank: leaves of the sphere tree in the order TraceRay pops them (c1 first)
@@ -586,7 +606,8 @@ int prt_upload_scene(prt_ctx * ctx, const prt_scene_desc * s) {
     for (uint32_t i = 0; i < 1024; ++i) ddirs[i] = diffuse_tangent_dir(i);
 
     std::vector<float4> nodes4(bvh.nodes.size() / 4);
-    memcpy(nodes4.data(), bvh.nodes.data(), bvh.nodes.size() * sizeof(float));
+    memcpy(nodes4.data(), bvh.nodes.data(), bvh.nodes.size() * sizeof(uint32_t));
+    ctx->stack_bound = bvh.stack_bound;
 
     HIP_TRY(ctx, ctx->nodes.upload(nodes4));
     HIP_TRY(ctx, ctx->tris.upload(tris));
