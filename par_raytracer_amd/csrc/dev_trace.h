@@ -34,7 +34,13 @@ enum { TRACE_CLOSEST = 0, TRACE_ANY = 1 };
 
 struct TraceStats {
     unsigned int nodes, tris;
+    unsigned int wnodes, wleaves, wtris, wrefills;   // counted by the first active lane only (wave-level steps)
 };
+
+PRT_D bool first_active_lane() {
+    const unsigned long long m = __ballot(true);
+    return (int)(__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u))) == (__ffsll((long long)m) - 1);
+}
 
 PRT_D float as_f(int v) { return __int_as_float(v); }
 PRT_D int as_i(float v) { return __float_as_int(v); }
@@ -146,7 +152,7 @@ template <int BLOCK, bool COUNT>
 PRT_D void trav_node_step(const DevScene & sc, TravRay & r, const TravStack & stk, TraceStats & st) {
     const uint4 * np = reinterpret_cast<const uint4 *>(sc.nodes) + 4 * (size_t)r.node;
     const uint4 w0 = np[0], w1 = np[1], w2 = np[2], w3 = np[3];
-    if (COUNT) st.nodes++;
+    if (COUNT) { st.nodes++; if (first_active_lane()) st.wnodes++; }
     const float kx = __uint_as_float((w0.w & 0xFFu) << 23) * r.ix;
     const float ky = __uint_as_float(((w0.w >> 8) & 0xFFu) << 23) * r.iy;
     const float kz = __uint_as_float(((w0.w >> 16) & 0xFFu) << 23) * r.iz;
@@ -194,11 +200,12 @@ PRT_D bool trav_leaf(const DevScene & sc, TravRay & r, const TravStack & stk, Tr
     const f3 qp = r.o - (r.o + r.d);                 // raytracer.cpp:88-89, not bitwise -d
     const unsigned int leaf = (unsigned int)~r.node;
     const unsigned int first = leaf >> 2, count = (leaf & 3u) + 1u;
+    if (COUNT) { if (first_active_lane()) st.wleaves++; }
     for (unsigned int i = 0; i < count; ++i) {
         const unsigned int ti = first + i;
         const float4 * tp = sc.tris + 3 * (size_t)ti;
         const float4 r0 = tp[0], r1 = tp[1], r2 = tp[2];
-        if (COUNT) st.tris++;
+        if (COUNT) { st.tris++; if (first_active_lane()) st.wtris++; }
         float t, v, w;
         bool eq;
         bool hit = tri_test(r.o, r.d, qp, mk3(r0.x, r0.y, r0.z), mk3(r0.w, r1.x, r1.y), mk3(r1.z, r1.w, r2.x),

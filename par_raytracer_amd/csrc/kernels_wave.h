@@ -110,7 +110,7 @@ __global__ __launch_bounds__(256) void k_raygen(DevCamera cam, DevParams P, Wave
 // Persistent traversal.  grid = resident blocks; dynamic LDS = stack_entries * BLOCK * 4.
 template <int BLOCK, bool COUNT>
 __global__ __launch_bounds__(BLOCK) void k_trace(DevScene sc, DevParams P, WaveBuffers B, int cur, unsigned int n_closest,
-                                                  unsigned int n_shadow, int keep_min, unsigned int chunk, int multi_light,
+                                                  unsigned int n_shadow, int keep_min, int node_min, unsigned int chunk, int multi_light,
                                                   DevCounters * ctr) {
     extern __shared__ int s_stack[];
     TravStack stack;
@@ -131,7 +131,7 @@ __global__ __launch_bounds__(BLOCK) void k_trace(DevScene sc, DevParams P, WaveB
     int sample = 0;
     bool exhausted = false;              // wave-uniform: the queue has no more rays to hand out
     TraceStats st;
-    st.nodes = st.tris = 0;
+    st.nodes = st.tris = st.wnodes = st.wleaves = st.wtris = st.wrefills = 0;
 
     unsigned int chunk_next = 0, chunk_end = 0;      // wave-uniform: rays reserved for this wave, not yet handed out
     for (;;) {
@@ -151,6 +151,7 @@ __global__ __launch_bounds__(BLOCK) void k_trace(DevScene sc, DevParams P, WaveB
                 }
             }
             const unsigned int avail = chunk_end - chunk_next;
+            if (COUNT && avail && lane == 0) st.wrefills++;
             if (avail) {
                 const unsigned int prefix = __builtin_amdgcn_mbcnt_hi((unsigned int)(idle >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)idle, 0u));
                 const unsigned int n_idle = (unsigned int)__popcll(idle);
@@ -185,9 +186,17 @@ __global__ __launch_bounds__(BLOCK) void k_trace(DevScene sc, DevParams P, WaveB
         // ---- traverse until fewer than `leave_below` lanes of the wave are still busy
         const int leave_below = (exhausted && chunk_next == chunk_end) ? 1 : keep_min;
         while (ray >= 0) {
-            while (r.node >= 0) trav_node_step<BLOCK, COUNT>(sc, r, stack, st);
+            // Node phase.  Lanes drop out as they reach a leaf; once fewer than `node_min` lanes are still
+            // walking, the stragglers are suspended too (they keep their node) so the wave can run the leaf
+            // phase for the majority instead of idling behind the longest walk.
+            const int walkers = __popcll(__ballot(r.node >= 0));
+            const int nmin = node_min < (walkers >> 1) ? node_min : (walkers >> 1);
+            while (r.node >= 0) {
+                trav_node_step<BLOCK, COUNT>(sc, r, stack, st);
+                if (__popcll(__ballot(r.node >= 0)) < nmin) break;
+            }
             bool fin = r.node == TRAV_SENTINEL;
-            if (!fin) fin = trav_leaf<BLOCK, COUNT>(sc, r, stack, st);
+            if (!fin && r.node < 0) fin = trav_leaf<BLOCK, COUNT>(sc, r, stack, st);
             if (fin) {
                 if ((unsigned int)ray < n_closest) {
                     B.hits[ray] = make_float4(r.best.t, r.best.v, r.best.w, as_f(r.best.tri));
@@ -216,6 +225,10 @@ __global__ __launch_bounds__(BLOCK) void k_trace(DevScene sc, DevParams P, WaveB
     if (COUNT) {
         atomicAdd(&ctr->node_visits, (unsigned long long)st.nodes);
         atomicAdd(&ctr->tri_tests, (unsigned long long)st.tris);
+        atomicAdd(&ctr->wave_node_steps, (unsigned long long)st.wnodes);
+        atomicAdd(&ctr->wave_leaf_steps, (unsigned long long)st.wleaves);
+        atomicAdd(&ctr->wave_tri_steps, (unsigned long long)st.wtris);
+        atomicAdd(&ctr->wave_refills, (unsigned long long)st.wrefills);
     }
 }
 

@@ -220,8 +220,13 @@ int render_wavefront(prt_ctx * ctx, const DevCamera & cam, const DevParams & P, 
                                  : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace<BLOCK, false>, BLOCK, lds);
     if (oe != hipSuccess || per_cu < 1) per_cu = 2;
     per_cu = std::min(per_cu, 8);
+    int keep_min = 40;
+    // tuning knobs for experiments (not part of the ABI)
+    if (const char * e = getenv("PRT_TRACE_BLOCKS_PER_CU")) per_cu = std::max(1, std::min(per_cu, atoi(e)));
+    if (const char * e = getenv("PRT_KEEP_MIN")) keep_min = std::max(1, std::min(64, atoi(e)));
+    int node_min = 32;
+    if (const char * e = getenv("PRT_NODE_MIN")) node_min = std::max(0, std::min(64, atoi(e)));
     const unsigned int max_blocks = (unsigned int)per_cu * (unsigned int)ctx->cu_count;
-    const int keep_min = 40;
     const int multi_light = ctx->scene.light_count > 1 ? 1 : 0;
 
     const unsigned int gen_grid = (n_samples + 255) / 256;
@@ -246,10 +251,10 @@ int render_wavefront(prt_ctx * ctx, const DevCamera & cam, const DevParams & P, 
         HIP_TRY(ctx, hipEventRecord(ctx->ev[2], stream));
         if (count_visits)
             hipLaunchKernelGGL((k_trace<BLOCK, true>), dim3(grid), dim3(BLOCK), lds, stream, ctx->scene, P, B, cur, n_closest, n_shadow,
-                               keep_min, chunk, multi_light, ctx->counters.p);
+                               keep_min, node_min, chunk, multi_light, ctx->counters.p);
         else
             hipLaunchKernelGGL((k_trace<BLOCK, false>), dim3(grid), dim3(BLOCK), lds, stream, ctx->scene, P, B, cur, n_closest, n_shadow,
-                               keep_min, chunk, multi_light, ctx->counters.p);
+                               keep_min, node_min, chunk, multi_light, ctx->counters.p);
         HIP_TRY(ctx, hipGetLastError());
         HIP_TRY(ctx, hipEventRecord(ctx->ev[3], stream));
         n_launch++;
@@ -393,6 +398,12 @@ int render_pixels(prt_ctx * ctx, const prt_camera * cam_in, const prt_params * p
             trace_ms = trace_ms_accum;
             h.ray_count = host_ray_count;
         }
+        if (getenv("PRT_DEBUG_UTIL") && h.wave_node_steps)
+            fprintf(stderr, "[prt] lane utilisation: node loop %.1f%% (%llu wave steps), triangle tests %.1f%% (%llu wave steps, %llu leaf visits), %llu refills (%.1f rays each)\n",
+                    100.0 * (double)h.node_visits / (64.0 * (double)h.wave_node_steps), (unsigned long long)h.wave_node_steps,
+                    100.0 * (double)h.tri_tests / (64.0 * (double)h.wave_tri_steps), (unsigned long long)h.wave_tri_steps,
+                    (unsigned long long)h.wave_leaf_steps, (unsigned long long)h.wave_refills,
+                    h.wave_refills ? (double)host_ray_count / (double)h.wave_refills : 0.0);
         memset(counters, 0, sizeof(*counters));
         counters->ray_count = h.ray_count;
         counters->node_visits = h.node_visits;
