@@ -15,8 +15,11 @@ A ray is one TraceRay call (raytracer.cpp:161): primary, shadow, bounce.  value 
 Total work is fixed as N grows -> "scaling": "strong".
 
 Extra objects on the JSON line:
-  roofline      dominant kernel (k_render_mega): SURVEY.md §8d algorithmic bytes of one launch / its mean
-                duration measured with HIP events on the kernel's own stream inside the timed region.
+  roofline      dominant kernel (k_trace, the persistent traversal kernel; one launch per bounce round):
+                SURVEY.md §8d algorithmic bytes of its launches in a frame (rays x 52 B + BVH nodes fetched x 64 B
+                + triangle tests x 48 B) / their summed duration, measured with HIP events on the kernel's own
+                stream inside the timed region.  `traffic` = HBM bytes of the same launches from rocprofv3 PMC
+                passes of this command (profiles/traffic_C4.json), or null.
   cpu_baseline  the CPU oracle ("port", oracle/prt_oracle.cpp, proven bit-identical to the compiled
                 reference) timed on this host's cores on a sparse pixel lattice of the SAME frame; rank 0,
                 N = 1 only.  The same lattice is the parity check of the GPU frame (max |dRGB|, ray counts).
@@ -80,7 +83,7 @@ def main():
     import torch
     import torch.distributed as dist
 
-    from par_raytracer_amd import api, capi, scenes
+    from par_raytracer_amd import api, capi, scenes, sharding
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
@@ -119,37 +122,26 @@ def main():
 
     # ---- output buffers (device).  Shards are padded to the largest shard so the gather has equal sizes.
     my_rows = r.shard_rows(height, SHARD_BLOCK_ROWS, rank, world)
-    max_rows = max(r.shard_rows(height, SHARD_BLOCK_ROWS, k, world) for k in range(world))
+    assert my_rows == sharding.shard_rows(height, SHARD_BLOCK_ROWS, rank, world)
+    max_rows = sharding.max_shard_rows(height, SHARD_BLOCK_ROWS, world)
     shard = torch.zeros((max_rows, width, 4), dtype=torch.float32, device=dev)
-    frame = None
     gather_list = None
     row_index = None
+    frame = None
     if world > 1 and rank == 0:
         gather_list = [torch.empty_like(shard) for _ in range(world)]
-        frame = torch.empty((height, width, 4), dtype=torch.float32, device=dev)
-        # destination row of every (rank, local row) slot; padded slots point at a scratch row `height`
-        idx = np.full((world, max_rows), height, dtype=np.int64)
-        for k in range(world):
-            row = 0
-            b = k
-            while b * SHARD_BLOCK_ROWS < height:
-                y0 = b * SHARD_BLOCK_ROWS
-                rows = min(SHARD_BLOCK_ROWS, height - y0)
-                idx[k, row:row + rows] = np.arange(y0, y0 + rows)
-                row += rows
-                b += world
-        row_index = torch.from_numpy(idx.reshape(-1)).to(dev)
-        frame_pad = torch.empty((height + 1, width, 4), dtype=torch.float32, device=dev)
+        row_index = torch.from_numpy(sharding.row_index(height, SHARD_BLOCK_ROWS, world)).to(dev)
 
     def step(want_counters=True):
         """One frame.  Returns this rank's counters."""
+        nonlocal frame
         if world == 1:
             c = r.render_device(cam, params, width, height, 0, width * height, shard.data_ptr(), want_counters)
         else:
             c = r.render_shard_device(cam, params, width, height, SHARD_BLOCK_ROWS, rank, world, shard.data_ptr(), want_counters)
-            dist.gather(shard, gather_list, dst=0)
+            dist.gather(shard, gather_list, dst=0)                  # RCCL over xGMI: 7 shards -> GPU 0
             if rank == 0:
-                frame_pad.index_copy_(0, row_index, torch.cat(gather_list, dim=0))
+                frame = sharding.assemble(torch.cat(gather_list, dim=0), row_index, height)
         return c
 
     def sync_all():
@@ -193,8 +185,11 @@ def main():
     else:
         cc = r.render_shard_device(cam, pcount, width, height, SHARD_BLOCK_ROWS, rank, world, shard.data_ptr(), True)
     n_px_local = my_rows * width if world > 1 else width * height
-    alg_bytes = (cc.ray_count * B_RAY + cc.node_visits * B_NODE + cc.tri_tests * B_TRI + cc.shaded_hits * B_SHADE +
-                 n_px_local * B_PIXEL)
+    mega = (args.pipeline & 0xFF) == 1
+    # k_trace moves rays, nodes and triangle records; shading records and the framebuffer belong to k_shade / k_resolve
+    alg_bytes = cc.ray_count * B_RAY + cc.node_visits * B_NODE + cc.tri_tests * B_TRI
+    if mega:
+        alg_bytes += cc.shaded_hits * B_SHADE + n_px_local * B_PIXEL
     kernel_ms = float(np.mean(trace_ms))
     achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
     traffic = None
@@ -202,13 +197,14 @@ def main():
     if os.path.exists(tpath) and world == 1:
         try:
             with open(tpath) as f:
-                traffic = json.load(f).get("hbm_bytes_per_launch")
+                traffic = json.load(f).get("hbm_bytes_per_frame_k_trace")
         except Exception:
             traffic = None
-    roofline = {"bound": "hbm", "kernel": "k_render_mega", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+    roofline = {"bound": "hbm", "kernel": "k_render_mega" if mega else "k_trace", "launches_per_frame": int(cc.trace_kernel_launches),
+                "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                "algorithmic_bytes_per_launch": int(alg_bytes), "kernel_ms": round(kernel_ms, 4),
-                "per_launch": {"rays": int(cc.ray_count), "node_visits": int(cc.node_visits), "tri_tests": int(cc.tri_tests),
+                "algorithmic_bytes_per_frame": int(alg_bytes), "kernel_ms_per_frame": round(kernel_ms, 4),
+                "per_frame": {"rays": int(cc.ray_count), "node_visits": int(cc.node_visits), "tri_tests": int(cc.tri_tests),
                                "shaded_hits": int(cc.shaded_hits), "pixels": int(n_px_local)},
                 "bytes_per_unit": {"ray": B_RAY, "node": B_NODE, "tri_test": B_TRI, "shaded_hit": B_SHADE, "pixel": B_PIXEL}}
 
@@ -250,7 +246,7 @@ def main():
                        "spp": spp, "bounce_depth": depth, "rays_per_frame": int(rays_total / args.steps),
                        "parallelism": "pixel rows sharded in %d-row blocks over %d GPU(s)%s" % (
                            SHARD_BLOCK_ROWS, world, ", RCCL gather to rank 0" if world > 1 else ""),
-                       "pipeline": "megakernel"},
+                       "pipeline": "megakernel" if mega else "wavefront"},
             "render_ms_device": round(float(np.mean(render_ms)), 4),
             "roofline": roofline, "cpu_baseline": cpu_baseline, "parity": parity,
         }

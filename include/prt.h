@@ -198,6 +198,11 @@ typedef struct prt_scene_info {
 } prt_scene_info;
 int prt_get_scene_info(const prt_ctx * ctx, prt_scene_info * info);
 
+/* Host-only self check of the acceleration structure prt_upload_scene builds (runs without a GPU; the
+ * CPU test-suite calls it): every triangle inside every ancestor's de-quantised box, every triangle in
+ * exactly one leaf, links in range.  out[6] = { violations, nodes, depth, stack bound, leaves, triangle refs }. */
+int prt_debug_check_bvh(const prt_scene_desc * scene, uint64_t * out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -735,4 +735,74 @@ int prt_render_pixel_list(prt_ctx * ctx, const prt_camera * cam, const prt_param
     return 0;
 }
 
+// Host-only self check of the acceleration structure (no GPU needed; used by the CPU test-suite): builds the
+// quantised 4-wide BVH for `scene` exactly as prt_upload_scene does and verifies that every triangle lies
+// inside the de-quantised box of every ancestor, that every triangle is referenced by exactly one leaf and
+// that links are in range.  out[0] = violations, out[1] = nodes, out[2] = depth, out[3] = stack bound,
+// out[4] = leaves, out[5] = triangles referenced.
+int prt_debug_check_bvh(const prt_scene_desc * s, uint64_t * out) {
+    if (!s || !out || s->index_count % 3) return -1;
+    const uint32_t n_tris = s->index_count / 3;
+    std::vector<float> verts((size_t)n_tris * 9);
+    for (uint32_t t = 0; t < n_tris; ++t)
+        for (int c = 0; c < 3; ++c) memcpy(&verts[(size_t)t * 9 + 3 * c], s->positions + 3 * (size_t)s->idx_positions[3 * t + c], 12);
+    Bvh4Result bvh;
+    build_bvh4q(verts.data(), n_tris, BVH_LEAF_MAX, 4, &bvh);
+    uint64_t violations = 0, leaves = 0, refs = 0;
+    std::vector<uint8_t> seen(std::max(1u, n_tris), 0);
+    struct Item { uint32_t node; float lo[3], hi[3]; };
+    std::vector<Item> stack;
+    Item root;
+    root.node = 0;
+    for (int a = 0; a < 3; ++a) { root.lo[a] = -3.0e38f; root.hi[a] = 3.0e38f; }
+    stack.push_back(root);
+    while (!stack.empty()) {
+        Item it = stack.back();
+        stack.pop_back();
+        if (it.node >= bvh.node_count) { violations++; continue; }
+        const uint32_t * d = &bvh.nodes[(size_t)it.node * 16];
+        float org[3], scale[3];
+        for (int a = 0; a < 3; ++a) {
+            memcpy(&org[a], &d[a], 4);
+            uint32_t bits = ((d[3] >> (8 * a)) & 0xFFu) << 23;
+            memcpy(&scale[a], &bits, 4);
+        }
+        const uint32_t count = d[3] >> 24;
+        if (count < 1 || count > 4) violations++;
+        for (uint32_t k = 0; k < count && k < 4; ++k) {
+            Item ch;
+            for (int a = 0; a < 3; ++a) {
+                ch.lo[a] = std::max(it.lo[a], org[a] + (float)((d[4 + a] >> (8 * k)) & 0xFFu) * scale[a]);
+                ch.hi[a] = std::min(it.hi[a], org[a] + (float)((d[7 + a] >> (8 * k)) & 0xFFu) * scale[a]);
+            }
+            const int32_t link = (int32_t)d[10 + k];
+            if (link >= 0) {
+                ch.node = (uint32_t)link;
+                stack.push_back(ch);
+            } else {
+                const uint32_t leaf = (uint32_t)~link, first = leaf >> 2, cnt = (leaf & 3u) + 1u;
+                leaves++;
+                for (uint32_t i = 0; i < cnt; ++i) {
+                    const uint32_t slot = first + i;
+                    if (slot >= n_tris) { if (n_tris) violations++; continue; }
+                    refs++;
+                    if (seen[slot]++) violations++;
+                    const uint32_t t = bvh.tri_order[slot];
+                    for (int c = 0; c < 3; ++c)
+                        for (int a = 0; a < 3; ++a) {
+                            const float v = verts[(size_t)t * 9 + 3 * c + a];
+                            // de-quantised planes may round by an ulp of the coordinate; the kernels widen every box
+                            // by 2^-16 of the scene extent, far more than that
+                            const float tol = 4.0f * 1.1920929e-7f * std::max(1.0f, fabsf(v));
+                            if (v < ch.lo[a] - tol || v > ch.hi[a] + tol) violations++;
+                        }
+                }
+            }
+        }
+    }
+    for (uint32_t t = 0; t < n_tris; ++t) if (!seen[t]) violations++;
+    out[0] = violations; out[1] = bvh.node_count; out[2] = bvh.max_depth; out[3] = bvh.stack_bound; out[4] = leaves; out[5] = refs;
+    return 0;
+}
+
 }  // extern "C"

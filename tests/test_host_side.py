@@ -1,0 +1,226 @@
+"""Host logic on CPU: OBJ/MTL loader, sphere hierarchy, flattening, tone map + PNG, C ABI surface, BVH builder.
+
+No compute call needs a GPU here: prt_create must fail cleanly without one, and everything else is host code.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import re
+import struct
+import subprocess
+import zlib
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, host_scene, load_golden, scene_dir
+
+from par_raytracer_amd import api, capi, scenes
+
+
+# ---- the C ABI: every symbol the headers declare is exported ----------------------------------------------
+
+def _declared(header):
+    text = open(os.path.join(ROOT, "include", header)).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(prt_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_hip_library_exports_every_declared_symbol():
+    lib = capi.hip_lib()
+    names = _declared("prt.h")
+    assert set(names) == set(capi.PRT_SYMBOLS), "capi.PRT_SYMBOLS out of sync with include/prt.h"
+    for n in names:
+        assert hasattr(lib, n), "libprt_hip.so does not export %s" % n
+    assert lib.prt_abi_version() == 1
+
+
+def test_host_library_exports_every_declared_symbol():
+    lib = capi.host_lib()
+    names = _declared("prt_host.h")
+    assert set(names) == set(capi.PRT_HOST_SYMBOLS)
+    for n in names:
+        assert hasattr(lib, n), "libprt_host.so does not export %s" % n
+
+
+def test_struct_sizes_match_the_reference_layouts():
+    # SURVEY.md §8a A19 [probed] sizes of the reference structs these mirror
+    assert C.sizeof(capi.PrtBSphere) == 24          # BoundingSphere
+    assert C.sizeof(capi.PrtCamera) == 64           # Camera
+    assert C.sizeof(capi.PrtLight) == 48            # LightSource
+
+
+def test_error_paths_without_a_gpu_or_scene():
+    lib = capi.hip_lib()
+    import torch
+    if not torch.cuda.is_available():
+        assert not lib.prt_create(0)
+        assert b"no HIP device" in lib.prt_last_error(None)
+    assert lib.prt_upload_scene(None, None) == -1
+    assert lib.prt_render(None, None, None, 1, 1, 0, 1, None, None) == -1
+    assert lib.prt_shard_rows(1080, 8, 0, 0) == 0 and lib.prt_shard_rows(1080, 0, 0, 1) == 0
+
+
+def test_shard_rows_partition_the_frame():
+    lib = capi.hip_lib()
+    for h, br, n in ((1080, 8, 8), (1080, 8, 3), (17, 8, 2), (5, 8, 8), (2160, 8, 8), (100, 7, 4)):
+        rows = [lib.prt_shard_rows(h, br, r, n) for r in range(n)]
+        assert sum(rows) == h
+        # python mirror of the block walk used by bench.py
+        for r in range(n):
+            mine, b = 0, r
+            while b * br < h:
+                mine += min(br, h - b * br)
+                b += n
+            assert mine == rows[r]
+
+
+# ---- loader + hierarchy against the reference's parse of the same files ------------------------------------
+
+def _sums(a):
+    a = np.ascontiguousarray(a).view(np.uint8).reshape(-1)
+    return np.array([a.size, int(a.astype(np.uint64).sum()),
+                     int((a.astype(np.uint64) * (np.arange(a.size, dtype=np.uint64) % 251 + 1)).sum() % (1 << 62))], dtype=np.uint64)
+
+
+@pytest.mark.parametrize("name", ["c1_sphere_plane_256", "c2_cornell_128", "icosphere_l3_two_lights", "terrain64_d3",
+                                  "terrain192_d2", "c3_icosphere_1080p_l24"])
+def test_loader_and_hierarchy_bit_identical_to_reference(name):
+    g = load_golden(name)
+    hs = host_scene(str(g["scene"]), int(g["light_mode"]))
+    a = hs.arrays()
+    for k in ("positions", "texcoords", "normals", "idx_positions", "idx_texcoords", "idx_normals"):
+        assert np.array_equal(_sums(a[k]), g["sum_" + k]), k
+    assert np.array_equal(a["spheres"].view(np.uint32), g["spheres"].view(np.uint32)), "sphere tree differs from the reference"
+    assert np.array_equal(a["sphere_children"], g["sphere_children"])
+    assert np.array_equal(a["sphere_group"], g["sphere_group"])
+    assert np.array_equal(a["groups"][:, 1].astype(np.uint32), g["group_index_counts"])
+    assert hs.n_tris == int(g["triangles"])
+
+
+def test_loader_matches_generator_arrays():
+    s, d = scene_dir("cornell_box")
+    hs = host_scene("cornell_box")
+    a = hs.arrays()
+    assert np.array_equal(a["positions"], s.positions) and np.array_equal(a["normals"], s.normals)
+    faces = np.concatenate([g.faces for g in s.groups]).reshape(-1, 3)
+    assert np.array_equal(a["idx_positions"], faces[:, 0].astype(np.uint32))
+    # material 0 is the scene default (main.cpp:579), MTL materials follow in first-use order
+    m = a["materials"]
+    assert np.allclose(m[0, :3], [10.0, 1.5, 1.0]) and np.allclose(m[0, 3:7], [0.75, 0.5, 0.75, 1.0])
+    names = [g.material for g in s.groups]
+    by_name = {mm.name: mm for mm in s.materials}
+    for gi, nm in enumerate(names):
+        row = m[a["groups"][gi, 2]]
+        assert np.allclose(row[:3], [by_name[nm].Ns, by_name[nm].Ni, by_name[nm].d])
+        assert np.allclose(row[7:10], by_name[nm].Kd)
+
+
+def test_obj_quirks(tmp_path):
+    """Format behaviour of obj_parser.cpp the loader preserves."""
+    (tmp_path / "q.mtl").write_text("newmtl a\nNs 5\nNi 1.2\nd 0.5\nKa 1 0 0\nKd 0 1 0\nKs 0 0 1\n\nnewmtl b\nKd 0.5 0.5 0.5\n")
+    (tmp_path / "q.obj").write_text(
+        "mtllib q.mtl\nv 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nv 0 0 1\nvt 0 0\nvn 0 0 1\n"
+        "g quad\nusemtl a\nf 1/1/1 2/1/1 3/1/1 4/1/1\n"          # 4 corners -> fan of 2 triangles
+        "usemtl b\nf -5/-1/-1 -4/-1/-1 -1/-1/-1\n"                # second usemtl splits the group; negative = relative
+        "g nomat\nf 1/1/1 2/1/1 5/1/1\n")
+    hs = api.HostScene(str(tmp_path), "q.obj")
+    a = hs.arrays()
+    assert hs.n_tris == 4
+    assert a["groups"].shape[0] == 3                                    # quad, quad (split), nomat
+    assert list(a["idx_positions"][:6]) == [0, 1, 2, 0, 2, 3]           # fan around corner 0
+    assert list(a["idx_positions"][6:9]) == [0, 1, 4]                   # -5,-4,-1 of 5 positions
+    m = a["materials"]
+    mat_a = m[a["groups"][0, 2]]
+    mat_b = m[a["groups"][1, 2]]
+    assert np.allclose(mat_a[:3], [5, 1.2, 0.5]) and np.allclose(mat_a[3:7], [1, 0, 0, 1])
+    assert np.allclose(mat_b[:3], [0, 0, 0]), "materials start zeroed: missing d means alpha 0 (obj_parser.cpp:255)"
+    assert a["groups"][2, 2] == 0                                        # group without usemtl -> default material
+
+
+def test_missing_file_is_an_error_not_a_crash(tmp_path):
+    with pytest.raises(RuntimeError):
+        api.HostScene(str(tmp_path), "does_not_exist.obj")
+
+
+# ---- acceleration structure (host-only check of what upload builds) -----------------------------------------
+
+@pytest.mark.parametrize("name", ["cornell_box", "sphere_plane", "icosphere_l3", "terrain_64", "terrain_192"])
+def test_bvh_is_conservative_and_complete(name):
+    hs = host_scene(name)
+    out = (C.c_uint64 * 6)()
+    assert capi.hip_lib().prt_debug_check_bvh(hs.desc, out) == 0
+    violations, nodes, depth, bound, leaves, refs = list(out)
+    assert violations == 0
+    assert refs == hs.n_tris and leaves >= hs.n_tris / 4
+    assert bound == 3 * depth + 2
+
+
+def test_bvh_degenerate_scenes(tmp_path):
+    # one triangle, and many coincident triangles (all centroids equal -> median splits)
+    (tmp_path / "one.obj").write_text("v 0 0 0\nv 1 0 0\nv 0 1 0\nvt 0 0\nvn 0 0 1\ng t\nf 1/1/1 2/1/1 3/1/1\n")
+    lines = "v 0 0 0\nv 1 0 0\nv 0 1 0\nvt 0 0\nvn 0 0 1\ng t\n" + "f 1/1/1 2/1/1 3/1/1\n" * 37
+    (tmp_path / "many.obj").write_text(lines)
+    for f, n in (("one.obj", 1), ("many.obj", 37)):
+        hs = api.HostScene(str(tmp_path), f)
+        out = (C.c_uint64 * 6)()
+        assert capi.hip_lib().prt_debug_check_bvh(hs.desc, out) == 0
+        assert out[0] == 0 and out[5] == n
+
+
+# ---- tone map + PNG -------------------------------------------------------------------------------------------
+
+def _decode_png(path):
+    data = open(path, "rb").read()
+    assert data[:8] == b"\x89PNG\r\n\x1a\n"
+    off, chunks = 8, {}
+    idat = b""
+    while off < len(data):
+        n, tag = struct.unpack(">I4s", data[off:off + 8])
+        body = data[off + 8:off + 8 + n]
+        crc, = struct.unpack(">I", data[off + 8 + n:off + 12 + n])
+        assert crc == (zlib.crc32(tag + body) & 0xFFFFFFFF)
+        if tag == b"IDAT":
+            idat += body
+        chunks[tag] = body
+        off += 12 + n
+    w, h, depth, ctype = struct.unpack(">IIBB", chunks[b"IHDR"][:10])
+    raw = zlib.decompress(idat)
+    rows = [raw[(w * 4 + 1) * y + 1:(w * 4 + 1) * (y + 1)] for y in range(h)]
+    assert all(raw[(w * 4 + 1) * y] == 0 for y in range(h))
+    return w, h, depth, ctype, np.frombuffer(b"".join(rows), dtype=np.uint8).reshape(h, w, 4)
+
+
+def test_tonemap_and_png_roundtrip(tmp_path):
+    g = load_golden("c2_cornell_128")
+    rgb = g["rgb"]
+    h, w = rgb.shape[:2]
+    rgba = np.concatenate([rgb, np.ones((h, w, 1), dtype=np.float32)], axis=2).astype(np.float32)
+    lib = capi.host_lib()
+    out8 = np.zeros((h, w, 4), dtype=np.uint8)
+    luma = lib.prt_host_tonemap(rgba.ctypes.data_as(C.c_void_p), w, h, out8.ctypes.data_as(C.c_void_p))
+    # numpy restatement of main.cpp:78-127 in float32, sequential log sum
+    l = (np.float32(0.2126) * rgb[:, :, 0] + np.float32(0.7152) * rgb[:, :, 1]) + np.float32(0.0722) * rgb[:, :, 2]
+    acc = np.float32(0.0)
+    for v in np.log(np.float32(0.01) + l.reshape(-1)).astype(np.float32):
+        acc = np.float32(acc + v)
+    expect_luma = np.exp(acc / np.float32(w * h))
+    assert abs(luma - expect_luma) <= 2e-6 * expect_luma
+    assert np.all(out8[:, :, 3] == 255) and out8[:, :, :3].max() > 40
+    path = str(tmp_path / "o.png")
+    assert lib.prt_host_write_image(rgba.ctypes.data_as(C.c_void_p), w, h, path.encode()) == 0
+    pw, ph, depth, ctype, px = _decode_png(path)
+    assert (pw, ph, depth, ctype) == (w, h, 8, 6)
+    assert np.array_equal(px, out8)
+
+
+# ---- driver binary ------------------------------------------------------------------------------------------------
+
+def test_driver_reports_missing_scene(tmp_path):
+    exe = os.path.join(ROOT, "par_raytracer_amd", "prt_main")
+    if not os.path.exists(exe):
+        pytest.skip("prt_main not built")
+    p = subprocess.run([exe, "-d", str(tmp_path), "--obj", "nope.obj", "-w", "8", "-h", "8"], stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=60)
+    assert p.returncode == 1 and b"Cannot load" in p.stderr
