@@ -124,7 +124,8 @@ typedef struct prt_params {
     uint64_t seed;
 } prt_params;
 
-enum { PRT_PIPELINE_DEFAULT = 0, PRT_PIPELINE_MEGAKERNEL = 1, PRT_PIPELINE_WAVEFRONT = 2, PRT_PIPELINE_MASK = 0xFF };
+enum { PRT_PIPELINE_DEFAULT = 0, PRT_PIPELINE_MEGAKERNEL = 1, PRT_PIPELINE_WAVEFRONT = 2, PRT_PIPELINE_PERSISTENT = 3,
+       PRT_PIPELINE_MASK = 0xFF };
 /* OR-ed into prt_params.pipeline: also count BVH node visits and triangle tests (costs a few percent;
  * ray_count and shaded_hits are always counted). */
 enum { PRT_FLAG_COUNT_VISITS = 0x100 };

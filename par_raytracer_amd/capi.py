@@ -88,7 +88,7 @@ class PrtSceneInfo(C.Structure):
         return {n: getattr(self, n) for n, _ in self._fields_}
 
 
-PIPELINE_DEFAULT, PIPELINE_MEGAKERNEL, PIPELINE_WAVEFRONT = 0, 1, 2
+PIPELINE_DEFAULT, PIPELINE_MEGAKERNEL, PIPELINE_WAVEFRONT, PIPELINE_PERSISTENT = 0, 1, 2, 3
 FLAG_COUNT_VISITS = 0x100
 
 # Every symbol include/prt.h declares; tests/test_capi_symbols.py checks the library exports them all.

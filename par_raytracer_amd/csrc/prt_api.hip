@@ -20,6 +20,7 @@
 #include "dev_scene.h"
 #include "kernels_mega.h"
 #include "kernels_wave.h"
+#include "kernels_persist.h"
 
 using namespace prt;
 
@@ -181,6 +182,33 @@ void launch_mega(prt_ctx * ctx, bool count, unsigned int grid, size_t lds, const
                            n_samples, ctx->sample_rgb.p, ctx->counters.p, ctx->ring_ws.p);
 }
 
+template <int MAXLEV, bool RING>
+int launch_persistent(prt_ctx * ctx, bool count, size_t lds, const DevCamera & cam, const DevParams & P, unsigned int n_samples,
+                      int keep_min, int node_min, int blocks_cap) {
+    constexpr int BLOCK = 256;
+    int per_cu = 0;
+    hipError_t oe = count ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_render_persistent<BLOCK, MAXLEV, RING, true>, BLOCK, lds)
+                          : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_render_persistent<BLOCK, MAXLEV, RING, false>, BLOCK, lds);
+    if (oe != hipSuccess || per_cu < 1) per_cu = 2;
+    per_cu = std::min(per_cu, blocks_cap);
+    const unsigned int max_blocks = (unsigned int)per_cu * (unsigned int)ctx->cu_count;
+    const unsigned int grid = std::max(1u, std::min(max_blocks, (n_samples + BLOCK - 1) / BLOCK));
+    // samples reserved per head atomic: whole waves, 64..512, ~1/16 of a wave's fair share
+    unsigned int chunk = n_samples / (grid * (BLOCK / 64) * 16u);
+    chunk = std::max(64u, std::min(512u, (chunk / 64u) * 64u));
+    if (RING) {
+        hipError_t e = ctx->ring_ws.ensure((size_t)16 * grid * BLOCK);
+        if (e != hipSuccess) { ctx->error = std::string("ring workspace: ") + hipGetErrorString(e); return -10; }
+    }
+    if (count)
+        hipLaunchKernelGGL((k_render_persistent<BLOCK, MAXLEV, RING, true>), dim3(grid), dim3(BLOCK), lds, ctx->stream, ctx->scene, cam, P,
+                           n_samples, ctx->sample_rgb.p, ctx->counters.p, ctx->ring_ws.p, ctx->wf_counts.p, keep_min, node_min, chunk);
+    else
+        hipLaunchKernelGGL((k_render_persistent<BLOCK, MAXLEV, RING, false>), dim3(grid), dim3(BLOCK), lds, ctx->stream, ctx->scene, cam, P,
+                           n_samples, ctx->sample_rgb.p, ctx->counters.p, ctx->ring_ws.p, ctx->wf_counts.p, keep_min, node_min, chunk);
+    return 0;
+}
+
 // The wavefront pipeline (kernels_wave.h): raygen, then rounds of {persistent trace, shade} until no ray is
 // left.  Queue sizes come back to the host once per round (8 bytes): they size the next launches, end the
 // loop and sum to ray_count (every queued ray is one TraceRay call, raytracer.cpp:161).
@@ -334,7 +362,7 @@ int render_pixels(prt_ctx * ctx, const prt_camera * cam_in, const prt_params * p
     const unsigned int n_samples = (unsigned int)n_samples64;
     HIP_TRY(ctx, ctx->sample_rgb.ensure(n_samples64));
     HIP_TRY(ctx, ctx->counters.ensure(1));
-    if (ring) HIP_TRY(ctx, ctx->ring_ws.ensure(n_samples64 * 16));
+    if (ring && (params->pipeline & PRT_PIPELINE_MASK) != PRT_PIPELINE_PERSISTENT) HIP_TRY(ctx, ctx->ring_ws.ensure(n_samples64 * 16));
 
     // Traversal stack: LDS column of up to STACK_LDS_CAP entries per lane; the rest of the worst-case bound
     // (3 pushes per 4-wide level + sentinel) is backed by a global spill column that real rays never reach.
@@ -348,7 +376,7 @@ int render_pixels(prt_ctx * ctx, const prt_camera * cam_in, const prt_params * p
 
     unsigned int pipeline = params->pipeline & PRT_PIPELINE_MASK;
     if (pipeline == PRT_PIPELINE_DEFAULT) pipeline = PRT_PIPELINE_WAVEFRONT;
-    if (pipeline != PRT_PIPELINE_MEGAKERNEL && pipeline != PRT_PIPELINE_WAVEFRONT) { ctx->error = "prt_render: unknown pipeline"; return -1; }
+    if (pipeline != PRT_PIPELINE_MEGAKERNEL && pipeline != PRT_PIPELINE_WAVEFRONT && pipeline != PRT_PIPELINE_PERSISTENT) { ctx->error = "prt_render: unknown pipeline"; return -1; }
 
     {
         const unsigned int spill_entries = ctx->stack_bound > stack_entries ? ctx->stack_bound - stack_entries : 0;
@@ -378,6 +406,25 @@ int render_pixels(prt_ctx * ctx, const prt_camera * cam_in, const prt_params * p
         hipLaunchKernelGGL(k_resolve, dim3((px.n_pixels + 255) / 256), dim3(256), 0, stream, ctx->sample_rgb.p, d_out, px.n_pixels, P.spp);
         HIP_TRY(ctx, hipGetLastError());
         launches = 1;
+    } else if (n_samples && pipeline == PRT_PIPELINE_PERSISTENT) {
+        HIP_TRY(ctx, ctx->wf_counts.ensure(16));
+        HIP_TRY(ctx, hipMemsetAsync(ctx->wf_counts.p, 0, 16, stream));
+        int keep_min = 40, node_min = 32;
+        if (const char * e = getenv("PRT_KEEP_MIN")) keep_min = std::max(1, std::min(64, atoi(e)));
+        if (const char * e = getenv("PRT_NODE_MIN")) node_min = std::max(0, std::min(64, atoi(e)));
+        int blocks_cap = 8;
+        if (const char * e = getenv("PRT_TRACE_BLOCKS_PER_CU")) blocks_cap = std::max(1, std::min(8, atoi(e)));
+        HIP_TRY(ctx, hipEventRecord(ctx->ev[2], stream));
+        int rc = 0;
+        if (!ring && levels <= 3) rc = launch_persistent<3, false>(ctx, count_visits, lds, cam, P, n_samples, keep_min, node_min, blocks_cap);
+        else if (levels <= 9) rc = launch_persistent<9, true>(ctx, count_visits, lds, cam, P, n_samples, keep_min, node_min, blocks_cap);
+        else rc = launch_persistent<17, true>(ctx, count_visits, lds, cam, P, n_samples, keep_min, node_min, blocks_cap);
+        if (rc) return rc;
+        HIP_TRY(ctx, hipGetLastError());
+        HIP_TRY(ctx, hipEventRecord(ctx->ev[3], stream));
+        hipLaunchKernelGGL(k_resolve, dim3((px.n_pixels + 255) / 256), dim3(256), 0, stream, ctx->sample_rgb.p, d_out, px.n_pixels, P.spp);
+        HIP_TRY(ctx, hipGetLastError());
+        launches = 1;
     } else if (n_samples) {
         int rc = render_wavefront(ctx, cam, P, ring, count_visits, n_samples, lds, &host_ray_count, &trace_ms_accum, &launches);
         if (rc) return rc;
@@ -392,12 +439,13 @@ int render_pixels(prt_ctx * ctx, const prt_camera * cam_in, const prt_params * p
         HIP_TRY(ctx, hipMemcpy(&h, ctx->counters.p, sizeof(h), hipMemcpyDeviceToHost));
         float ms = 0.0f, trace_ms = 0.0f;
         HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
-        if (pipeline == PRT_PIPELINE_MEGAKERNEL) {
+        if (pipeline == PRT_PIPELINE_MEGAKERNEL || pipeline == PRT_PIPELINE_PERSISTENT) {
             if (launches) HIP_TRY(ctx, hipEventElapsedTime(&trace_ms, ctx->ev[2], ctx->ev[3]));
         } else {
             trace_ms = trace_ms_accum;
             h.ray_count = host_ray_count;
         }
+        if (pipeline != PRT_PIPELINE_WAVEFRONT) host_ray_count = h.ray_count;
         if (getenv("PRT_DEBUG_UTIL") && h.wave_node_steps)
             fprintf(stderr, "[prt] lane utilisation: node loop %.1f%% (%llu wave steps), triangle tests %.1f%% (%llu wave steps, %llu leaf visits), %llu refills (%.1f rays each)\n",
                     100.0 * (double)h.node_visits / (64.0 * (double)h.wave_node_steps), (unsigned long long)h.wave_node_steps,

@@ -28,7 +28,7 @@ def _render_fixture(gpu_renderer_factory, name, pipeline=0):
     return g, img, ctr
 
 
-PIPELINES = {"megakernel": 1, "wavefront": 2}
+PIPELINES = {"megakernel": 1, "wavefront": 2, "persistent": 3}
 
 
 @pytest.mark.parametrize("pipeline", sorted(PIPELINES))
