@@ -411,43 +411,40 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, DevParams P, WaveB
             const int iters = depth - level;
             const DevMaterial fm = sc.materials[f.mat];
             const f3 own = f.alpha < 1.0f ? f.T_in * f.alpha : f.T_in;
-            bool spawned = false;
+            // which child comes next (cheap), then ONE copy of the expensive direction code for both lobes
+            int kind = -1;                                                          // 0 diffuse, 1 specular, 2 alpha continuation
             if (f.stage == WF_STAGE_REFL) {                                         // raytracer.cpp:516-526
-                if (iters > 0 && (unsigned int)f.idx < P.reflection_samples) {
-                    const unsigned int series_i = (unsigned int)(rng_next<RING>(rng, ring, ring_stride) % 1024ull);
-                    const float4 ts = sc.diffuse_dirs[series_i];
-                    next_d = tangent_to_world(f.hit_n, mk3(ts.x, ts.y, ts.z));
-                    const float cw = ref_max(0.0f, dot3(f.hit_n, next_d));
-                    next_T = own * (mk3(fm.diffuse[0], fm.diffuse[1], fm.diffuse[2]) * f.w_diffuse * cw);
-                    next_o = f.hit_p;
-                    f.idx++;
-                    spawned = true;
-                } else {
-                    f.stage = WF_STAGE_SPEC;
-                    f.idx = 0;
-                }
+                if (iters > 0 && (unsigned int)f.idx < P.reflection_samples) kind = 0;
+                else { f.stage = WF_STAGE_SPEC; f.idx = 0; }
             }
-            if (!spawned && f.stage == WF_STAGE_SPEC) {                             // raytracer.cpp:528-535
-                if (iters > 0 && (unsigned int)f.idx < P.spec_samples) {
-                    const float4 ts = sc.spec_dirs[(size_t)f.mat * sc.spec_samples + (unsigned int)f.idx];
-                    next_d = tangent_to_world(f.hit_n, mk3(ts.x, ts.y, ts.z));
-                    const float cw = ref_max(0.0f, dot3(next_d, f.ray_d * -1.0f));
-                    next_T = own * (mk3(fm.specular[0], fm.specular[1], fm.specular[2]) * cw);
-                    next_o = f.hit_p;
-                    f.idx++;
-                    spawned = true;
-                } else {
-                    f.stage = WF_STAGE_ALPHA;
-                }
+            if (kind < 0 && f.stage == WF_STAGE_SPEC) {                             // raytracer.cpp:528-535
+                if (iters > 0 && (unsigned int)f.idx < P.spec_samples) kind = 1;
+                else f.stage = WF_STAGE_ALPHA;
             }
-            if (!spawned && f.stage == WF_STAGE_ALPHA) {                            // raytracer.cpp:547-552
+            if (kind < 0 && f.stage == WF_STAGE_ALPHA) {                            // raytracer.cpp:547-552
                 f.stage = WF_STAGE_DONE;
-                if (f.alpha < 1.0f) {
-                    next_o = f.hit_pos + f.ray_d * P.ray_bias * 2.0f;
-                    next_d = f.ray_d;
-                    next_T = f.T_in * (1.0f - f.alpha);
-                    spawned = true;
+                if (f.alpha < 1.0f) kind = 2;
+            }
+            const bool spawned = kind >= 0;
+            if (kind == 2) {
+                next_o = f.hit_pos + f.ray_d * P.ray_bias * 2.0f;
+                next_d = f.ray_d;
+                next_T = f.T_in * (1.0f - f.alpha);
+            } else if (kind >= 0) {
+                float4 ts;
+                if (kind == 0) {
+                    const unsigned int series_i = (unsigned int)(rng_next<RING>(rng, ring, ring_stride) % 1024ull);
+                    ts = sc.diffuse_dirs[series_i];
+                } else {
+                    ts = sc.spec_dirs[(size_t)f.mat * sc.spec_samples + (unsigned int)f.idx];
                 }
+                next_d = tangent_to_world(f.hit_n, mk3(ts.x, ts.y, ts.z));
+                const float cw = kind == 0 ? ref_max(0.0f, dot3(f.hit_n, next_d)) : ref_max(0.0f, dot3(next_d, f.ray_d * -1.0f));
+                const f3 lobe = kind == 0 ? mk3(fm.diffuse[0], fm.diffuse[1], fm.diffuse[2]) * f.w_diffuse
+                                          : mk3(fm.specular[0], fm.specular[1], fm.specular[2]);
+                next_T = own * (lobe * cw);
+                next_o = f.hit_p;
+                f.idx++;
             }
             if (!spawned) { f_held = false; mode = M_RETURN_UP; continue; }
             f_held = true;                                // f (at `level`) stays in registers until the child's fate is known
