@@ -353,7 +353,8 @@ void build_bvh4q(const float * verts, uint32_t n_tris, uint32_t leaf_max, uint32
         for (uint32_t k = 0; k < 4; ++k) {
             int32_t link;
             if (k >= w.n) {
-                link = (int32_t)0x80000001;                  // empty slot (never a valid leaf or node)
+                link = ~(int32_t)(n_tris << 2);               // empty slot: a 1-triangle leaf naming the all-zero dummy record
+                                                             // the uploader appends at slot n_tris (always rejected: d = 0)
             } else if (is_leaf(w.tmp[k])) {
                 link = leaf_link(w.tmp[k]);
             } else {

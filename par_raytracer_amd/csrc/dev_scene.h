@@ -108,7 +108,7 @@ struct DevCounters {          // device-side accumulators (atomics, one add per 
     unsigned long long tri_tests;
     unsigned long long shaded_hits;
     // wave-level step counts (COUNT builds only): lane utilisation = lane-level count / (64 * wave-level count)
-    unsigned long long wave_node_steps, wave_leaf_steps, wave_tri_steps, wave_refills;
+    unsigned long long wave_node_steps, wave_leaf_steps, wave_tri_steps, wave_refills, max_sp, culled;
 };
 
 enum { BVH_LEAF_MAX = 4 };

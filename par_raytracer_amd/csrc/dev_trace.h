@@ -35,6 +35,7 @@ enum { TRACE_CLOSEST = 0, TRACE_ANY = 1 };
 struct TraceStats {
     unsigned int nodes, tris;
     unsigned int wnodes, wleaves, wtris, wrefills;   // counted by the first active lane only (wave-level steps)
+    unsigned int max_sp, culled;                     // deepest stack use; popped nodes whose entry distance was already beyond the hit
 };
 
 PRT_D bool first_active_lane() {
@@ -84,8 +85,8 @@ PRT_D bool tri_test(f3 o, f3 d, f3 qp, f3 a, f3 ab, f3 ac, f3 n, float best_t, f
 struct TravRay {
     f3 o, d;                          // origin ALREADY biased by direction * ray_bias (raytracer.cpp:163), direction
     float ix, iy, iz;                 // 1 / direction, components clamped away from 0
-    float plx, ply, plz;              // (o + pad) / direction: entry parameter offset of the widened lo planes
-    float phx, phy, phz;              // (o - pad) / direction: same for the hi planes
+    float pnx, pny, pnz;              // (o +- pad) / direction for the plane the ray ENTERS through on each axis
+    float pfx, pfy, pfz;              // ... and for the plane it LEAVES through (pad always widens the box)
     HitRec best;
     unsigned int best_rank;
     int node, sp, kind;
@@ -124,8 +125,10 @@ PRT_D void trav_init(TravRay & r, f3 o, f3 d, int kind, float pad, const TravSta
     float dy = fabsf(d.y) < tiny ? (d.y < 0.0f ? -tiny : tiny) : d.y;
     float dz = fabsf(d.z) < tiny ? (d.z < 0.0f ? -tiny : tiny) : d.z;
     r.ix = 1.0f / dx; r.iy = 1.0f / dy; r.iz = 1.0f / dz;
-    r.plx = (o.x + pad) * r.ix; r.ply = (o.y + pad) * r.iy; r.plz = (o.z + pad) * r.iz;
-    r.phx = (o.x - pad) * r.ix; r.phy = (o.y - pad) * r.iy; r.phz = (o.z - pad) * r.iz;
+    // direction >= 0: enters through the lo plane (seen from o + pad), leaves through hi (from o - pad); else swapped
+    r.pnx = (dx < 0.0f ? o.x - pad : o.x + pad) * r.ix; r.pfx = (dx < 0.0f ? o.x + pad : o.x - pad) * r.ix;
+    r.pny = (dy < 0.0f ? o.y - pad : o.y + pad) * r.iy; r.pfy = (dy < 0.0f ? o.y + pad : o.y - pad) * r.iy;
+    r.pnz = (dz < 0.0f ? o.z - pad : o.z + pad) * r.iz; r.pfz = (dz < 0.0f ? o.z + pad : o.z - pad) * r.iz;
     r.best.t = 3.402823466e+38f;
     r.best.v = r.best.w = 0.0f;
     r.best.tri = -1;
@@ -152,30 +155,35 @@ template <int BLOCK, bool COUNT>
 PRT_D void trav_node_step(const DevScene & sc, TravRay & r, const TravStack & stk, TraceStats & st) {
     const uint4 * np = reinterpret_cast<const uint4 *>(sc.nodes) + 4 * (size_t)r.node;
     const uint4 w0 = np[0], w1 = np[1], w2 = np[2], w3 = np[3];
-    if (COUNT) { st.nodes++; if (first_active_lane()) st.wnodes++; }
+    if (COUNT) { st.nodes++; if (first_active_lane()) st.wnodes++; if ((unsigned int)r.sp > st.max_sp) st.max_sp = (unsigned int)r.sp; }
     const float kx = __uint_as_float((w0.w & 0xFFu) << 23) * r.ix;
     const float ky = __uint_as_float(((w0.w >> 8) & 0xFFu) << 23) * r.iy;
     const float kz = __uint_as_float(((w0.w >> 16) & 0xFFu) << 23) * r.iz;
-    const unsigned int count = w0.w >> 24;
     const float ox = __uint_as_float(w0.x), oy = __uint_as_float(w0.y), oz = __uint_as_float(w0.z);
-    const float clx = __builtin_fmaf(ox, r.ix, -r.plx), chx = __builtin_fmaf(ox, r.ix, -r.phx);
-    const float cly = __builtin_fmaf(oy, r.iy, -r.ply), chy = __builtin_fmaf(oy, r.iy, -r.phy);
-    const float clz = __builtin_fmaf(oz, r.iz, -r.plz), chz = __builtin_fmaf(oz, r.iz, -r.phz);
-    const unsigned int qlx = w1.x, qly = w1.y, qlz = w1.z, qhx = w1.w, qhy = w2.x, qhz = w2.y;
+    // entry / exit parameter of the node origin on each axis; the ray's direction signs pick, per axis, which
+    // quantised plane set (lo or hi bytes) is the entry side - no per-plane min/max, and an empty child slot
+    // (lo = 255 > hi = 0 on every axis) can never satisfy entry <= exit.
+    const float cnx = __builtin_fmaf(ox, r.ix, -r.pnx), cfx = __builtin_fmaf(ox, r.ix, -r.pfx);
+    const float cny = __builtin_fmaf(oy, r.iy, -r.pny), cfy = __builtin_fmaf(oy, r.iy, -r.pfy);
+    const float cnz = __builtin_fmaf(oz, r.iz, -r.pnz), cfz = __builtin_fmaf(oz, r.iz, -r.pfz);
+    const bool sx = r.ix < 0.0f, sy = r.iy < 0.0f, sz = r.iz < 0.0f;
+    const unsigned int qnx = sx ? w1.w : w1.x, qfx = sx ? w1.x : w1.w;
+    const unsigned int qny = sy ? w2.x : w1.y, qfy = sy ? w1.y : w2.x;
+    const unsigned int qnz = sz ? w2.y : w1.z, qfz = sz ? w1.z : w2.y;
     float key[4];
     int link[4] = { (int)w2.z, (int)w2.w, (int)w3.x, (int)w3.y };
     const float inf = __uint_as_float(0x7F800000u);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const float ax = __builtin_fmaf((float)((qlx >> (8 * k)) & 0xFFu), kx, clx);
-        const float bx = __builtin_fmaf((float)((qhx >> (8 * k)) & 0xFFu), kx, chx);
-        const float ay = __builtin_fmaf((float)((qly >> (8 * k)) & 0xFFu), ky, cly);
-        const float by = __builtin_fmaf((float)((qhy >> (8 * k)) & 0xFFu), ky, chy);
-        const float az = __builtin_fmaf((float)((qlz >> (8 * k)) & 0xFFu), kz, clz);
-        const float bz = __builtin_fmaf((float)((qhz >> (8 * k)) & 0xFFu), kz, chz);
-        const float tmin = fmaxf(fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz)), 0.0f);
-        const float tmax = fminf(fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz)), r.best.t);
-        key[k] = ((unsigned int)k < count && tmin <= tmax) ? tmin : inf;
+        const float nx = __builtin_fmaf((float)((qnx >> (8 * k)) & 0xFFu), kx, cnx);
+        const float fx = __builtin_fmaf((float)((qfx >> (8 * k)) & 0xFFu), kx, cfx);
+        const float ny = __builtin_fmaf((float)((qny >> (8 * k)) & 0xFFu), ky, cny);
+        const float fy = __builtin_fmaf((float)((qfy >> (8 * k)) & 0xFFu), ky, cfy);
+        const float nz = __builtin_fmaf((float)((qnz >> (8 * k)) & 0xFFu), kz, cnz);
+        const float fz = __builtin_fmaf((float)((qfz >> (8 * k)) & 0xFFu), kz, cfz);
+        const float tmin = fmaxf(fmaxf(fmaxf(nx, ny), nz), 0.0f);
+        const float tmax = fminf(fminf(fminf(fx, fy), fz), r.best.t);
+        key[k] = tmin <= tmax ? tmin : inf;
     }
     // sorting network for 4 keys, ascending; misses (inf) sink to the end
     cswap(key[0], key[1], link[0], link[1]);
@@ -189,6 +197,7 @@ PRT_D void trav_node_step(const DevScene & sc, TravRay & r, const TravStack & st
         if (key[1] < inf) { stack_push<BLOCK>(stk, r.sp, link[1]); r.sp++; }
         r.node = link[0];
     } else {
+        if (COUNT && r.best.tri >= 0) st.culled++;
         r.sp--;
         r.node = stack_pop<BLOCK>(stk, r.sp);
     }

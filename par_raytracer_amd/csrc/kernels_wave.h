@@ -131,7 +131,7 @@ __global__ __launch_bounds__(BLOCK) void k_trace(DevScene sc, DevParams P, WaveB
     int sample = 0;
     bool exhausted = false;              // wave-uniform: the queue has no more rays to hand out
     TraceStats st;
-    st.nodes = st.tris = st.wnodes = st.wleaves = st.wtris = st.wrefills = 0;
+    st.nodes = st.tris = st.wnodes = st.wleaves = st.wtris = st.wrefills = st.max_sp = st.culled = 0;
 
     unsigned int chunk_next = 0, chunk_end = 0;      // wave-uniform: rays reserved for this wave, not yet handed out
     for (;;) {
@@ -229,6 +229,8 @@ __global__ __launch_bounds__(BLOCK) void k_trace(DevScene sc, DevParams P, WaveB
         atomicAdd(&ctr->wave_leaf_steps, (unsigned long long)st.wleaves);
         atomicAdd(&ctr->wave_tri_steps, (unsigned long long)st.wtris);
         atomicAdd(&ctr->wave_refills, (unsigned long long)st.wrefills);
+        atomicMax(&ctr->max_sp, (unsigned long long)st.max_sp);
+        atomicAdd(&ctr->culled, (unsigned long long)st.culled);
     }
 }
 

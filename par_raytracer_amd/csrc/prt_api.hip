@@ -452,6 +452,10 @@ int render_pixels(prt_ctx * ctx, const prt_camera * cam_in, const prt_params * p
                     100.0 * (double)h.tri_tests / (64.0 * (double)h.wave_tri_steps), (unsigned long long)h.wave_tri_steps,
                     (unsigned long long)h.wave_leaf_steps, (unsigned long long)h.wave_refills,
                     h.wave_refills ? (double)host_ray_count / (double)h.wave_refills : 0.0);
+        if (getenv("PRT_DEBUG_UTIL") && h.wave_node_steps)
+            fprintf(stderr, "[prt] deepest stack %llu entries (LDS column %u, bound %u); %llu of %llu node visits (%.1f%%) hit no child after a hit was known\n",
+                    (unsigned long long)h.max_sp, stack_entries, ctx->stack_bound, (unsigned long long)h.culled,
+                    (unsigned long long)h.node_visits, 100.0 * (double)h.culled / (double)h.node_visits);
         memset(counters, 0, sizeof(*counters));
         counters->ray_count = h.ray_count;
         counters->node_visits = h.node_visits;
@@ -609,7 +613,7 @@ int prt_upload_scene(prt_ctx * ctx, const prt_scene_desc * s) {
     }
 
     // ---- device records in BVH leaf order
-    const uint32_t n_rec = std::max(1u, n_tris);
+    const uint32_t n_rec = n_tris + 1;                              // + the all-zero dummy triangle empty BVH slots point at
     std::vector<float4> tris((size_t)n_rec * 3, make_float4(0, 0, 0, 0)), shade((size_t)n_rec * 4, make_float4(0, 0, 0, 0));
     std::vector<unsigned int> rank(n_rec, 0);
     float abs_max = 0.0f;
@@ -817,8 +821,15 @@ int prt_debug_check_bvh(const prt_scene_desc * s, uint64_t * out) {
         }
         const uint32_t count = d[3] >> 24;
         if (count < 1 || count > 4) violations++;
-        for (uint32_t k = 0; k < count && k < 4; ++k) {
+        for (uint32_t k = 0; k < 4; ++k) {
             Item ch;
+            if (k >= count) {
+                // empty slot: inverted box on every axis and a link to the dummy leaf
+                const int32_t el = (int32_t)d[10 + k];
+                if (el >= 0 || ((uint32_t)~el >> 2) != n_tris) violations++;
+                for (int a = 0; a < 3; ++a) if (((d[4 + a] >> (8 * k)) & 0xFFu) != 255u || ((d[7 + a] >> (8 * k)) & 0xFFu) != 0u) violations++;
+                continue;
+            }
             for (int a = 0; a < 3; ++a) {
                 ch.lo[a] = std::max(it.lo[a], org[a] + (float)((d[4 + a] >> (8 * k)) & 0xFFu) * scale[a]);
                 ch.hi[a] = std::min(it.hi[a], org[a] + (float)((d[7 + a] >> (8 * k)) & 0xFFu) * scale[a]);
@@ -832,7 +843,8 @@ int prt_debug_check_bvh(const prt_scene_desc * s, uint64_t * out) {
                 leaves++;
                 for (uint32_t i = 0; i < cnt; ++i) {
                     const uint32_t slot = first + i;
-                    if (slot >= n_tris) { if (n_tris) violations++; continue; }
+                    if (slot == n_tris) continue;                       // the dummy triangle of an empty slot
+                    if (slot > n_tris) { violations++; continue; }
                     refs++;
                     if (seen[slot]++) violations++;
                     const uint32_t t = bvh.tri_order[slot];
