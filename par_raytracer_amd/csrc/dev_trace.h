@@ -15,9 +15,7 @@
 // can differ by an ulp from the final `t*ood < best` test for two nearly coincident hits, the one place
 // where visit order is observable (SURVEY.md §7.2 "Tie-breaking").
 //
-// Traversal stack: per-lane column of a workgroup LDS array (entry e of lane l at stack[e*BLOCK + l],
-// so a wave's push/pop of one level is one conflict-free ds_write/ds_read_b32), with a global spill column
-// behind it for the (never observed) case of a ray holding more entries than the LDS column has.
+// Traversal stack: per-lane LDS column, with a flag-and-retrace fallback on a global column (see LdsStack).
 #pragma once
 
 #include "dev_scene.h"
@@ -90,33 +88,37 @@ struct TravRay {
     HitRec best;
     unsigned int best_rank;
     int node, sp, kind;
+    bool overflow;                    // a push was dropped: the result is not trustworthy, re-trace on the slow stack
 };
 
-// Stack access.  Entries [0, lds_entries) live in this lane's LDS column; a traversal that ever needs more
-// (3 pushes per level are possible, far more than any real ray uses) continues in a per-lane global spill
-// column, so the LDS footprint - which bounds occupancy - is sized for the common case, not the worst.
-struct TravStack {
-    int * lds;                 // this lane's column, stride BLOCK
-    int * spill;               // this lane's global column, stride spill_stride (may be null if never needed)
-    unsigned int lds_entries;
-    size_t spill_stride;
+// Traversal stacks.  The fast one is this lane's column of a workgroup LDS array (entry e of lane l at
+// col[e*BLOCK + l]: a wave's push/pop of one level is one conflict-free ds_write/ds_read_b32).  Its height
+// bounds occupancy, so it is sized for what rays really use (<= 24 entries; the deepest ever observed on the 1M
+// triangle scene is 16) and not for the worst case (3 pushes per 4-wide level).  A push that does not fit is
+// DROPPED and the ray is flagged; a flagged ray is re-traced from scratch on the slow stack, a per-lane column in
+// global memory that holds the full bound.  The hot loop therefore carries one compare per push and no spill code.
+template <int BLOCK>
+struct LdsStack {
+    int * col;
+    unsigned int cap;
+    PRT_D bool push(int sp, int v) const {
+        if ((unsigned int)sp < cap) { col[sp * BLOCK] = v; return true; }
+        return false;
+    }
+    PRT_D int pop(int sp) const { return col[sp * BLOCK]; }
 };
 
-template <int BLOCK>
-PRT_D void stack_push(const TravStack & s, int sp, int v) {
-    if ((unsigned int)sp < s.lds_entries) s.lds[sp * BLOCK] = v;
-    else s.spill[(size_t)((unsigned int)sp - s.lds_entries) * s.spill_stride] = v;
-}
-template <int BLOCK>
-PRT_D int stack_pop(const TravStack & s, int sp) {
-    if ((unsigned int)sp < s.lds_entries) return s.lds[sp * BLOCK];
-    return s.spill[(size_t)((unsigned int)sp - s.lds_entries) * s.spill_stride];
-}
+struct GlobalStack {
+    int * col;
+    size_t stride;
+    PRT_D bool push(int sp, int v) const { col[(size_t)sp * stride] = v; return true; }
+    PRT_D int pop(int sp) const { return col[(size_t)sp * stride]; }
+};
 
 enum { TRAV_SENTINEL = (int)0x80000000 };   // bottom-of-stack marker; never a valid leaf link (first_tri < 2^29)
 
-template <int BLOCK>
-PRT_D void trav_init(TravRay & r, f3 o, f3 d, int kind, float pad, const TravStack & stk) {
+template <class STK>
+PRT_D void trav_init(TravRay & r, f3 o, f3 d, int kind, float pad, const STK & stk) {
     r.o = o;
     r.d = d;
     // direction components are clamped away from 0 so no inf/NaN enters the box test
@@ -134,8 +136,9 @@ PRT_D void trav_init(TravRay & r, f3 o, f3 d, int kind, float pad, const TravSta
     r.best.tri = -1;
     r.best_rank = 0xFFFFFFFFu;
     r.kind = kind;
-    stk.lds[0] = TRAV_SENTINEL;
+    stk.push(0, TRAV_SENTINEL);
     r.sp = 1;
+    r.overflow = false;
     r.node = 0;
 }
 
@@ -151,8 +154,8 @@ PRT_D void cswap(float & ka, float & kb, int & la, int & lb) {
 //   plane = origin + q * 2^e  =>  t = (plane - o -+ pad) / d = q * (2^e / d) + (origin / d - (o +- pad) / d)
 // so after 3 scale products and 6 FMAs per node every plane costs one byte->float convert and one FMA.
 // The slab test may use FMA: it only has to be conservative, and the boxes are widened by `pad`.
-template <int BLOCK, bool COUNT>
-PRT_D void trav_node_step(const DevScene & sc, TravRay & r, const TravStack & stk, TraceStats & st) {
+template <class STK, bool COUNT>
+PRT_D void trav_node_step(const DevScene & sc, TravRay & r, const STK & stk, TraceStats & st) {
     const uint4 * np = reinterpret_cast<const uint4 *>(sc.nodes) + 4 * (size_t)r.node;
     const uint4 w0 = np[0], w1 = np[1], w2 = np[2], w3 = np[3];
     if (COUNT) { st.nodes++; if (first_active_lane()) st.wnodes++; if ((unsigned int)r.sp > st.max_sp) st.max_sp = (unsigned int)r.sp; }
@@ -192,20 +195,20 @@ PRT_D void trav_node_step(const DevScene & sc, TravRay & r, const TravStack & st
     cswap(key[1], key[3], link[1], link[3]);
     cswap(key[1], key[2], link[1], link[2]);
     if (key[0] < inf) {
-        if (key[3] < inf) { stack_push<BLOCK>(stk, r.sp, link[3]); r.sp++; }
-        if (key[2] < inf) { stack_push<BLOCK>(stk, r.sp, link[2]); r.sp++; }
-        if (key[1] < inf) { stack_push<BLOCK>(stk, r.sp, link[1]); r.sp++; }
+        if (key[3] < inf) { if (stk.push(r.sp, link[3])) r.sp++; else r.overflow = true; }
+        if (key[2] < inf) { if (stk.push(r.sp, link[2])) r.sp++; else r.overflow = true; }
+        if (key[1] < inf) { if (stk.push(r.sp, link[1])) r.sp++; else r.overflow = true; }
         r.node = link[0];
     } else {
         if (COUNT && r.best.tri >= 0) st.culled++;
         r.sp--;
-        r.node = stack_pop<BLOCK>(stk, r.sp);
+        r.node = stk.pop(r.sp);
     }
 }
 
 // The leaf in r.node: test its triangles, then pop.  Returns true when an any-hit ray found its hit.
-template <int BLOCK, bool COUNT>
-PRT_D bool trav_leaf(const DevScene & sc, TravRay & r, const TravStack & stk, TraceStats & st) {
+template <class STK, bool COUNT>
+PRT_D bool trav_leaf(const DevScene & sc, TravRay & r, const STK & stk, TraceStats & st) {
     const f3 qp = r.o - (r.o + r.d);                 // raytracer.cpp:88-89, not bitwise -d
     const unsigned int leaf = (unsigned int)~r.node;
     const unsigned int first = leaf >> 2, count = (leaf & 3u) + 1u;
@@ -237,23 +240,34 @@ PRT_D bool trav_leaf(const DevScene & sc, TravRay & r, const TravStack & stk, Tr
         }
     }
     r.sp--;
-    r.node = stack_pop<BLOCK>(stk, r.sp);
+    r.node = stk.pop(r.sp);
     return false;
 }
 
 // Whole-ray traversal, "while-while" (Aila & Laine): every lane first walks internal nodes until it holds
 // a leaf (or runs out of work), and only then does the wave run the triangle code.  With 64 lanes a fused
 // node-or-leaf loop would execute the (4x longer) leaf body in almost every iteration.
-template <int BLOCK, bool COUNT>
-PRT_D HitRec trace_ray(const DevScene & sc, f3 o, f3 d, int kind, float pad, const TravStack & stk, TraceStats & st) {
+template <class STK, bool COUNT>
+PRT_D HitRec trace_ray_on(const DevScene & sc, f3 o, f3 d, int kind, float pad, const STK & stk, TraceStats & st, bool & overflow) {
     TravRay r;
-    trav_init<BLOCK>(r, o, d, kind, pad, stk);
+    trav_init(r, o, d, kind, pad, stk);
     for (;;) {
-        while (r.node >= 0) trav_node_step<BLOCK, COUNT>(sc, r, stk, st);
+        while (r.node >= 0) trav_node_step<STK, COUNT>(sc, r, stk, st);
         if (r.node == TRAV_SENTINEL) break;
-        if (trav_leaf<BLOCK, COUNT>(sc, r, stk, st)) break;
+        if (trav_leaf<STK, COUNT>(sc, r, stk, st)) break;
     }
+    overflow = r.overflow;
     return r.best;
+}
+
+// Fast stack first; the (never observed) overflow case re-traces on the slow stack.
+template <int BLOCK, bool COUNT>
+PRT_D HitRec trace_ray(const DevScene & sc, f3 o, f3 d, int kind, float pad, const LdsStack<BLOCK> & fast, const GlobalStack & slow,
+                       TraceStats & st) {
+    bool overflow;
+    HitRec h = trace_ray_on<LdsStack<BLOCK>, COUNT>(sc, o, d, kind, pad, fast, st, overflow);
+    if (overflow) h = trace_ray_on<GlobalStack, COUNT>(sc, o, d, kind, pad, slow, st, overflow);
+    return h;
 }
 
 }  // namespace prt

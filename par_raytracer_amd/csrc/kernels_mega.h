@@ -37,11 +37,12 @@ __global__ __launch_bounds__(BLOCK) void k_render_mega(DevScene sc, DevCamera ca
     extern __shared__ int s_stack[];
     const unsigned int sid = blockIdx.x * BLOCK + threadIdx.x;
     if (sid >= n_samples) return;
-    TravStack stack;
-    stack.lds = s_stack + threadIdx.x;
-    stack.spill = P.stack_spill + sid;
-    stack.lds_entries = P.stack_lds_entries;
-    stack.spill_stride = P.stack_spill_stride;
+    LdsStack<BLOCK> stack;
+    stack.col = s_stack + threadIdx.x;
+    stack.cap = P.stack_lds_entries;
+    GlobalStack slow;
+    slow.col = P.stack_spill + sid;
+    slow.stride = P.stack_spill_stride;
     const unsigned int pixel = pixel_of_local(P, sid / P.spp);
     const unsigned int samp = sid % P.spp;
     u64 * ring = RING ? ring_ws + sid : nullptr;
@@ -61,7 +62,7 @@ __global__ __launch_bounds__(BLOCK) void k_render_mega(DevScene sc, DevCamera ca
     while (sample_advance<RING>(sc, P, S, cur, store, hit, req, shaded, ring, ring_stride)) {
         rays++;                                                     // debug->ray_count++  raytracer.cpp:161
         const f3 ob = req.o + req.d * P.ray_bias;                   // raytracer.cpp:163
-        hit = trace_ray<BLOCK, COUNT>(sc, ob, req.d, req.kind, P.box_pad, stack, st);
+        hit = trace_ray<BLOCK, COUNT>(sc, ob, req.d, req.kind, P.box_pad, stack, slow, st);
     }
     sample_rgb[sid] = make_float4(S.ret.x, S.ret.y, S.ret.z, 0.0f);
     flush_counters(ctr, rays, shaded, st, COUNT);

@@ -36,11 +36,12 @@ __global__ __launch_bounds__(BLOCK, 4) void k_render_persistent(DevScene sc, Dev
     extern __shared__ int s_stack[];
     const unsigned int slot = blockIdx.x * BLOCK + threadIdx.x;          // persistent lane id
     const unsigned int lane = lane_id();
-    TravStack stack;
-    stack.lds = s_stack + threadIdx.x;
-    stack.spill = P.stack_spill + slot;
-    stack.lds_entries = P.stack_lds_entries;
-    stack.spill_stride = P.stack_spill_stride;
+    LdsStack<BLOCK> stack;
+    stack.col = s_stack + threadIdx.x;
+    stack.cap = P.stack_lds_entries;
+    GlobalStack slow;
+    slow.col = P.stack_spill + slot;
+    slow.stride = P.stack_spill_stride;
     u64 * ring = RING ? ring_ws + slot : nullptr;
     const size_t ring_stride = (size_t)gridDim.x * BLOCK;
 
@@ -96,7 +97,7 @@ __global__ __launch_bounds__(BLOCK, 4) void k_render_persistent(DevScene sc, Dev
             if (sample_advance<RING>(sc, P, S, cur, store, hit, req, shaded, ring, ring_stride)) {
                 rays++;                                                     // debug->ray_count++  raytracer.cpp:161
                 const f3 ob = req.o + req.d * P.ray_bias;                   // raytracer.cpp:163
-                trav_init<BLOCK>(r, ob, req.d, req.kind, P.box_pad, stack);
+                trav_init(r, ob, req.d, req.kind, P.box_pad, stack);
                 state = LANE_TRAVERSE;
             } else {
                 sample_rgb[sid] = make_float4(S.ret.x, S.ret.y, S.ret.z, 0.0f);
@@ -117,12 +118,16 @@ __global__ __launch_bounds__(BLOCK, 4) void k_render_persistent(DevScene sc, Dev
             const int walkers = __popcll(__ballot(r.node >= 0));
             const int nmin = node_min < (walkers >> 1) ? node_min : (walkers >> 1);
             while (r.node >= 0) {
-                trav_node_step<BLOCK, COUNT>(sc, r, stack, st);
+                trav_node_step<LdsStack<BLOCK>, COUNT>(sc, r, stack, st);
                 if (__popcll(__ballot(r.node >= 0)) < nmin) break;
             }
             bool fin = r.node == TRAV_SENTINEL;
-            if (!fin && r.node < 0) fin = trav_leaf<BLOCK, COUNT>(sc, r, stack, st);
+            if (!fin && r.node < 0) fin = trav_leaf<LdsStack<BLOCK>, COUNT>(sc, r, stack, st);
             if (fin) {
+                if (r.overflow) {
+                    bool again;
+                    r.best = trace_ray_on<GlobalStack, COUNT>(sc, r.o, r.d, r.kind, P.box_pad, slow, st, again);
+                }
                 hit = r.best;
                 state = LANE_ADVANCE;
                 break;

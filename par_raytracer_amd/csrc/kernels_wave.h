@@ -45,7 +45,8 @@ struct WaveBuffers {
     float4 * sq_o;               // shadow queue: (o.xyz, sample)
     float4 * sq_d;               //               (d.xyz, kind)
     float4 * sq_c;               //               (radiance if unoccluded .xyz, light distance^2)
-    unsigned int * counts;       // [0] next closest count, [1] next shadow count, [2] trace fetch head
+    unsigned int * counts;       // [0] next closest count, [1] next shadow count, [2] trace fetch head, [3] overflowed rays
+    unsigned int * overflow;     // ray indices whose traversal dropped a stack push (re-traced by k_trace_overflow)
     unsigned int n_samples;
 };
 
@@ -113,11 +114,9 @@ __global__ __launch_bounds__(BLOCK) void k_trace(DevScene sc, DevParams P, WaveB
                                                   unsigned int n_shadow, int keep_min, int node_min, unsigned int chunk, int multi_light,
                                                   DevCounters * ctr) {
     extern __shared__ int s_stack[];
-    TravStack stack;
-    stack.lds = s_stack + threadIdx.x;
-    stack.spill = P.stack_spill + (blockIdx.x * BLOCK + threadIdx.x);
-    stack.lds_entries = P.stack_lds_entries;
-    stack.spill_stride = P.stack_spill_stride;
+    LdsStack<BLOCK> stack;
+    stack.col = s_stack + threadIdx.x;
+    stack.cap = P.stack_lds_entries;
     const unsigned int total = n_closest + n_shadow;
     const unsigned int lane = lane_id();
     const float4 * rq_o = B.rq_o[cur];
@@ -174,7 +173,7 @@ __global__ __launch_bounds__(BLOCK) void k_trace(DevScene sc, DevParams P, WaveB
                     sample = as_i(ro.w);
                     const f3 d = mk3(rd.x, rd.y, rd.z);
                     const f3 ob = mk3(ro.x, ro.y, ro.z) + d * P.ray_bias;          // raytracer.cpp:163
-                    trav_init<BLOCK>(r, ob, d, kind == WF_KIND_SHADOW_ANY ? TRACE_ANY : TRACE_CLOSEST, P.box_pad, stack);
+                    trav_init(r, ob, d, kind == WF_KIND_SHADOW_ANY ? TRACE_ANY : TRACE_CLOSEST, P.box_pad, stack);
                     payload.w = kind == WF_KIND_CLOSEST ? 0.0f : (kind == WF_KIND_SHADOW_ANY ? -1.0f : payload.w);
                     ray = (int)idx;
                 }
@@ -192,13 +191,17 @@ __global__ __launch_bounds__(BLOCK) void k_trace(DevScene sc, DevParams P, WaveB
             const int walkers = __popcll(__ballot(r.node >= 0));
             const int nmin = node_min < (walkers >> 1) ? node_min : (walkers >> 1);
             while (r.node >= 0) {
-                trav_node_step<BLOCK, COUNT>(sc, r, stack, st);
+                trav_node_step<LdsStack<BLOCK>, COUNT>(sc, r, stack, st);
                 if (__popcll(__ballot(r.node >= 0)) < nmin) break;
             }
             bool fin = r.node == TRAV_SENTINEL;
-            if (!fin && r.node < 0) fin = trav_leaf<BLOCK, COUNT>(sc, r, stack, st);
+            if (!fin && r.node < 0) fin = trav_leaf<LdsStack<BLOCK>, COUNT>(sc, r, stack, st);
             if (fin) {
-                if ((unsigned int)ray < n_closest) {
+                if (r.overflow) {
+                    // a push did not fit the LDS column (never observed on real scenes): hand the ray to
+                    // k_trace_overflow, which redoes it on a full-height global stack before k_shade runs
+                    B.overflow[atomicAdd(B.counts + 3, 1u)] = (unsigned int)ray;
+                } else if ((unsigned int)ray < n_closest) {
                     B.hits[ray] = make_float4(r.best.t, r.best.v, r.best.w, as_f(r.best.tri));
                 } else {
                     // shadow ray: add the precomputed radiance when unoccluded.  payload.w < 0: directional light
@@ -231,6 +234,65 @@ __global__ __launch_bounds__(BLOCK) void k_trace(DevScene sc, DevParams P, WaveB
         atomicAdd(&ctr->wave_refills, (unsigned long long)st.wrefills);
         atomicMax(&ctr->max_sp, (unsigned long long)st.max_sp);
         atomicAdd(&ctr->culled, (unsigned long long)st.culled);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Slow path of k_trace: rays whose LDS stack column overflowed are re-traced from scratch on a per-lane global
+// stack that holds the full worst-case bound.  A small fixed grid launched after every k_trace of a scene whose
+// bound exceeds the LDS column; it reads the list length on the device (no host round trip) and normally finds 0.
+template <bool COUNT>
+__global__ __launch_bounds__(256) void k_trace_overflow(DevScene sc, DevParams P, WaveBuffers B, int cur, unsigned int n_closest,
+                                                         int multi_light, DevCounters * ctr) {
+    const unsigned int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned int n_overflow = B.counts[3];
+    TraceStats st;
+    st.nodes = st.tris = st.wnodes = st.wleaves = st.wtris = st.wrefills = st.max_sp = st.culled = 0;
+    GlobalStack slow;
+    slow.col = P.stack_spill + gid;
+    slow.stride = P.stack_spill_stride;
+    for (unsigned int i = gid; i < n_overflow; i += gridDim.x * blockDim.x) {
+        const unsigned int idx = B.overflow[i];
+        float4 ro, rd, payload = make_float4(0, 0, 0, 0);
+        int kind;
+        if (idx < n_closest) {
+            ro = B.rq_o[cur][idx];
+            rd = B.rq_d[cur][idx];
+            kind = WF_KIND_CLOSEST;
+        } else {
+            const unsigned int j = idx - n_closest;
+            ro = B.sq_o[j];
+            rd = B.sq_d[j];
+            payload = B.sq_c[j];
+            kind = as_i(rd.w);
+        }
+        const int sample = as_i(ro.w);
+        const f3 d = mk3(rd.x, rd.y, rd.z);
+        const f3 ob = mk3(ro.x, ro.y, ro.z) + d * P.ray_bias;
+        bool again;
+        const HitRec best = trace_ray_on<GlobalStack, COUNT>(sc, ob, d, kind == WF_KIND_SHADOW_ANY ? TRACE_ANY : TRACE_CLOSEST,
+                                                             P.box_pad, slow, st, again);
+        if (idx < n_closest) {
+            B.hits[idx] = make_float4(best.t, best.v, best.w, as_f(best.tri));
+        } else {
+            const float dist_sq = kind == WF_KIND_SHADOW_ANY ? -1.0f : payload.w;
+            const bool lit = best.tri < 0 || (dist_sq >= 0.0f && best.t * best.t <= dist_sq);
+            if (lit) {
+                if (multi_light) {
+                    atomicAdd(&B.accum[sample].x, payload.x);
+                    atomicAdd(&B.accum[sample].y, payload.y);
+                    atomicAdd(&B.accum[sample].z, payload.z);
+                } else {
+                    float4 a = B.accum[sample];
+                    a.x += payload.x; a.y += payload.y; a.z += payload.z;
+                    B.accum[sample] = a;
+                }
+            }
+        }
+    }
+    if (COUNT) {
+        atomicAdd(&ctr->node_visits, (unsigned long long)st.nodes);
+        atomicAdd(&ctr->tri_tests, (unsigned long long)st.tris);
     }
 }
 

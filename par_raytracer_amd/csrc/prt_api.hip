@@ -93,6 +93,7 @@ struct prt_ctx {
     DevBuf<float4> wf_f4;                 // one slab carved into the float4 arrays of WaveBuffers
     DevBuf<ulonglong2> wf_rng;
     DevBuf<unsigned int> wf_counts;
+    DevBuf<unsigned int> wf_overflow;
     int cu_count = 0;
     unsigned int stack_bound = 0;
     DevBuf<int> stack_spill;
@@ -225,6 +226,7 @@ int render_wavefront(prt_ctx * ctx, const DevCamera & cam, const DevParams & P, 
     HIP_TRY(ctx, ctx->wf_f4.ensure(f4_total));
     HIP_TRY(ctx, ctx->wf_rng.ensure(ring ? 2 * N : N));
     HIP_TRY(ctx, ctx->wf_counts.ensure(16));
+    HIP_TRY(ctx, ctx->wf_overflow.ensure(N * (1 + (size_t)n_lights)));
 
     WaveBuffers B;
     memset(&B, 0, sizeof(B));
@@ -241,6 +243,7 @@ int render_wavefront(prt_ctx * ctx, const DevCamera & cam, const DevParams & P, 
     B.sq_d = f; f += N * n_lights;
     B.sq_c = f; f += N * n_lights;
     B.counts = ctx->wf_counts.p;
+    B.overflow = ctx->wf_overflow.p;
 
     // persistent grid: as many blocks as are resident
     int per_cu = 0;
@@ -256,6 +259,7 @@ int render_wavefront(prt_ctx * ctx, const DevCamera & cam, const DevParams & P, 
     if (const char * e = getenv("PRT_NODE_MIN")) node_min = std::max(0, std::min(64, atoi(e)));
     const unsigned int max_blocks = (unsigned int)per_cu * (unsigned int)ctx->cu_count;
     const int multi_light = ctx->scene.light_count > 1 ? 1 : 0;
+    const bool may_overflow = ctx->stack_bound > P.stack_lds_entries;
 
     const unsigned int gen_grid = (n_samples + 255) / 256;
     if (ring) hipLaunchKernelGGL(k_raygen<true>, dim3(gen_grid), dim3(256), 0, stream, cam, P, B);
@@ -286,6 +290,16 @@ int render_wavefront(prt_ctx * ctx, const DevCamera & cam, const DevParams & P, 
         HIP_TRY(ctx, hipGetLastError());
         HIP_TRY(ctx, hipEventRecord(ctx->ev[3], stream));
         n_launch++;
+        if (may_overflow) {
+            // only scenes whose worst-case stack bound exceeds the LDS column can overflow; the kernel reads the
+            // list length on the device and normally finds it zero
+            constexpr unsigned int OVF_BLOCKS = 64;
+            if (count_visits)
+                hipLaunchKernelGGL(k_trace_overflow<true>, dim3(OVF_BLOCKS), dim3(256), 0, stream, ctx->scene, P, B, cur, n_closest, multi_light, ctx->counters.p);
+            else
+                hipLaunchKernelGGL(k_trace_overflow<false>, dim3(OVF_BLOCKS), dim3(256), 0, stream, ctx->scene, P, B, cur, n_closest, multi_light, ctx->counters.p);
+            HIP_TRY(ctx, hipGetLastError());
+        }
         if (n_closest) {
             constexpr int SB = 1024;
             const unsigned int sgrid = (n_closest + SB - 1) / SB;
@@ -364,11 +378,13 @@ int render_pixels(prt_ctx * ctx, const prt_camera * cam_in, const prt_params * p
     HIP_TRY(ctx, ctx->counters.ensure(1));
     if (ring && (params->pipeline & PRT_PIPELINE_MASK) != PRT_PIPELINE_PERSISTENT) HIP_TRY(ctx, ctx->ring_ws.ensure(n_samples64 * 16));
 
-    // Traversal stack: LDS column of up to STACK_LDS_CAP entries per lane; the rest of the worst-case bound
-    // (3 pushes per 4-wide level + sentinel) is backed by a global spill column that real rays never reach.
+    // Traversal stack: LDS column of up to STACK_LDS_CAP entries per lane (occupancy); rays that would need more
+    // - 3 pushes per 4-wide level are possible, nothing real comes close - are re-traced on a full-height global
+    // column (dev_trace.h LdsStack / GlobalStack).
     constexpr int BLOCK = 256;
-    constexpr unsigned int STACK_LDS_CAP = 24;
-    const unsigned int stack_entries = std::min(ctx->stack_bound, STACK_LDS_CAP);
+    unsigned int stack_cap = 24;
+    if (const char * e = getenv("PRT_STACK_CAP")) stack_cap = (unsigned int)std::max(2, std::min(40, atoi(e)));   // test hook: force the fallback
+    const unsigned int stack_entries = std::min(ctx->stack_bound, stack_cap);
     const size_t lds = (size_t)stack_entries * BLOCK * sizeof(int);
     P.stack_lds_entries = stack_entries;
     P.stack_spill = nullptr;
@@ -379,10 +395,13 @@ int render_pixels(prt_ctx * ctx, const prt_camera * cam_in, const prt_params * p
     if (pipeline != PRT_PIPELINE_MEGAKERNEL && pipeline != PRT_PIPELINE_WAVEFRONT && pipeline != PRT_PIPELINE_PERSISTENT) { ctx->error = "prt_render: unknown pipeline"; return -1; }
 
     {
-        const unsigned int spill_entries = ctx->stack_bound > stack_entries ? ctx->stack_bound - stack_entries : 0;
+        const unsigned int spill_entries = ctx->stack_bound;        // the slow stack holds the whole bound
+        // one slow-stack column per lane that may need it: every sample lane (megakernel), every persistent lane
+        // (persistent), every ray of a round (wavefront: the overflow kernel indexes columns by list position)
         const size_t spill_lanes = pipeline == PRT_PIPELINE_MEGAKERNEL ? ((n_samples64 + BLOCK - 1) / BLOCK) * BLOCK
-                                                                        : (size_t)8 * (size_t)ctx->cu_count * BLOCK;
-        if (spill_entries) {
+                                 : pipeline == PRT_PIPELINE_PERSISTENT ? (size_t)8 * (size_t)ctx->cu_count * BLOCK
+                                                                       : (size_t)64 * BLOCK;     // k_trace_overflow's fixed grid
+        if (spill_entries > stack_entries) {
             if (spill_lanes >= (1ull << 32)) { ctx->error = "prt_render: too many lanes for the stack spill area"; return -1; }
             HIP_TRY(ctx, ctx->stack_spill.ensure((size_t)spill_entries * spill_lanes));
             P.stack_spill = ctx->stack_spill.p;
@@ -517,7 +536,7 @@ void prt_destroy(prt_ctx * ctx) {
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     ctx->nodes.release(); ctx->tris.release(); ctx->shade.release(); ctx->diffuse_dirs.release(); ctx->spec_dirs.release();
     ctx->tri_rank.release(); ctx->materials.release(); ctx->lights.release();
-    ctx->sample_rgb.release(); ctx->frame_out.release(); ctx->counters.release(); ctx->ring_ws.release(); ctx->pixel_list.release(); ctx->wf_f4.release(); ctx->wf_rng.release(); ctx->wf_counts.release(); ctx->stack_spill.release();
+    ctx->sample_rgb.release(); ctx->frame_out.release(); ctx->counters.release(); ctx->ring_ws.release(); ctx->pixel_list.release(); ctx->wf_f4.release(); ctx->wf_rng.release(); ctx->wf_counts.release(); ctx->wf_overflow.release(); ctx->stack_spill.release();
     for (int i = 0; i < 4; ++i) if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;

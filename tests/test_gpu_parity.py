@@ -105,3 +105,19 @@ def test_counting_variant_same_pixels(gpu_renderer_factory):
     b, cb = r.render(cam, p2, w, h)
     assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
     assert ca.ray_count == cb.ray_count and cb.node_visits > 0 and cb.tri_tests > 0 and ca.node_visits == 0
+
+
+@pytest.mark.parametrize("pipeline", sorted(PIPELINES))
+def test_stack_overflow_falls_back_to_the_slow_stack(gpu_renderer_factory, pipeline, monkeypatch):
+    """PRT_STACK_CAP=2 leaves room for the sentinel and one entry, so nearly every ray drops a push, is flagged
+    and re-traced on the global stack: results must not change."""
+    g = load_golden("terrain64_d3")
+    r = gpu_renderer_factory(str(g["scene"]), 0)
+    cam, p = camera_and_params(g, PIPELINES[pipeline])
+    w, h = int(g["width"]), int(g["height"])
+    ref, c_ref = r.render(cam, p, w, h)
+    monkeypatch.setenv("PRT_STACK_CAP", "2")
+    got, c_got = r.render(cam, p, w, h)
+    monkeypatch.delenv("PRT_STACK_CAP")
+    assert np.array_equal(ref.view(np.uint32), got.view(np.uint32))
+    assert c_ref.ray_count == c_got.ray_count == int(g["ray_count"])
