@@ -45,6 +45,7 @@ struct Builder {
     std::atomic<uint32_t> max_depth;
     std::atomic<int> threads_free;
     uint32_t leaf_max;
+    float trav_cost = 1.0f;     // SAH: cost of one traversal step relative to one triangle test
 
     uint32_t alloc() { return next_node.fetch_add(1); }
 
@@ -113,7 +114,7 @@ struct Builder {
 
         // leaf if allowed and cheaper than splitting (traversal step cost 1, triangle test cost 1)
         if (count <= leaf_max) {
-            float split_cost = (best_axis >= 0 && parent_area > 0.0f) ? 1.0f + best_cost / parent_area : FLT_MAX;
+            float split_cost = (best_axis >= 0 && parent_area > 0.0f) ? trav_cost + best_cost / parent_area : FLT_MAX;
             if ((float)count <= split_cost) { make_leaf(); return; }
         }
 
@@ -272,12 +273,13 @@ inline uint32_t float_bits(float f) {
 
 }  // namespace
 
-void build_bvh4q(const float * verts, uint32_t n_tris, uint32_t leaf_max, uint32_t threads, Bvh4Result * out) {
+void build_bvh4q(const float * verts, uint32_t n_tris, uint32_t leaf_max, uint32_t threads, Bvh4Result * out, float trav_cost) {
     *out = Bvh4Result();
     if (leaf_max < 1) leaf_max = 1;
     if (leaf_max > 4) leaf_max = 4;
     Builder b;
     b.leaf_max = leaf_max;
+    b.trav_cost = trav_cost;
     b.prims.resize(n_tris);
     Box scene;
     scene.reset();

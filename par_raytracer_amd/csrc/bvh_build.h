@@ -33,6 +33,6 @@ struct Bvh4Result {
     uint32_t stack_bound = 0;          // entries a traversal can ever hold: 3 per level + sentinel
     float scene_lo[3] = { 0, 0, 0 }, scene_hi[3] = { 0, 0, 0 };
 };
-void build_bvh4q(const float * verts, uint32_t n_tris, uint32_t leaf_max, uint32_t threads, Bvh4Result * out);
+void build_bvh4q(const float * verts, uint32_t n_tris, uint32_t leaf_max, uint32_t threads, Bvh4Result * out, float trav_cost = 1.0f);
 
 }  // namespace prt

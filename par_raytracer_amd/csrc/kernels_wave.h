@@ -47,7 +47,8 @@ struct WaveBuffers {
     float4 * sq_c;               //               (radiance if unoccluded .xyz, light distance^2)
     unsigned int * counts;       // [0] next closest count, [1] next shadow count, [2] trace fetch head, [3] overflowed rays
     unsigned int * overflow;     // ray indices whose traversal dropped a stack push (re-traced by k_trace_overflow)
-    unsigned int n_samples;
+    unsigned int n_samples;      // samples of THIS chain (all per-sample arrays are indexed 0 .. n_samples)
+    unsigned int sample_base;    // global id of its first sample (pixel / key derivation only)
 };
 
 PRT_D unsigned int lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
@@ -93,8 +94,9 @@ template <bool RING>
 __global__ __launch_bounds__(256) void k_raygen(DevCamera cam, DevParams P, WaveBuffers B) {
     const unsigned int sid = blockIdx.x * blockDim.x + threadIdx.x;
     if (sid >= B.n_samples) return;
-    const unsigned int pixel = pixel_of_local(P, sid / P.spp);
-    const unsigned int samp = sid % P.spp;
+    const unsigned int gsid = B.sample_base + sid;
+    const unsigned int pixel = pixel_of_local(P, gsid / P.spp);
+    const unsigned int samp = gsid % P.spp;
     SampleState S;
     Frame cur;
     u64 * ring = RING ? B.ring + sid : nullptr;

@@ -90,10 +90,19 @@ struct prt_ctx {
     DevBuf<unsigned long long> ring_ws;
     DevBuf<unsigned int> pixel_list;
     // wavefront pipeline workspace
-    DevBuf<float4> wf_f4;                 // one slab carved into the float4 arrays of WaveBuffers
-    DevBuf<ulonglong2> wf_rng;
-    DevBuf<unsigned int> wf_counts;
-    DevBuf<unsigned int> wf_overflow;
+    // one set per chain: the frame is split into two halves that run their rounds on two streams, so that one
+    // half's (latency-bound) k_shade overlaps the other half's (issue-bound) k_trace
+    struct ChainWs {
+        DevBuf<float4> f4;                // one slab carved into the float4 arrays of WaveBuffers
+        DevBuf<ulonglong2> rng;
+        DevBuf<unsigned int> counts;
+        DevBuf<unsigned int> overflow;
+        DevBuf<int> slow_stack;
+        hipStream_t stream = nullptr;
+        hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr, ev_done = nullptr, ev_first = nullptr;
+        unsigned int * host_counts = nullptr;   // pinned
+    } chain[2];
+    DevBuf<unsigned int> wf_counts;       // persistent pipeline's sample counter
     int cu_count = 0;
     unsigned int stack_bound = 0;
     DevBuf<int> stack_spill;
@@ -211,115 +220,220 @@ int launch_persistent(prt_ctx * ctx, bool count, size_t lds, const DevCamera & c
 }
 
 // The wavefront pipeline (kernels_wave.h): raygen, then rounds of {persistent trace, shade} until no ray is
-// left.  Queue sizes come back to the host once per round (8 bytes): they size the next launches, end the
-// loop and sum to ray_count (every queued ray is one TraceRay call, raytracer.cpp:161).
-int render_wavefront(prt_ctx * ctx, const DevCamera & cam, const DevParams & P, bool ring, bool count_visits,
-                     unsigned int n_samples, size_t lds, unsigned long long * ray_count, float * trace_ms, unsigned int * launches) {
-    hipStream_t stream = ctx->stream;
-    constexpr int BLOCK = 256;
+// left.  Queue sizes come back to the host once per round (8 bytes, pinned): they size the next launches, end
+// the loop and sum to ray_count (every queued ray is one TraceRay call, raytracer.cpp:161).
+//
+// Large frames are split into two CHAINS (sample halves) that run their rounds on two streams, the second chain
+// starting when the first has finished its first trace: from then on one chain's k_shade (latency / HBM bound)
+// tends to run beside the other chain's k_trace (vector-issue bound).  The persistent trace grid is capped so
+// that a shade workgroup still fits on every CU; k_shade uses 256-thread workgroups in this mode for the same
+// reason.  One host thread drives both chains, waiting on whichever round finishes next.
+struct Chain {
+    WaveBuffers B;
+    DevParams P;
+    prt_ctx::ChainWs * ws;
+    unsigned int n_closest = 0, n_shadow = 0, round = 0, launches = 0;
+    int cur = 0;
+    bool active = false;
+    unsigned long long rays = 0;
+    float trace_ms = 0.0f;
+};
+
+int chain_setup(prt_ctx * ctx, Chain & c, int index, const DevParams & P, bool ring, unsigned int base, unsigned int n_samples) {
+    prt_ctx::ChainWs & w = ctx->chain[index];
+    c.ws = &w;
+    c.P = P;
     const size_t N = n_samples;
     const unsigned int levels = std::max(1u, P.bounce_depth);
     const unsigned int fr4 = ring ? 5u : 4u;
     const unsigned int n_lights = std::max(1u, ctx->scene.light_count);
-    // float4 slab: accum(aliases sample_rgb) is separate; frames + 2x3 closest queues + hits + 3 shadow arrays
+    // float4 slab: frames + 2x3 closest queues + hits + 3 shadow arrays (accum aliases the shared sample_rgb)
     const size_t f4_total = (size_t)levels * fr4 * N + 6 * N + N + 3 * N * n_lights;
-    HIP_TRY(ctx, ctx->wf_f4.ensure(f4_total));
-    HIP_TRY(ctx, ctx->wf_rng.ensure(ring ? 2 * N : N));
-    HIP_TRY(ctx, ctx->wf_counts.ensure(16));
-    HIP_TRY(ctx, ctx->wf_overflow.ensure(N * (1 + (size_t)n_lights)));
-
-    WaveBuffers B;
+    HIP_TRY(ctx, w.f4.ensure(f4_total));
+    HIP_TRY(ctx, w.rng.ensure(ring ? 2 * N : N));
+    HIP_TRY(ctx, w.counts.ensure(16));
+    HIP_TRY(ctx, w.overflow.ensure(N * (1 + (size_t)n_lights)));
+    if (ctx->stack_bound > P.stack_lds_entries) {
+        HIP_TRY(ctx, w.slow_stack.ensure((size_t)ctx->stack_bound * 64 * 256));     // k_trace_overflow's fixed grid
+        c.P.stack_spill = w.slow_stack.p;
+        c.P.stack_spill_stride = 64 * 256;
+    }
+    WaveBuffers & B = c.B;
     memset(&B, 0, sizeof(B));
     B.n_samples = n_samples;
-    B.accum = ctx->sample_rgb.p;
-    B.rng = ctx->wf_rng.p;
-    B.rng_aux = ring ? ctx->wf_rng.p + N : nullptr;
-    B.ring = ring ? ctx->ring_ws.p : nullptr;
-    float4 * f = ctx->wf_f4.p;
+    B.sample_base = base;
+    B.accum = ctx->sample_rgb.p + base;
+    B.rng = w.rng.p;
+    B.rng_aux = ring ? w.rng.p + N : nullptr;
+    B.ring = ring ? ctx->ring_ws.p + (size_t)16 * base : nullptr;   // this chain's own [16][n_samples] block of the shared ring workspace
+    float4 * f = w.f4.p;
     B.frames = f; f += (size_t)levels * fr4 * N;
     for (int q = 0; q < 2; ++q) { B.rq_o[q] = f; f += N; B.rq_d[q] = f; f += N; B.rq_t[q] = f; f += N; }
     B.hits = f; f += N;
     B.sq_o = f; f += N * n_lights;
     B.sq_d = f; f += N * n_lights;
     B.sq_c = f; f += N * n_lights;
-    B.counts = ctx->wf_counts.p;
-    B.overflow = ctx->wf_overflow.p;
+    B.counts = w.counts.p;
+    B.overflow = w.overflow.p;
+    c.n_closest = n_samples;
+    c.n_shadow = 0;
+    c.active = n_samples > 0;
+    return 0;
+}
 
+struct WaveTuning {
+    int per_cu, keep_min, node_min, multi_light, shade_block;
+    bool may_overflow, ring, count_visits;
+    size_t lds;
+};
+
+// Enqueue one round of a chain: counters reset, trace, overflow re-trace, shade, counts -> pinned host memory.
+int chain_issue_round(prt_ctx * ctx, Chain & c, const WaveTuning & t) {
+    constexpr int BLOCK = 256;
+    hipStream_t stream = c.ws->stream;
+    const WaveBuffers & B = c.B;
+    c.rays += (unsigned long long)c.n_closest + c.n_shadow;
+    HIP_TRY(ctx, hipMemsetAsync(B.counts, 0, 16, stream));
+    const unsigned int total = c.n_closest + c.n_shadow;
+    const unsigned int max_blocks = (unsigned int)t.per_cu * (unsigned int)ctx->cu_count;
+    const unsigned int grid = std::max(1u, std::min(max_blocks, (total + BLOCK - 1) / BLOCK));
+    // rays reserved per head atomic: ~1/8 of a wave's fair share, whole waves, 64..512
+    unsigned int chunk = total / (grid * (BLOCK / 64) * 8u);
+    chunk = std::max(64u, std::min(512u, (chunk / 64u) * 64u));
+    HIP_TRY(ctx, hipEventRecord(c.ws->ev_t0, stream));
+    if (t.count_visits)
+        hipLaunchKernelGGL((k_trace<BLOCK, true>), dim3(grid), dim3(BLOCK), t.lds, stream, ctx->scene, c.P, B, c.cur, c.n_closest, c.n_shadow,
+                           t.keep_min, t.node_min, chunk, t.multi_light, ctx->counters.p);
+    else
+        hipLaunchKernelGGL((k_trace<BLOCK, false>), dim3(grid), dim3(BLOCK), t.lds, stream, ctx->scene, c.P, B, c.cur, c.n_closest, c.n_shadow,
+                           t.keep_min, t.node_min, chunk, t.multi_light, ctx->counters.p);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipEventRecord(c.ws->ev_t1, stream));
+    if (c.round == 0) HIP_TRY(ctx, hipEventRecord(c.ws->ev_first, stream));
+    c.launches++;
+    if (t.may_overflow) {
+        // only scenes whose worst-case stack bound exceeds the LDS column can overflow; the kernel reads the
+        // list length on the device and normally finds it zero
+        constexpr unsigned int OVF_BLOCKS = 64;
+        if (t.count_visits)
+            hipLaunchKernelGGL(k_trace_overflow<true>, dim3(OVF_BLOCKS), dim3(256), 0, stream, ctx->scene, c.P, B, c.cur, c.n_closest, t.multi_light, ctx->counters.p);
+        else
+            hipLaunchKernelGGL(k_trace_overflow<false>, dim3(OVF_BLOCKS), dim3(256), 0, stream, ctx->scene, c.P, B, c.cur, c.n_closest, t.multi_light, ctx->counters.p);
+        HIP_TRY(ctx, hipGetLastError());
+    }
+    if (c.n_closest) {
+        if (t.shade_block == 1024) {
+            const unsigned int sgrid = (c.n_closest + 1023) / 1024;
+            if (t.ring) hipLaunchKernelGGL((k_shade<true, 1024>), dim3(sgrid), dim3(1024), 0, stream, ctx->scene, c.P, B, c.cur, c.n_closest, ctx->counters.p);
+            else hipLaunchKernelGGL((k_shade<false, 1024>), dim3(sgrid), dim3(1024), 0, stream, ctx->scene, c.P, B, c.cur, c.n_closest, ctx->counters.p);
+        } else {
+            const unsigned int sgrid = (c.n_closest + 255) / 256;
+            if (t.ring) hipLaunchKernelGGL((k_shade<true, 256>), dim3(sgrid), dim3(256), 0, stream, ctx->scene, c.P, B, c.cur, c.n_closest, ctx->counters.p);
+            else hipLaunchKernelGGL((k_shade<false, 256>), dim3(sgrid), dim3(256), 0, stream, ctx->scene, c.P, B, c.cur, c.n_closest, ctx->counters.p);
+        }
+        HIP_TRY(ctx, hipGetLastError());
+    }
+    HIP_TRY(ctx, hipMemcpyAsync(c.ws->host_counts, B.counts, 8, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(ctx, hipEventRecord(c.ws->ev_done, stream));
+    return 0;
+}
+
+// Wait for the chain's round in flight; returns with its next queue sizes loaded.
+int chain_finish_round(prt_ctx * ctx, Chain & c) {
+    HIP_TRY(ctx, hipEventSynchronize(c.ws->ev_done));
+    float ms = 0.0f;
+    HIP_TRY(ctx, hipEventElapsedTime(&ms, c.ws->ev_t0, c.ws->ev_t1));
+    c.trace_ms += ms;
+    const unsigned int n_lights = std::max(1u, ctx->scene.light_count);
+    const unsigned int next_closest = c.n_closest ? c.ws->host_counts[0] : 0;
+    const unsigned int next_shadow = c.n_closest ? c.ws->host_counts[1] : 0;
+    if (next_closest > c.B.n_samples || next_shadow > c.B.n_samples * n_lights) { ctx->error = "prt_render: wavefront queue overflow"; return -6; }
+    c.n_closest = next_closest;
+    c.n_shadow = next_shadow;
+    c.cur ^= 1;
+    c.round++;
+    if (c.round > 100000) { ctx->error = "prt_render: wavefront loop did not terminate"; return -5; }
+    c.active = c.n_closest + c.n_shadow > 0;
+    return 0;
+}
+
+int render_wavefront(prt_ctx * ctx, const DevCamera & cam, const DevParams & P, bool ring, bool count_visits,
+                     unsigned int n_samples, size_t lds, unsigned long long * ray_count, float * trace_ms, unsigned int * launches) {
+    constexpr int BLOCK = 256;
+    WaveTuning t;
+    t.lds = lds;
+    t.ring = ring;
+    t.count_visits = count_visits;
     // persistent grid: as many blocks as are resident
     int per_cu = 0;
     hipError_t oe = count_visits ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace<BLOCK, true>, BLOCK, lds)
                                  : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace<BLOCK, false>, BLOCK, lds);
     if (oe != hipSuccess || per_cu < 1) per_cu = 2;
     per_cu = std::min(per_cu, 8);
-    int keep_min = 40;
+    t.keep_min = 40;
+    t.node_min = 32;
+    int n_chains = n_samples >= (1u << 23) ? 2 : 1;          // measured +2 % on 16.6 M samples; small frames: not worth the extra launches
+    int split_per_cu = 4;
     // tuning knobs for experiments (not part of the ABI)
-    if (const char * e = getenv("PRT_TRACE_BLOCKS_PER_CU")) per_cu = std::max(1, std::min(per_cu, atoi(e)));
-    if (const char * e = getenv("PRT_KEEP_MIN")) keep_min = std::max(1, std::min(64, atoi(e)));
-    int node_min = 32;
-    if (const char * e = getenv("PRT_NODE_MIN")) node_min = std::max(0, std::min(64, atoi(e)));
-    const unsigned int max_blocks = (unsigned int)per_cu * (unsigned int)ctx->cu_count;
-    const int multi_light = ctx->scene.light_count > 1 ? 1 : 0;
-    const bool may_overflow = ctx->stack_bound > P.stack_lds_entries;
+    if (const char * e = getenv("PRT_TRACE_BLOCKS_PER_CU")) { per_cu = std::max(1, std::min(per_cu, atoi(e))); split_per_cu = per_cu; }
+    if (const char * e = getenv("PRT_KEEP_MIN")) t.keep_min = std::max(1, std::min(64, atoi(e)));
+    if (const char * e = getenv("PRT_NODE_MIN")) t.node_min = std::max(0, std::min(64, atoi(e)));
+    if (const char * e = getenv("PRT_CHAINS")) n_chains = std::max(1, std::min(2, atoi(e)));
+    if (n_samples < 2) n_chains = 1;
+    t.per_cu = n_chains == 2 ? std::min(per_cu, split_per_cu) : per_cu;
+    t.shade_block = n_chains == 2 ? 256 : 1024;
+    if (const char * e = getenv("PRT_SHADE_BLOCK")) t.shade_block = atoi(e) == 256 ? 256 : 1024;
+    t.multi_light = ctx->scene.light_count > 1 ? 1 : 0;
+    t.may_overflow = ctx->stack_bound > P.stack_lds_entries;
 
-    const unsigned int gen_grid = (n_samples + 255) / 256;
-    if (ring) hipLaunchKernelGGL(k_raygen<true>, dim3(gen_grid), dim3(256), 0, stream, cam, P, B);
-    else hipLaunchKernelGGL(k_raygen<false>, dim3(gen_grid), dim3(256), 0, stream, cam, P, B);
-    HIP_TRY(ctx, hipGetLastError());
-
-    unsigned int n_closest = n_samples, n_shadow = 0;
-    unsigned long long rays = 0;
-    int cur = 0;
-    unsigned int n_launch = 0;
-    *trace_ms = 0.0f;
-    for (unsigned int round = 0; n_closest + n_shadow > 0; ++round) {
-        if (round > 100000) { ctx->error = "prt_render: wavefront loop did not terminate"; return -5; }
-        rays += (unsigned long long)n_closest + n_shadow;
-        HIP_TRY(ctx, hipMemsetAsync(B.counts, 0, 16, stream));
-        const unsigned int total = n_closest + n_shadow;
-        const unsigned int grid = std::max(1u, std::min(max_blocks, (total + BLOCK - 1) / BLOCK));
-        // rays reserved per head atomic: ~1/8 of a wave's fair share, whole waves, 64..512
-        unsigned int chunk = total / (grid * (BLOCK / 64) * 8u);
-        chunk = std::max(64u, std::min(512u, (chunk / 64u) * 64u));
-        HIP_TRY(ctx, hipEventRecord(ctx->ev[2], stream));
-        if (count_visits)
-            hipLaunchKernelGGL((k_trace<BLOCK, true>), dim3(grid), dim3(BLOCK), lds, stream, ctx->scene, P, B, cur, n_closest, n_shadow,
-                               keep_min, node_min, chunk, multi_light, ctx->counters.p);
-        else
-            hipLaunchKernelGGL((k_trace<BLOCK, false>), dim3(grid), dim3(BLOCK), lds, stream, ctx->scene, P, B, cur, n_closest, n_shadow,
-                               keep_min, node_min, chunk, multi_light, ctx->counters.p);
-        HIP_TRY(ctx, hipGetLastError());
-        HIP_TRY(ctx, hipEventRecord(ctx->ev[3], stream));
-        n_launch++;
-        if (may_overflow) {
-            // only scenes whose worst-case stack bound exceeds the LDS column can overflow; the kernel reads the
-            // list length on the device and normally finds it zero
-            constexpr unsigned int OVF_BLOCKS = 64;
-            if (count_visits)
-                hipLaunchKernelGGL(k_trace_overflow<true>, dim3(OVF_BLOCKS), dim3(256), 0, stream, ctx->scene, P, B, cur, n_closest, multi_light, ctx->counters.p);
-            else
-                hipLaunchKernelGGL(k_trace_overflow<false>, dim3(OVF_BLOCKS), dim3(256), 0, stream, ctx->scene, P, B, cur, n_closest, multi_light, ctx->counters.p);
-            HIP_TRY(ctx, hipGetLastError());
-        }
-        if (n_closest) {
-            constexpr int SB = 1024;
-            const unsigned int sgrid = (n_closest + SB - 1) / SB;
-            if (ring) hipLaunchKernelGGL((k_shade<true, SB>), dim3(sgrid), dim3(SB), 0, stream, ctx->scene, P, B, cur, n_closest, ctx->counters.p);
-            else hipLaunchKernelGGL((k_shade<false, SB>), dim3(sgrid), dim3(SB), 0, stream, ctx->scene, P, B, cur, n_closest, ctx->counters.p);
-            HIP_TRY(ctx, hipGetLastError());
-        }
-        unsigned int h[2] = { 0, 0 };
-        HIP_TRY(ctx, hipMemcpyAsync(h, B.counts, 8, hipMemcpyDeviceToHost, stream));
-        HIP_TRY(ctx, hipStreamSynchronize(stream));
-        float ms = 0.0f;
-        HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3]));
-        *trace_ms += ms;
-        n_closest = n_closest ? h[0] : 0;
-        n_shadow = h[1];
-        if (n_closest > n_samples || n_shadow > n_samples * n_lights) { ctx->error = "prt_render: wavefront queue overflow"; return -6; }
-        cur ^= 1;
+    Chain chain[2];
+    // split at a multiple of spp * 64 so both halves start on a pixel and a wave boundary
+    unsigned int n0 = n_samples;
+    if (n_chains == 2) {
+        const unsigned int unit = P.spp * 64u;
+        n0 = (unsigned int)(((unsigned long long)n_samples / 2 + unit - 1) / unit * unit);
+        if (n0 >= n_samples) { n0 = n_samples; n_chains = 1; t.per_cu = per_cu; }
     }
-    *ray_count = rays;
-    *launches = n_launch;
+    int rc = chain_setup(ctx, chain[0], 0, P, ring, 0, n0);
+    if (rc) return rc;
+    if (n_chains == 2 && (rc = chain_setup(ctx, chain[1], 1, P, ring, n0, n_samples - n0))) return rc;
+
+    for (int c = 0; c < n_chains; ++c) {
+        hipStream_t st = chain[c].ws->stream;
+        if (c == 1) {
+            // chain 1's stream: after everything already queued on the main stream (scene upload, memsets) ...
+            HIP_TRY(ctx, hipEventRecord(ctx->chain[1].ev_done, ctx->stream));
+            HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->chain[1].ev_done, 0));
+        }
+        const unsigned int gen_grid = (chain[c].B.n_samples + 255) / 256;
+        if (ring) hipLaunchKernelGGL(k_raygen<true>, dim3(gen_grid), dim3(256), 0, st, cam, chain[c].P, chain[c].B);
+        else hipLaunchKernelGGL(k_raygen<false>, dim3(gen_grid), dim3(256), 0, st, cam, chain[c].P, chain[c].B);
+        HIP_TRY(ctx, hipGetLastError());
+    }
+    // first rounds: chain 1 starts tracing when chain 0's first trace is done (antiphase from then on)
+    if ((rc = chain_issue_round(ctx, chain[0], t))) return rc;
+    if (n_chains == 2) {
+        HIP_TRY(ctx, hipStreamWaitEvent(chain[1].ws->stream, chain[0].ws->ev_first, 0));
+        if ((rc = chain_issue_round(ctx, chain[1], t))) return rc;
+    }
+    for (;;) {
+        bool any = false;
+        for (int c = 0; c < n_chains; ++c) {
+            if (!chain[c].active) continue;
+            any = true;
+            if ((rc = chain_finish_round(ctx, chain[c]))) return rc;
+            if (chain[c].active && (rc = chain_issue_round(ctx, chain[c], t))) return rc;
+        }
+        if (!any) break;
+    }
+    if (n_chains == 2) {
+        // the resolve runs on the main stream: it has to see chain 1's results
+        HIP_TRY(ctx, hipEventRecord(ctx->chain[1].ev_done, chain[1].ws->stream));
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->chain[1].ev_done, 0));
+    }
+    *ray_count = chain[0].rays + (n_chains == 2 ? chain[1].rays : 0);
+    *trace_ms = chain[0].trace_ms + (n_chains == 2 ? chain[1].trace_ms : 0.0f);
+    *launches = chain[0].launches + (n_chains == 2 ? chain[1].launches : 0);
     return 0;
 }
 
@@ -400,8 +514,8 @@ int render_pixels(prt_ctx * ctx, const prt_camera * cam_in, const prt_params * p
         // (persistent), every ray of a round (wavefront: the overflow kernel indexes columns by list position)
         const size_t spill_lanes = pipeline == PRT_PIPELINE_MEGAKERNEL ? ((n_samples64 + BLOCK - 1) / BLOCK) * BLOCK
                                  : pipeline == PRT_PIPELINE_PERSISTENT ? (size_t)8 * (size_t)ctx->cu_count * BLOCK
-                                                                       : (size_t)64 * BLOCK;     // k_trace_overflow's fixed grid
-        if (spill_entries > stack_entries) {
+                                                                       : 0;                      // wavefront: per chain, see chain_setup
+        if (spill_entries > stack_entries && spill_lanes) {
             if (spill_lanes >= (1ull << 32)) { ctx->error = "prt_render: too many lanes for the stack spill area"; return -1; }
             HIP_TRY(ctx, ctx->stack_spill.ensure((size_t)spill_entries * spill_lanes));
             P.stack_spill = ctx->stack_spill.p;
@@ -522,6 +636,16 @@ prt_ctx * prt_create(int device_id) {
     memset(&ctx->info, 0, sizeof(ctx->info));
     e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
     for (int i = 0; i < 4 && e == hipSuccess; ++i) e = hipEventCreate(&ctx->ev[i]);
+    ctx->chain[0].stream = ctx->stream;
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->chain[1].stream, hipStreamNonBlocking);
+    for (int c = 0; c < 2 && e == hipSuccess; ++c) {
+        prt_ctx::ChainWs & w = ctx->chain[c];
+        e = hipEventCreate(&w.ev_t0);
+        if (e == hipSuccess) e = hipEventCreate(&w.ev_t1);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&w.ev_done, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&w.ev_first, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipHostMalloc((void **)&w.host_counts, 64, hipHostMallocDefault);
+    }
     if (e != hipSuccess) {
         g_create_error = std::string("prt_create: stream/event creation: ") + hipGetErrorString(e);
         delete ctx;
@@ -536,7 +660,17 @@ void prt_destroy(prt_ctx * ctx) {
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     ctx->nodes.release(); ctx->tris.release(); ctx->shade.release(); ctx->diffuse_dirs.release(); ctx->spec_dirs.release();
     ctx->tri_rank.release(); ctx->materials.release(); ctx->lights.release();
-    ctx->sample_rgb.release(); ctx->frame_out.release(); ctx->counters.release(); ctx->ring_ws.release(); ctx->pixel_list.release(); ctx->wf_f4.release(); ctx->wf_rng.release(); ctx->wf_counts.release(); ctx->wf_overflow.release(); ctx->stack_spill.release();
+    ctx->sample_rgb.release(); ctx->frame_out.release(); ctx->counters.release(); ctx->ring_ws.release(); ctx->pixel_list.release(); ctx->wf_counts.release(); ctx->stack_spill.release();
+    for (int c = 0; c < 2; ++c) {
+        prt_ctx::ChainWs & w = ctx->chain[c];
+        w.f4.release(); w.rng.release(); w.counts.release(); w.overflow.release(); w.slow_stack.release();
+        if (w.ev_t0) (void)hipEventDestroy(w.ev_t0);
+        if (w.ev_t1) (void)hipEventDestroy(w.ev_t1);
+        if (w.ev_done) (void)hipEventDestroy(w.ev_done);
+        if (w.ev_first) (void)hipEventDestroy(w.ev_first);
+        if (w.host_counts) (void)hipHostFree(w.host_counts);
+        if (c == 1 && w.stream) (void)hipStreamDestroy(w.stream);
+    }
     for (int i = 0; i < 4; ++i) if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -590,7 +724,11 @@ int prt_upload_scene(prt_ctx * ctx, const prt_scene_desc * s) {
         if (!(fabsf(verts[i]) < 1e18f)) { ctx->error = "prt_upload_scene: vertex coordinate is not finite or exceeds 1e18"; return -1; }
     Bvh4Result bvh;
     unsigned int hw = std::max(1u, std::thread::hardware_concurrency());
-    build_bvh4q(verts.data(), n_tris, BVH_LEAF_MAX, std::min(hw, 16u), &bvh);
+    unsigned int leaf_max = BVH_LEAF_MAX;
+    if (const char * e = getenv("PRT_LEAF_MAX")) leaf_max = (unsigned int)std::max(1, std::min(4, atoi(e)));   // experiment knob
+    float trav_cost = 1.0f;
+    if (const char * e = getenv("PRT_SAH_TRAV_COST")) trav_cost = (float)atof(e);                             // experiment knob
+    build_bvh4q(verts.data(), n_tris, leaf_max, std::min(hw, 16u), &bvh, trav_cost);
     double build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
 
     // ---- reference visit rank: leaves of the sphere tree in the order TraceRay pops them (c1 first)
