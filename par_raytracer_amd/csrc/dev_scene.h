@@ -18,8 +18,8 @@
 //                (a.xyz, ab.x) (ab.yz, ac.xy) (ac.z, n.xyz)   with ab = b-a, ac = c-a, n = Cross(ab, ac)
 //              computed on the host with the reference's float expressions (raytracer.cpp:85-91), so the
 //              device test consumes the same bits the CPU test would compute per call
-//   shade      64 B per triangle = 4 x float4, same order: the three vertex normals, the three texcoords
-//              and the material index - fetched once per shaded hit, not per test
+//   shade      64 B per triangle = 4 x float4, same order: the three vertex normals, the geometric normal
+//              n (again) and the material index - ONE gather per shaded hit, not per test
 //   tri_rank   u32 per triangle: position in the reference's own visit order (sphere tree DFS with c1
 //              first, then ascending index inside a group; raytracer.cpp:136, 208-209).  Only read when
 //              two hits have bit-equal t, to keep the reference's "first hit wins" (strict <, :149, :220)
@@ -62,6 +62,7 @@ struct DevScene {
     const float4 * diffuse_dirs;
     const float4 * spec_dirs;
     unsigned int light_count;
+    unsigned int material_count;
     unsigned int spec_samples;
     unsigned int tri_count;
     unsigned int node_count;

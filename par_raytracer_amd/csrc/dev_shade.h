@@ -130,10 +130,9 @@ PRT_D bool sample_advance(const DevScene & sc, const DevParams & P, SampleState 
             shaded_hits++;
             const f3 ob = cur.ray_o + cur.ray_d * P.ray_bias;                       // raytracer.cpp:163
             const f3 pos = ob + cur.ray_d * hit.t;                                  // raytracer.cpp:121
-            const float4 r2 = sc.tris[3 * (size_t)hit.tri + 2];
-            const f3 gn = normalize3(mk3(r2.y, r2.z, r2.w));                        // raytracer.cpp:122
             const float4 * sp = sc.shade + 4 * (size_t)hit.tri;
             const float4 s0 = sp[0], s1 = sp[1], s2 = sp[2], s3 = sp[3];
+            const f3 gn = normalize3(mk3(s2.y, s2.z, s2.w));                        // raytracer.cpp:122 (n = Cross(ab, ac))
             const int m = as_i(s3.w);
             const DevMaterial mat = sc.materials[m];
             cur.hit_pos = pos;

@@ -341,6 +341,26 @@ template <bool RING, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, DevParams P, WaveBuffers B, int cur, unsigned int n_closest,
                                                  DevCounters * ctr) {
     __shared__ unsigned int s_cnt[BLOCK / 64 + 1];
+    // Small read-only tables staged in LDS once per workgroup: every dependent global load removed from the
+    // per-hit chain (triangle -> material -> light -> direction table) is a memory round trip less per wave.
+    constexpr int LDS_MATS = 32, LDS_LIGHTS = 4;
+    __shared__ float4 s_diffuse[1024];                         // 16 KB: the Hammersley cosine-lobe directions
+    __shared__ DevMaterial s_mats[LDS_MATS];                    // 2 KB
+    __shared__ DevLight s_lights[LDS_LIGHTS];
+    const bool lds_mats = sc.material_count <= (unsigned int)LDS_MATS;
+    const bool lds_lights = sc.light_count <= (unsigned int)LDS_LIGHTS;
+    for (unsigned int k = threadIdx.x; k < 1024u; k += BLOCK) s_diffuse[k] = sc.diffuse_dirs[k];
+    if (lds_mats) {
+        const float4 * src = reinterpret_cast<const float4 *>(sc.materials);
+        float4 * dst = reinterpret_cast<float4 *>(s_mats);
+        for (unsigned int k = threadIdx.x; k < sc.material_count * 4u; k += BLOCK) dst[k] = src[k];
+    }
+    if (lds_lights) {
+        const float4 * src = reinterpret_cast<const float4 *>(sc.lights);
+        float4 * dst = reinterpret_cast<float4 *>(s_lights);
+        for (unsigned int k = threadIdx.x; k < sc.light_count * 3u; k += BLOCK) dst[k] = src[k];
+    }
+    __syncthreads();
     const unsigned int i = blockIdx.x * BLOCK + threadIdx.x;
     const bool live = i < n_closest;
     const int depth = (int)P.bounce_depth;
@@ -385,7 +405,7 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, DevParams P, WaveB
     bool want_shadow = false;
     bool f_held = false;
     f3 T_own = T;
-    DevMaterial mat = sc.materials[0];
+    DevMaterial mat = lds_mats ? s_mats[0] : sc.materials[0];
     if (live) {
         if (hit.tri < 0) {                                                         // raytracer.cpp:573-575
             add = add + T * P.background;
@@ -394,12 +414,11 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, DevParams P, WaveB
             shaded = 1;
             const f3 ob = ray_o + ray_d * P.ray_bias;                               // raytracer.cpp:163
             const f3 pos = ob + ray_d * hit.t;                                      // raytracer.cpp:121
-            const float4 r2 = sc.tris[3 * (size_t)hit.tri + 2];
-            const f3 gn = normalize3(mk3(r2.y, r2.z, r2.w));                        // raytracer.cpp:122
             const float4 * sp = sc.shade + 4 * (size_t)hit.tri;
             const float4 s0 = sp[0], s1 = sp[1], s2 = sp[2], s3 = sp[3];
+            const f3 gn = normalize3(mk3(s2.y, s2.z, s2.w));                        // raytracer.cpp:122 (n = Cross(ab, ac))
             const int m = as_i(s3.w);
-            mat = sc.materials[m];
+            mat = lds_mats ? s_mats[m] : sc.materials[m];
             const float alpha = mat.alpha;
             if (mat.alpha <= 1.0f && alpha <= 0.05f) {                              // raytracer.cpp:443-453
                 next_o = pos + ray_d * P.ray_bias * 2.0f;
@@ -441,7 +460,7 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, DevParams P, WaveB
         float dist_sq = -1.0f;
         int kind = WF_KIND_SHADOW_ANY;
         if (want_shadow) {
-            const DevLight L = sc.lights[li];
+            const DevLight L = lds_lights ? s_lights[li] : sc.lights[li];
             f3 light_color = mk3(L.color[0], L.color[1], L.color[2]);
             f3 light_vector;
             if (L.type == 0) {
@@ -475,7 +494,7 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, DevParams P, WaveB
     while (mode != M_DONE) {
         if (mode == M_NEXT_CHILD) {                       // frame f at `level` spawns its next child, if any
             const int iters = depth - level;
-            const DevMaterial fm = sc.materials[f.mat];
+            const DevMaterial fm = lds_mats ? s_mats[f.mat] : sc.materials[f.mat];
             const f3 own = f.alpha < 1.0f ? f.T_in * f.alpha : f.T_in;
             // which child comes next (cheap), then ONE copy of the expensive direction code for both lobes
             int kind = -1;                                                          // 0 diffuse, 1 specular, 2 alpha continuation
@@ -500,7 +519,7 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, DevParams P, WaveB
                 float4 ts;
                 if (kind == 0) {
                     const unsigned int series_i = (unsigned int)(rng_next<RING>(rng, ring, ring_stride) % 1024ull);
-                    ts = sc.diffuse_dirs[series_i];
+                    ts = s_diffuse[series_i];
                 } else {
                     ts = sc.spec_dirs[(size_t)f.mat * sc.spec_samples + (unsigned int)f.idx];
                 }
