@@ -43,8 +43,10 @@ struct WaveBuffers {
     float4 * rq_t[2];            //                                      (throughput.xyz, -)
     float4 * hits;               // [N] (t, v, w, tri) by queue position
     float4 * sq_o;               // shadow queue: (o.xyz, sample)
-    float4 * sq_d;               //               (d.xyz, kind)
-    float4 * sq_c;               //               (radiance if unoccluded .xyz, light distance^2)
+    float4 * sq_c;               //               (radiance if unoccluded .xyz, w): w >= 0: point light, w = distance^2 to
+                                 //               it (raytracer.cpp:393-396); w < 0: directional light number -w - 1, whose
+                                 //               direction comes from the light table - no per-ray copy of a constant
+    float4 * sq_d;               //               (d.xyz, -)   written and read for point lights only
     unsigned int * counts;       // [0] next closest count, [1] next shadow count, [2] trace fetch head, [3] overflowed rays
     unsigned int * overflow;     // ray indices whose traversal dropped a stack push (re-traced by k_trace_overflow)
     unsigned int n_samples;      // samples of THIS chain (all per-sample arrays are indexed 0 .. n_samples)
@@ -168,15 +170,21 @@ __global__ __launch_bounds__(BLOCK) void k_trace(DevScene sc, DevParams P, WaveB
                     } else {
                         const unsigned int j = idx - n_closest;
                         ro = B.sq_o[j];
-                        rd = B.sq_d[j];
                         payload = B.sq_c[j];
-                        kind = as_i(rd.w);
+                        if (payload.w < 0.0f) {          // directional light: the direction is a per-light constant
+                            const DevLight & L = sc.lights[(unsigned int)(-payload.w) - 1u];
+                            const f3 lv = mk3(L.facing[0], L.facing[1], L.facing[2]) * -1.0f;   // raytracer.cpp:240
+                            rd = make_float4(lv.x, lv.y, lv.z, 0.0f);
+                            kind = WF_KIND_SHADOW_ANY;
+                        } else {
+                            rd = B.sq_d[j];
+                            kind = WF_KIND_SHADOW_DIST;
+                        }
                     }
                     sample = as_i(ro.w);
                     const f3 d = mk3(rd.x, rd.y, rd.z);
                     const f3 ob = mk3(ro.x, ro.y, ro.z) + d * P.ray_bias;          // raytracer.cpp:163
                     trav_init(r, ob, d, kind == WF_KIND_SHADOW_ANY ? TRACE_ANY : TRACE_CLOSEST, P.box_pad, stack);
-                    payload.w = kind == WF_KIND_CLOSEST ? 0.0f : (kind == WF_KIND_SHADOW_ANY ? -1.0f : payload.w);
                     ray = (int)idx;
                 }
                 chunk_next += take;
@@ -264,9 +272,16 @@ __global__ __launch_bounds__(256) void k_trace_overflow(DevScene sc, DevParams P
         } else {
             const unsigned int j = idx - n_closest;
             ro = B.sq_o[j];
-            rd = B.sq_d[j];
             payload = B.sq_c[j];
-            kind = as_i(rd.w);
+            if (payload.w < 0.0f) {
+                const DevLight & L = sc.lights[(unsigned int)(-payload.w) - 1u];
+                const f3 lv = mk3(L.facing[0], L.facing[1], L.facing[2]) * -1.0f;
+                rd = make_float4(lv.x, lv.y, lv.z, 0.0f);
+                kind = WF_KIND_SHADOW_ANY;
+            } else {
+                rd = B.sq_d[j];
+                kind = WF_KIND_SHADOW_DIST;
+            }
         }
         const int sample = as_i(ro.w);
         const f3 d = mk3(rd.x, rd.y, rd.z);
@@ -485,8 +500,12 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, DevParams P, WaveB
         const unsigned int slot = block_append<BLOCK / 64>(B.counts + 1, want_shadow, s_cnt);
         if (want_shadow) {
             B.sq_o[slot] = make_float4(so.x, so.y, so.z, as_f((int)s));
-            B.sq_d[slot] = make_float4(sd.x, sd.y, sd.z, as_f(kind));
-            B.sq_c[slot] = make_float4(contrib.x, contrib.y, contrib.z, dist_sq);
+            if (kind == WF_KIND_SHADOW_DIST) {
+                B.sq_d[slot] = make_float4(sd.x, sd.y, sd.z, 0.0f);
+                B.sq_c[slot] = make_float4(contrib.x, contrib.y, contrib.z, dist_sq);
+            } else {
+                B.sq_c[slot] = make_float4(contrib.x, contrib.y, contrib.z, -(float)(li + 1u));   // directional light li
+            }
         }
     }
 
@@ -530,6 +549,11 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, DevParams P, WaveB
                 next_T = own * (lobe * cw);
                 next_o = f.hit_p;
                 f.idx++;
+                // look ahead: if this was the frame's last child, retire the frame now so it is neither parked
+                // (64 B written, 64 B read back later) nor revisited
+                const bool more_refl = kind == 0 && (unsigned int)f.idx < P.reflection_samples;
+                const bool more_spec = kind == 0 ? P.spec_samples > 0u : (unsigned int)f.idx < P.spec_samples;
+                if (!more_refl && !more_spec && !(f.alpha < 1.0f)) f.stage = WF_STAGE_DONE;
             }
             if (!spawned) { f_held = false; mode = M_RETURN_UP; continue; }
             f_held = true;                                // f (at `level`) stays in registers until the child's fate is known
