@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256) void k_raygen(DevCamera cam, DevParams P, Wave
 // ---------------------------------------------------------------------------------------------------------
 // Persistent traversal.  grid = resident blocks; dynamic LDS = stack_entries * BLOCK * 4.
 template <int BLOCK, bool COUNT>
-__global__ __launch_bounds__(BLOCK) void k_trace(DevScene sc, DevParams P, WaveBuffers B, int cur, unsigned int n_closest,
+__global__ __launch_bounds__(BLOCK, 6) void k_trace(DevScene sc, DevParams P, WaveBuffers B, int cur, unsigned int n_closest,
                                                   unsigned int n_shadow, int keep_min, int node_min, unsigned int chunk, int multi_light,
                                                   DevCounters * ctr) {
     extern __shared__ int s_stack[];
