@@ -6,8 +6,10 @@ frame = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 f = glob.glob(d + "/*/*_kernel_trace.csv")[0]
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-idx = [i for i, r in enumerate(rows) if "k_raygen" in r["Kernel_Name"] or "k_render_mega" in r["Kernel_Name"]]
-a = idx[frame]; b = idx[frame + 1] if frame + 1 < len(idx) else len(rows)
+# a frame ends with its k_resolve; it starts right after the previous one
+ends = [i for i, r in enumerate(rows) if "k_resolve" in r["Kernel_Name"]]
+a = ends[frame - 1] + 1 if frame > 0 else 0
+b = ends[frame] + 1
 t0 = int(rows[a]["Start_Timestamp"])
 tot = {}
 for r in rows[a:b]:
