@@ -69,6 +69,9 @@ def main():
     ap.add_argument("--pipeline", type=int, default=0)
     ap.add_argument("--cpu-lattice", type=int, default=0, help="lattice stride of the CPU baseline (0 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="collective backend; gloo (host-staged) only exists to rehearse the N > 1 path on a 1-GPU box")
+    ap.add_argument("--share-device", action="store_true", help="rehearsal: every rank uses GPU 0")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -87,11 +90,17 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    if args.share_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)          # RCCL over xGMI
+        else:
+            dist.init_process_group("gloo")
+    cdev = dev if args.backend == "nccl" else torch.device("cpu")   # where collective payloads live
 
     scene_name, width, height, spp, depth, descr = WORKLOADS[args.workload]
 
@@ -139,9 +148,16 @@ def main():
             c = r.render_device(cam, params, width, height, 0, width * height, shard.data_ptr(), want_counters)
         else:
             c = r.render_shard_device(cam, params, width, height, SHARD_BLOCK_ROWS, rank, world, shard.data_ptr(), want_counters)
-            dist.gather(shard, gather_list, dst=0)                  # RCCL over xGMI: 7 shards -> GPU 0
-            if rank == 0:
-                frame = sharding.assemble(torch.cat(gather_list, dim=0), row_index, height)
+            if args.backend == "nccl":
+                dist.gather(shard, gather_list, dst=0)              # RCCL over xGMI: 7 shards -> GPU 0
+                if rank == 0:
+                    frame = sharding.assemble(torch.cat(gather_list, dim=0), row_index, height)
+            else:
+                host = shard.cpu()
+                gl = [torch.empty_like(host) for _ in range(world)] if rank == 0 else None
+                dist.gather(host, gl, dst=0)
+                if rank == 0:
+                    frame = sharding.assemble(torch.cat(gl, dim=0).to(dev), row_index, height)
         return c
 
     def sync_all():
@@ -165,7 +181,7 @@ def main():
     sync_all()
     elapsed = time.perf_counter() - t_start
 
-    t = torch.tensor([elapsed, float(rays_local)], dtype=torch.float64, device=dev)
+    t = torch.tensor([elapsed, float(rays_local)], dtype=torch.float64, device=cdev)
     if world > 1:
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -236,6 +252,16 @@ def main():
                   "ray_count_gpu": int(gctr.ray_count), "ray_count_cpu": int(octr.ray_count),
                   "ray_count_equal": bool(gctr.ray_count == octr.ray_count)}
 
+    multi_check = None
+    if world > 1 and rank == 0 and frame is not None:
+        # the assembled multi-GPU frame must be bit-identical to what one GPU computes for the same pixels
+        lat = 16
+        one, _ = r.render_lattice(cam, params, width, height, lat)
+        got = frame[::lat, ::lat].cpu().numpy()
+        multi_check = {"pixels": int(one.shape[0] * one.shape[1]),
+                       "bit_identical_to_single_gpu": bool(np.array_equal(one.view(np.uint32), got.view(np.uint32))),
+                       "max_abs_diff": float(np.abs(one - got).max())}
+
     if rank == 0:
         out = {
             "metric": "Mrays/s at 1920x1080x8spp, 1M-tri OBJ" if args.workload == "C4" else "Mrays/s (%s)" % args.workload,
@@ -245,10 +271,10 @@ def main():
             "config": {"workload": descr, "seed": SEED, "triangles": int(info.triangle_count), "width": width, "height": height,
                        "spp": spp, "bounce_depth": depth, "rays_per_frame": int(rays_total / args.steps),
                        "parallelism": "pixel rows sharded in %d-row blocks over %d GPU(s)%s" % (
-                           SHARD_BLOCK_ROWS, world, ", RCCL gather to rank 0" if world > 1 else ""),
+                           SHARD_BLOCK_ROWS, world, (", RCCL gather to rank 0" if args.backend == "nccl" else ", gloo gather (rehearsal)") if world > 1 else ""),
                        "pipeline": "megakernel" if mega else "wavefront"},
             "render_ms_device": round(float(np.mean(render_ms)), 4),
-            "roofline": roofline, "cpu_baseline": cpu_baseline, "parity": parity,
+            "roofline": roofline, "cpu_baseline": cpu_baseline, "parity": parity, "multi_gpu_check": multi_check,
         }
         print(json.dumps(out), flush=True)
     r.close()
