@@ -65,6 +65,8 @@ struct DevBuf {
 
 }  // namespace
 
+enum { PRT_MAX_CHAINS = 8 };
+
 struct prt_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -101,7 +103,7 @@ struct prt_ctx {
         hipStream_t stream = nullptr;
         hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr, ev_done = nullptr, ev_first = nullptr;
         unsigned int * host_counts = nullptr;   // pinned
-    } chain[2];
+    } chain[PRT_MAX_CHAINS];
     DevBuf<unsigned int> wf_counts;       // persistent pipeline's sample counter
     int cu_count = 0;
     unsigned int stack_bound = 0;
@@ -283,6 +285,7 @@ int chain_setup(prt_ctx * ctx, Chain & c, int index, const DevParams & P, bool r
 
 struct WaveTuning {
     int per_cu, keep_min, node_min, multi_light, shade_block;
+    unsigned int chunk_min;
     bool may_overflow, ring, count_visits;
     size_t lds;
 };
@@ -299,7 +302,7 @@ int chain_issue_round(prt_ctx * ctx, Chain & c, const WaveTuning & t) {
     const unsigned int grid = std::max(1u, std::min(max_blocks, (total + BLOCK - 1) / BLOCK));
     // rays reserved per head atomic: ~1/8 of a wave's fair share, whole waves, 64..512
     unsigned int chunk = total / (grid * (BLOCK / 64) * 8u);
-    chunk = std::max(64u, std::min(512u, (chunk / 64u) * 64u));
+    chunk = std::max(t.chunk_min, std::min(512u, (chunk / 64u) * 64u));
     HIP_TRY(ctx, hipEventRecord(c.ws->ev_t0, stream));
     if (t.count_visits)
         hipLaunchKernelGGL((k_trace<BLOCK, true>), dim3(grid), dim3(BLOCK), t.lds, stream, ctx->scene, c.P, B, c.cur, c.n_closest, c.n_shadow,
@@ -372,49 +375,55 @@ int render_wavefront(prt_ctx * ctx, const DevCamera & cam, const DevParams & P, 
     per_cu = std::min(per_cu, 8);
     t.keep_min = 40;
     t.node_min = 32;
+    t.chunk_min = 128;
+    if (const char * e = getenv("PRT_CHUNK_MIN")) t.chunk_min = (unsigned int)std::max(64, std::min(512, atoi(e)));
     int n_chains = n_samples >= (1u << 23) ? 2 : 1;          // measured +2 % on 16.6 M samples; small frames: not worth the extra launches
     int split_per_cu = 4;
     // tuning knobs for experiments (not part of the ABI)
     if (const char * e = getenv("PRT_TRACE_BLOCKS_PER_CU")) { per_cu = std::max(1, std::min(per_cu, atoi(e))); split_per_cu = per_cu; }
     if (const char * e = getenv("PRT_KEEP_MIN")) t.keep_min = std::max(1, std::min(64, atoi(e)));
     if (const char * e = getenv("PRT_NODE_MIN")) t.node_min = std::max(0, std::min(64, atoi(e)));
-    if (const char * e = getenv("PRT_CHAINS")) n_chains = std::max(1, std::min(2, atoi(e)));
-    if (n_samples < 2) n_chains = 1;
-    t.per_cu = n_chains == 2 ? std::min(per_cu, split_per_cu) : per_cu;
-    t.shade_block = n_chains == 2 ? 256 : 1024;
+    if (const char * e = getenv("PRT_CHAINS")) n_chains = std::max(1, std::min((int)PRT_MAX_CHAINS, atoi(e)));
+    // chains start on a pixel and a wave boundary
+    const unsigned int unit = P.spp * 64u;
+    while (n_chains > 1 && (unsigned long long)unit * n_chains > n_samples) n_chains--;
+    t.per_cu = n_chains >= 2 ? std::min(per_cu, split_per_cu) : per_cu;
+    t.shade_block = n_chains >= 2 ? 256 : 1024;
     if (const char * e = getenv("PRT_SHADE_BLOCK")) t.shade_block = atoi(e) == 256 ? 256 : 1024;
     t.multi_light = ctx->scene.light_count > 1 ? 1 : 0;
     t.may_overflow = ctx->stack_bound > P.stack_lds_entries;
 
-    Chain chain[2];
-    // split at a multiple of spp * 64 so both halves start on a pixel and a wave boundary
-    unsigned int n0 = n_samples;
-    if (n_chains == 2) {
-        const unsigned int unit = P.spp * 64u;
-        n0 = (unsigned int)(((unsigned long long)n_samples / 2 + unit - 1) / unit * unit);
-        if (n0 >= n_samples) { n0 = n_samples; n_chains = 1; t.per_cu = per_cu; }
+    Chain chain[PRT_MAX_CHAINS];
+    int rc = 0;
+    {
+        unsigned int base = 0;
+        const unsigned int per = (unsigned int)((((unsigned long long)n_samples + n_chains - 1) / n_chains + unit - 1) / unit * unit);
+        for (int c = 0; c < n_chains; ++c) {
+            const unsigned int n = c + 1 == n_chains ? n_samples - base : std::min(per, n_samples - base);
+            if ((rc = chain_setup(ctx, chain[c], c, P, ring, base, n))) return rc;
+            base += n;
+        }
     }
-    int rc = chain_setup(ctx, chain[0], 0, P, ring, 0, n0);
-    if (rc) return rc;
-    if (n_chains == 2 && (rc = chain_setup(ctx, chain[1], 1, P, ring, n0, n_samples - n0))) return rc;
 
     for (int c = 0; c < n_chains; ++c) {
         hipStream_t st = chain[c].ws->stream;
-        if (c == 1) {
-            // chain 1's stream: after everything already queued on the main stream (scene upload, memsets) ...
-            HIP_TRY(ctx, hipEventRecord(ctx->chain[1].ev_done, ctx->stream));
-            HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->chain[1].ev_done, 0));
+        if (c >= 1) {
+            // the extra streams start after everything already queued on the main stream (scene upload, memsets)
+            HIP_TRY(ctx, hipEventRecord(ctx->chain[c].ev_done, ctx->stream));
+            HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->chain[c].ev_done, 0));
         }
         const unsigned int gen_grid = (chain[c].B.n_samples + 255) / 256;
-        if (ring) hipLaunchKernelGGL(k_raygen<true>, dim3(gen_grid), dim3(256), 0, st, cam, chain[c].P, chain[c].B);
-        else hipLaunchKernelGGL(k_raygen<false>, dim3(gen_grid), dim3(256), 0, st, cam, chain[c].P, chain[c].B);
-        HIP_TRY(ctx, hipGetLastError());
+        if (gen_grid) {
+            if (ring) hipLaunchKernelGGL(k_raygen<true>, dim3(gen_grid), dim3(256), 0, st, cam, chain[c].P, chain[c].B);
+            else hipLaunchKernelGGL(k_raygen<false>, dim3(gen_grid), dim3(256), 0, st, cam, chain[c].P, chain[c].B);
+            HIP_TRY(ctx, hipGetLastError());
+        }
     }
-    // first rounds: chain 1 starts tracing when chain 0's first trace is done (antiphase from then on)
-    if ((rc = chain_issue_round(ctx, chain[0], t))) return rc;
-    if (n_chains == 2) {
-        HIP_TRY(ctx, hipStreamWaitEvent(chain[1].ws->stream, chain[0].ws->ev_first, 0));
-        if ((rc = chain_issue_round(ctx, chain[1], t))) return rc;
+    // first rounds: chain c starts tracing when chain c-1's first trace is done (staggered phases from then on)
+    for (int c = 0; c < n_chains; ++c) {
+        if (!chain[c].active) continue;
+        if (c >= 1 && chain[c - 1].launches) HIP_TRY(ctx, hipStreamWaitEvent(chain[c].ws->stream, chain[c - 1].ws->ev_first, 0));
+        if ((rc = chain_issue_round(ctx, chain[c], t))) return rc;
     }
     for (;;) {
         bool any = false;
@@ -426,14 +435,15 @@ int render_wavefront(prt_ctx * ctx, const DevCamera & cam, const DevParams & P, 
         }
         if (!any) break;
     }
-    if (n_chains == 2) {
-        // the resolve runs on the main stream: it has to see chain 1's results
-        HIP_TRY(ctx, hipEventRecord(ctx->chain[1].ev_done, chain[1].ws->stream));
-        HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->chain[1].ev_done, 0));
+    for (int c = 1; c < n_chains; ++c) {
+        // the resolve runs on the main stream: it has to see every chain's results
+        HIP_TRY(ctx, hipEventRecord(ctx->chain[c].ev_done, chain[c].ws->stream));
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->chain[c].ev_done, 0));
     }
-    *ray_count = chain[0].rays + (n_chains == 2 ? chain[1].rays : 0);
-    *trace_ms = chain[0].trace_ms + (n_chains == 2 ? chain[1].trace_ms : 0.0f);
-    *launches = chain[0].launches + (n_chains == 2 ? chain[1].launches : 0);
+    *ray_count = 0;
+    *trace_ms = 0.0f;
+    *launches = 0;
+    for (int c = 0; c < n_chains; ++c) { *ray_count += chain[c].rays; *trace_ms += chain[c].trace_ms; *launches += chain[c].launches; }
     return 0;
 }
 
@@ -637,8 +647,8 @@ prt_ctx * prt_create(int device_id) {
     e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
     for (int i = 0; i < 4 && e == hipSuccess; ++i) e = hipEventCreate(&ctx->ev[i]);
     ctx->chain[0].stream = ctx->stream;
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->chain[1].stream, hipStreamNonBlocking);
-    for (int c = 0; c < 2 && e == hipSuccess; ++c) {
+    for (int c = 1; c < PRT_MAX_CHAINS && e == hipSuccess; ++c) e = hipStreamCreateWithFlags(&ctx->chain[c].stream, hipStreamNonBlocking);
+    for (int c = 0; c < PRT_MAX_CHAINS && e == hipSuccess; ++c) {
         prt_ctx::ChainWs & w = ctx->chain[c];
         e = hipEventCreate(&w.ev_t0);
         if (e == hipSuccess) e = hipEventCreate(&w.ev_t1);
@@ -661,7 +671,7 @@ void prt_destroy(prt_ctx * ctx) {
     ctx->nodes.release(); ctx->tris.release(); ctx->shade.release(); ctx->diffuse_dirs.release(); ctx->spec_dirs.release();
     ctx->tri_rank.release(); ctx->materials.release(); ctx->lights.release();
     ctx->sample_rgb.release(); ctx->frame_out.release(); ctx->counters.release(); ctx->ring_ws.release(); ctx->pixel_list.release(); ctx->wf_counts.release(); ctx->stack_spill.release();
-    for (int c = 0; c < 2; ++c) {
+    for (int c = 0; c < PRT_MAX_CHAINS; ++c) {
         prt_ctx::ChainWs & w = ctx->chain[c];
         w.f4.release(); w.rng.release(); w.counts.release(); w.overflow.release(); w.slow_stack.release();
         if (w.ev_t0) (void)hipEventDestroy(w.ev_t0);
@@ -669,7 +679,7 @@ void prt_destroy(prt_ctx * ctx) {
         if (w.ev_done) (void)hipEventDestroy(w.ev_done);
         if (w.ev_first) (void)hipEventDestroy(w.ev_first);
         if (w.host_counts) (void)hipHostFree(w.host_counts);
-        if (c == 1 && w.stream) (void)hipStreamDestroy(w.stream);
+        if (c >= 1 && w.stream) (void)hipStreamDestroy(w.stream);
     }
     for (int i = 0; i < 4; ++i) if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
