@@ -204,6 +204,13 @@ int prt_get_scene_info(const prt_ctx * ctx, prt_scene_info * info);
  * exactly one leaf, links in range.  out[6] = { violations, nodes, depth, stack bound, leaves, triangle refs }. */
 int prt_debug_check_bvh(const prt_scene_desc * scene, uint64_t * out);
 
+/* Device known-answer hook (GPU test-suite): runs one device function of the hot path on `n` caller-supplied
+ * records (host pointers) and returns its outputs, so tests can compare them bit for bit with the reference's.
+ * kinds and record layouts: csrc/kernels_debug.h.  cam may be NULL except for the camera-ray kind; a scene
+ * must be uploaded (the diffuse-direction kind reads its table). */
+int prt_debug_device_kat(prt_ctx * ctx, int kind, const void * in, size_t in_bytes, void * out, size_t out_bytes,
+                         uint32_t n, const prt_camera * cam);
+
 #ifdef __cplusplus
 }
 #endif

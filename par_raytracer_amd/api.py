@@ -185,6 +185,15 @@ class Renderer:
                     "prt_render_shard")
         return out, counters
 
+    def device_kat(self, kind: int, records: np.ndarray, out_shape, out_dtype, cam: Optional[PrtCamera] = None) -> np.ndarray:
+        """Run one device function on `records` (see csrc/kernels_debug.h); test hook."""
+        rec = np.ascontiguousarray(records)
+        out = np.zeros(out_shape, dtype=out_dtype)
+        self._check(self._lib.prt_debug_device_kat(self._ctx, int(kind), rec.ctypes.data_as(C.c_void_p), rec.nbytes,
+                                                   out.ctypes.data_as(C.c_void_p), out.nbytes, rec.shape[0],
+                                                   C.byref(cam) if cam is not None else None), "prt_debug_device_kat")
+        return out
+
     def close(self):
         if self._ctx:
             self._lib.prt_destroy(self._ctx)

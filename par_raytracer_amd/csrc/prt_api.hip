@@ -21,6 +21,7 @@
 #include "kernels_mega.h"
 #include "kernels_wave.h"
 #include "kernels_persist.h"
+#include "kernels_debug.h"
 
 using namespace prt;
 
@@ -955,6 +956,38 @@ int prt_render_pixel_list(prt_ctx * ctx, const prt_camera * cam, const prt_param
     int rc = render_pixels(ctx, cam, params, width, height, px, ctx->frame_out.p, counters);
     if (rc) return rc;
     if (n_pixels) HIP_TRY(ctx, hipMemcpy(rgba_out, ctx->frame_out.p, (size_t)n_pixels * sizeof(float4), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int prt_debug_device_kat(prt_ctx * ctx, int kind, const void * in, size_t in_bytes, void * out, size_t out_bytes, uint32_t n,
+                         const prt_camera * cam_in) {
+    if (!ctx) return -1;
+    if (!ctx->has_scene) { ctx->error = "prt_debug_device_kat: upload a scene first"; return -2; }
+    if (!in || !out || !n) { ctx->error = "prt_debug_device_kat: null buffers"; return -1; }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    void * d_in = nullptr;
+    void * d_out = nullptr;
+    HIP_TRY(ctx, hipMalloc(&d_in, in_bytes));
+    HIP_TRY(ctx, hipMalloc(&d_out, out_bytes));
+    HIP_TRY(ctx, ctx->ring_ws.ensure((size_t)16 * n));
+    HIP_TRY(ctx, hipMemcpy(d_in, in, in_bytes, hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemset(d_out, 0, out_bytes));
+    DevCamera cam;
+    memset(&cam, 0, sizeof(cam));
+    if (cam_in) {
+        cam.position = ld3(cam_in->position);
+        cam.forward = ld3(cam_in->forward);
+        cam.right_scaled = ld3(cam_in->right) * cam_in->tan_a2 * cam_in->aspect;
+        cam.up_scaled = ld3(cam_in->up) * cam_in->tan_a2;
+        cam.inv_width = cam_in->inv_width;
+        cam.inv_height = cam_in->inv_height;
+    }
+    hipLaunchKernelGGL(k_debug_kat, dim3((n + 63) / 64), dim3(64), 0, ctx->stream, kind, d_in, d_out, n, ctx->scene, cam, ctx->ring_ws.p);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipMemcpy(out, d_out, out_bytes, hipMemcpyDeviceToHost));
+    (void)hipFree(d_in);
+    (void)hipFree(d_out);
     return 0;
 }
 
