@@ -201,22 +201,26 @@ def main():
     else:
         cc = r.render_shard_device(cam, pcount, width, height, SHARD_BLOCK_ROWS, rank, world, shard.data_ptr(), True)
     n_px_local = my_rows * width if world > 1 else width * height
-    mega = (args.pipeline & 0xFF) == 1
-    # k_trace moves rays, nodes and triangle records; shading records and the framebuffer belong to k_shade / k_resolve
+    used = int(cc.pipeline)                       # what PRT_PIPELINE_DEFAULT resolved to for this shard size
+    pipeline_name = {1: "megakernel", 2: "wavefront", 3: "persistent", 4: "pool"}[used]
+    kernel_name = {1: "k_render_mega", 2: "k_trace", 3: "k_render_persistent", 4: "k_pool"}[used]
+    fused = used != 2
+    # k_trace moves rays, nodes and triangle records; shading records and the framebuffer belong to k_shade / k_resolve.
+    # The single-launch pipelines do all of it in the one kernel that is timed.
     alg_bytes = cc.ray_count * B_RAY + cc.node_visits * B_NODE + cc.tri_tests * B_TRI
-    if mega:
+    if fused:
         alg_bytes += cc.shaded_hits * B_SHADE + n_px_local * B_PIXEL
     kernel_ms = float(np.mean(trace_ms))
     achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.workload)
-    if os.path.exists(tpath) and world == 1:
+    if os.path.exists(tpath) and world == 1 and not fused:
         try:
             with open(tpath) as f:
                 traffic = json.load(f).get("hbm_bytes_per_frame_k_trace")
         except Exception:
             traffic = None
-    roofline = {"bound": "hbm", "kernel": "k_render_mega" if mega else "k_trace", "launches_per_frame": int(cc.trace_kernel_launches),
+    roofline = {"bound": "hbm", "kernel": kernel_name, "launches_per_frame": int(cc.trace_kernel_launches),
                 "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                 "algorithmic_bytes_per_frame": int(alg_bytes), "kernel_ms_per_frame": round(kernel_ms, 4),
@@ -272,7 +276,7 @@ def main():
                        "spp": spp, "bounce_depth": depth, "rays_per_frame": int(rays_total / args.steps),
                        "parallelism": "pixel rows sharded in %d-row blocks over %d GPU(s)%s" % (
                            SHARD_BLOCK_ROWS, world, (", RCCL gather to rank 0" if args.backend == "nccl" else ", gloo gather (rehearsal)") if world > 1 else ""),
-                       "pipeline": "megakernel" if mega else "wavefront"},
+                       "pipeline": pipeline_name},
             "render_ms_device": round(float(np.mean(render_ms)), 4),
             "roofline": roofline, "cpu_baseline": cpu_baseline, "parity": parity, "multi_gpu_check": multi_check,
         }

@@ -124,8 +124,10 @@ typedef struct prt_params {
     uint64_t seed;
 } prt_params;
 
+/* DEFAULT picks by size: POOL (one launch, wave-private ray pools) up to ~5 M samples per call, WAVEFRONT (one launch
+ * per bounce round, global ray queues) above.  All pipelines produce the same image (see tests/test_gpu_parity.py). */
 enum { PRT_PIPELINE_DEFAULT = 0, PRT_PIPELINE_MEGAKERNEL = 1, PRT_PIPELINE_WAVEFRONT = 2, PRT_PIPELINE_PERSISTENT = 3,
-       PRT_PIPELINE_MASK = 0xFF };
+       PRT_PIPELINE_POOL = 4, PRT_PIPELINE_MASK = 0xFF };
 /* OR-ed into prt_params.pipeline: also count BVH node visits and triangle tests (costs a few percent;
  * ray_count and shaded_hits are always counted). */
 enum { PRT_FLAG_COUNT_VISITS = 0x100 };
@@ -140,7 +142,7 @@ typedef struct prt_counters {
     double render_ms;              /* ray generation -> resolved framebuffer, device time */
     double trace_kernel_ms;        /* time inside the dominant (traversal) kernel(s) */
     uint32_t trace_kernel_launches;
-    uint32_t reserved;
+    uint32_t pipeline;             /* the PRT_PIPELINE_* that ran (what PRT_PIPELINE_DEFAULT resolved to) */
 } prt_counters;
 
 typedef struct prt_ctx prt_ctx;

@@ -73,10 +73,10 @@ class PrtParams(C.Structure):
 class PrtCounters(C.Structure):
     _fields_ = [("ray_count", C.c_uint64), ("node_visits", C.c_uint64), ("tri_tests", C.c_uint64),
                 ("shaded_hits", C.c_uint64), ("render_ms", C.c_double), ("trace_kernel_ms", C.c_double),
-                ("trace_kernel_launches", C.c_uint32), ("reserved", C.c_uint32)]
+                ("trace_kernel_launches", C.c_uint32), ("pipeline", C.c_uint32)]
 
     def as_dict(self):
-        return {n: getattr(self, n) for n, _ in self._fields_ if n != "reserved"}
+        return {n: getattr(self, n) for n, _ in self._fields_}
 
 
 class PrtSceneInfo(C.Structure):
@@ -88,7 +88,7 @@ class PrtSceneInfo(C.Structure):
         return {n: getattr(self, n) for n, _ in self._fields_}
 
 
-PIPELINE_DEFAULT, PIPELINE_MEGAKERNEL, PIPELINE_WAVEFRONT, PIPELINE_PERSISTENT = 0, 1, 2, 3
+PIPELINE_DEFAULT, PIPELINE_MEGAKERNEL, PIPELINE_WAVEFRONT, PIPELINE_PERSISTENT, PIPELINE_POOL = 0, 1, 2, 3, 4
 FLAG_COUNT_VISITS = 0x100
 
 # Every symbol include/prt.h declares; tests/test_capi_symbols.py checks the library exports them all.

@@ -1,0 +1,318 @@
+// kernels_pool.h - the wave-pool pipeline: ONE launch per frame, every wave runs the whole wavefront loop on a
+// private pool of rays.
+//
+// Measured on the wavefront pipeline (profiles/r01_wavefront_*): each of its ~8 bounce rounds pays a launch ramp,
+// a drain tail (the longest rays of the round with the rest of the chip idle), a host round trip for the queue
+// sizes and chip-wide append atomics.  At full-frame size that is ~10 % of the frame; on a 1/8 frame shard
+// (multi-GPU) it is half of it.  Here the ROUND is private to a wave:
+//
+//   every wave owns `cap` closest-hit ray slots and `cap * lights` shadow ray slots in HBM (structure of arrays,
+//   so a wave's 64 lanes read / write 1 KB runs) and loops
+//     top up   while samples remain: reserve `cap - n` of them from the global sample counter (one atomic per
+//              top-up, the only inter-wave communication of the frame) and generate their camera rays in place
+//     trace    all rays of the pool, closest-hit and shadow mixed, with the same traversal loop as k_trace: lanes
+//              are refilled from the wave's own list by ballot / mbcnt rank, no atomics
+//     shade    all closest hits of the pool, 64 per pass at full lane utilisation, with shade_entry() of
+//              kernels_wave.h; the next rays are appended to the pool's other list by ballot prefix, no atomics
+//   until the sample counter is exhausted and its pool is empty.  Per-sample state (RNG, accumulated radiance,
+//   pending frames) lives in the same per-sample arrays as in the wavefront pipeline and is only ever touched by
+//   the wave that fetched the sample, so plain loads and stores are enough (a workgroup-scope fence between the
+//   phases orders them; the vector L1 is coherent within a CU).  Waves drift out of phase with each other, so the
+//   HBM-bound shading of some waves overlaps the issue-bound traversal of others on the same SIMD.
+//
+// Results are those of the wavefront pipeline bit for bit: same shade_entry(), same traversal, same per-sample
+// RNG keys; only the order in which independent samples are processed differs.
+#pragma once
+
+#include "kernels_wave.h"
+
+namespace prt {
+
+struct PoolBuffers {
+    float4 * cq;                 // [waves][2][3][cap]   closest-hit lists, double buffered: (o, sample) (d, level | pending << 8) (T, -)
+    float4 * hits;               // [waves][cap]         (t, v, w, tri) by list position
+    float4 * sq;                 // [waves][3][scap]     shadow list: (o, sample) (radiance, w) (d, -), see WaveBuffers::sq_*
+    unsigned int * head;         // global sample counter
+    unsigned int cap, scap;      // slots per wave; multiples of 64
+    unsigned int topup_min;      // top up when at least this many slots are free
+};
+
+// Emitter of k_pool: appends to the wave's private lists, slots by rank among the appending lanes.
+struct PoolEmit {
+    float4 * co, * cd, * ct;     // next closest list
+    float4 * so, * sc, * sd;     // next shadow list
+    unsigned int m_c, m_s;       // wave-uniform fill counts
+    PRT_D void shadow(bool want, unsigned int s, f3 o, f3 d, f3 contrib, float w, int kind) {
+        const unsigned long long mask = __ballot(want);
+        const unsigned int prefix = __builtin_amdgcn_mbcnt_hi((unsigned int)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)mask, 0u));
+        if (want) {
+            const unsigned int slot = m_s + prefix;
+            so[slot] = make_float4(o.x, o.y, o.z, as_f((int)s));
+            if (kind == WF_KIND_SHADOW_DIST) sd[slot] = make_float4(d.x, d.y, d.z, 0.0f);
+            sc[slot] = make_float4(contrib.x, contrib.y, contrib.z, w);
+        }
+        m_s += (unsigned int)__popcll(mask);
+    }
+    PRT_D void closest(bool want, unsigned int s, f3 o, f3 d, f3 T, int level, unsigned int pending) {
+        const unsigned long long mask = __ballot(want);
+        const unsigned int prefix = __builtin_amdgcn_mbcnt_hi((unsigned int)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)mask, 0u));
+        if (want) {
+            const unsigned int slot = m_c + prefix;
+            co[slot] = make_float4(o.x, o.y, o.z, as_f((int)s));
+            cd[slot] = make_float4(d.x, d.y, d.z, as_f(level | (int)(pending << 8)));
+            ct[slot] = make_float4(T.x, T.y, T.z, 0.0f);
+        }
+        m_c += (unsigned int)__popcll(mask);
+    }
+};
+
+PRT_D void pool_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }
+
+// grid = resident blocks; dynamic LDS = stack_entries * BLOCK * 4 (traversal stack columns).
+template <int BLOCK, int WAVES, bool LDSTAB, bool RING, bool COUNT>
+__global__ __launch_bounds__(BLOCK, WAVES) void k_pool(DevScene sc, DevCamera cam, DevParams P, WaveBuffers B, PoolBuffers Q, int keep_min,
+                                                 int node_min, int multi_light, DevCounters * ctr) {
+    extern __shared__ int s_stack[];
+    constexpr int LDS_MATS = 32, LDS_LIGHTS = 4;
+    __shared__ float4 s_diffuse[LDSTAB ? 1024 : 1];
+    __shared__ DevMaterial s_mats[LDS_MATS];
+    __shared__ DevLight s_lights[LDS_LIGHTS];
+    __shared__ unsigned long long s_red[2];
+    const bool lds_mats = sc.material_count <= (unsigned int)LDS_MATS;
+    const bool lds_lights = sc.light_count <= (unsigned int)LDS_LIGHTS;
+    if (LDSTAB) for (unsigned int k = threadIdx.x; k < 1024u; k += BLOCK) s_diffuse[k] = sc.diffuse_dirs[k];
+    if (lds_mats) {
+        const float4 * src = reinterpret_cast<const float4 *>(sc.materials);
+        float4 * dst = reinterpret_cast<float4 *>(s_mats);
+        for (unsigned int k = threadIdx.x; k < sc.material_count * 4u; k += BLOCK) dst[k] = src[k];
+    }
+    if (lds_lights) {
+        const float4 * src = reinterpret_cast<const float4 *>(sc.lights);
+        float4 * dst = reinterpret_cast<float4 *>(s_lights);
+        for (unsigned int k = threadIdx.x; k < sc.light_count * 3u; k += BLOCK) dst[k] = src[k];
+    }
+    if (threadIdx.x < 2) s_red[threadIdx.x] = 0ull;
+    __syncthreads();
+    ShadeTables tb;
+    tb.diffuse = LDSTAB ? s_diffuse : sc.diffuse_dirs;
+    tb.materials = lds_mats ? s_mats : sc.materials;
+    tb.lights = lds_lights ? s_lights : sc.lights;
+
+    LdsStack<BLOCK> stack;
+    stack.col = s_stack + threadIdx.x;
+    stack.cap = P.stack_lds_entries;
+    const unsigned int slot_id = blockIdx.x * BLOCK + threadIdx.x;
+    GlobalStack slow;
+    slow.col = P.stack_spill + slot_id;
+    slow.stride = P.stack_spill_stride;
+    const unsigned int lane = lane_id();
+    const unsigned int wave = (unsigned int)__builtin_amdgcn_readfirstlane((int)(slot_id >> 6));      // scalar: the list pointers stay in SGPRs
+    const unsigned int cap = Q.cap, scap = Q.scap;
+    float4 * const cq_base = Q.cq + (size_t)wave * 6u * cap;
+    float4 * const hits = Q.hits + (size_t)wave * cap;
+    float4 * const sq_o = Q.sq + (size_t)wave * 3u * scap;
+    float4 * const sq_c = sq_o + scap;
+    float4 * const sq_d = sq_c + scap;
+
+    int cur = 0;
+    unsigned int n_c = 0, n_s = 0;             // wave-uniform: rays in the current closest / shadow list
+    bool fetch_done = false;                   // wave-uniform: the sample counter ran past n_samples
+    unsigned long long rays = 0ull;            // wave-uniform
+    unsigned int shaded_w = 0;                 // wave-uniform
+    TraceStats st;
+    st.nodes = st.tris = st.wnodes = st.wleaves = st.wtris = st.wrefills = st.max_sp = st.culled = 0;
+
+    for (;;) {
+        float4 * const co = cq_base + (size_t)cur * 3u * cap;
+        float4 * const cd = co + cap;
+        float4 * const ct = cd + cap;
+
+        // ---- top up: fresh samples into the free closest-hit slots ------------------------------------------
+        if (!fetch_done && n_c + Q.topup_min <= cap) {
+            const unsigned int want = cap - n_c;
+            unsigned int base = 0;
+            if (lane == 0) base = atomicAdd(Q.head, want);
+            base = (unsigned int)__builtin_amdgcn_readfirstlane((int)base);
+            if (base >= B.n_samples) {
+                fetch_done = true;
+            } else {
+                unsigned int cnt = B.n_samples - base;
+                if (cnt <= want) fetch_done = true; else cnt = want;
+                for (unsigned int k = lane; k < cnt; k += 64u) {
+                    const unsigned int sid = base + k;
+                    const unsigned int gsid = B.sample_base + sid;
+                    SampleState S;
+                    Frame fr;
+                    u64 * ring = RING ? B.ring + sid : nullptr;
+                    sample_begin<RING>(cam, P, pixel_of_local(P, gsid / P.spp), gsid % P.spp, S, fr, ring, B.n_samples);
+                    B.rng[sid] = make_ulonglong2(S.rng.chain, S.rng.prev);
+                    if (RING) B.rng_aux[sid] = make_ulonglong2(S.rng.seed0, (u64)S.rng.k);
+                    B.accum[sid] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                    co[n_c + k] = make_float4(fr.ray_o.x, fr.ray_o.y, fr.ray_o.z, as_f((int)sid));
+                    cd[n_c + k] = make_float4(fr.ray_d.x, fr.ray_d.y, fr.ray_d.z, as_f(0));
+                    ct[n_c + k] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
+                }
+                n_c += cnt;
+            }
+        }
+        const unsigned int total = n_c + n_s;
+        if (total == 0u) {
+            if (fetch_done) break;
+            continue;
+        }
+        pool_fence();
+        rays += total;                                                     // debug->ray_count++  raytracer.cpp:161
+
+        // ---- trace: every ray of the pool ------------------------------------------------------------------
+        {
+            TravRay r;
+            r.node = TRAV_SENTINEL; r.sp = 0; r.kind = 0; r.overflow = false;
+            int ray = -1;
+            float4 payload = make_float4(0, 0, 0, 0);
+            int sample = 0;
+            unsigned int next = 0;                                         // wave-uniform: rays handed out so far
+            for (;;) {
+                const unsigned long long idle = __ballot(ray < 0);
+                if (idle != 0ull && next < total) {
+                    if (COUNT && lane == 0) st.wrefills++;
+                    const unsigned int avail = total - next;
+                    const unsigned int prefix = __builtin_amdgcn_mbcnt_hi((unsigned int)(idle >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)idle, 0u));
+                    const unsigned int n_idle = (unsigned int)__popcll(idle);
+                    const unsigned int take = n_idle < avail ? n_idle : avail;
+                    if (ray < 0 && prefix < take) {
+                        const unsigned int idx = next + prefix;
+                        float4 ro, rd;
+                        int kind;
+                        if (idx < n_c) {
+                            ro = co[idx];
+                            rd = cd[idx];
+                            kind = WF_KIND_CLOSEST;
+                        } else {
+                            const unsigned int j = idx - n_c;
+                            ro = sq_o[j];
+                            payload = sq_c[j];
+                            if (payload.w < 0.0f) {          // directional light: the direction is a per-light constant
+                                const DevLight & L = tb.lights[(unsigned int)(-payload.w) - 1u];
+                                const f3 lv = mk3(L.facing[0], L.facing[1], L.facing[2]) * -1.0f;   // raytracer.cpp:240
+                                rd = make_float4(lv.x, lv.y, lv.z, 0.0f);
+                                kind = WF_KIND_SHADOW_ANY;
+                            } else {
+                                rd = sq_d[j];
+                                kind = WF_KIND_SHADOW_DIST;
+                            }
+                        }
+                        sample = as_i(ro.w);
+                        const f3 d = mk3(rd.x, rd.y, rd.z);
+                        const f3 ob = mk3(ro.x, ro.y, ro.z) + d * P.ray_bias;          // raytracer.cpp:163
+                        trav_init(r, ob, d, kind == WF_KIND_SHADOW_ANY ? TRACE_ANY : TRACE_CLOSEST, P.box_pad, stack);
+                        ray = (int)idx;
+                    }
+                    next += take;
+                }
+                if (__ballot(ray >= 0) == 0ull) break;
+
+                const int leave_below = next == total ? 1 : keep_min;
+                while (ray >= 0) {
+                    const int walkers = __popcll(__ballot(r.node >= 0));
+                    const int nmin = node_min < (walkers >> 1) ? node_min : (walkers >> 1);
+                    while (r.node >= 0) {
+                        trav_node_step<LdsStack<BLOCK>, COUNT>(sc, r, stack, st);
+                        if (__popcll(__ballot(r.node >= 0)) < nmin) break;
+                    }
+                    bool fin = r.node == TRAV_SENTINEL;
+                    if (!fin && r.node < 0) fin = trav_leaf<LdsStack<BLOCK>, COUNT>(sc, r, stack, st);
+                    if (fin) {
+                        if (r.overflow) {
+                            // a push did not fit the LDS column (never observed on real scenes): redo the ray on this
+                            // lane's full-height global column
+                            bool again;
+                            r.best = trace_ray_on<GlobalStack, COUNT>(sc, r.o, r.d, r.kind, P.box_pad, slow, st, again);
+                        }
+                        if ((unsigned int)ray < n_c) {
+                            hits[ray] = make_float4(r.best.t, r.best.v, r.best.w, as_f(r.best.tri));
+                        } else {
+                            // shadow ray: add the precomputed radiance when unoccluded (k_trace has the commentary)
+                            const bool lit = r.best.tri < 0 || (payload.w >= 0.0f && r.best.t * r.best.t <= payload.w);
+                            if (lit) {
+                                if (multi_light) {
+                                    atomicAdd(&B.accum[sample].x, payload.x);
+                                    atomicAdd(&B.accum[sample].y, payload.y);
+                                    atomicAdd(&B.accum[sample].z, payload.z);
+                                } else {
+                                    float4 a = B.accum[sample];
+                                    a.x += payload.x; a.y += payload.y; a.z += payload.z;
+                                    B.accum[sample] = a;
+                                }
+                            }
+                        }
+                        ray = -1;
+                        break;
+                    }
+                    if (__popcll(__ballot(true)) < leave_below) break;
+                }
+            }
+        }
+        pool_fence();
+
+        // ---- shade: every closest hit of the pool, 64 per pass ----------------------------------------------
+        {
+            const int nxt = cur ^ 1;
+            PoolEmit emit;
+            emit.co = cq_base + (size_t)nxt * 3u * cap;
+            emit.cd = emit.co + cap;
+            emit.ct = emit.cd + cap;
+            emit.so = sq_o; emit.sc = sq_c; emit.sd = sq_d;
+            emit.m_c = 0; emit.m_s = 0;
+            for (unsigned int b0 = 0; b0 < n_c; b0 += 64u) {
+                const unsigned int i = b0 + lane;
+                const bool live = i < n_c;
+                unsigned int s = 0;
+                int level = 0;
+                unsigned int pending = 0;
+                f3 ray_o = mk3(0, 0, 0), ray_d = mk3(0, 0, 1), T = mk3(0, 0, 0);
+                HitRec hit;
+                hit.t = 0.0f; hit.v = hit.w = 0.0f; hit.tri = -1;
+                if (live) {
+                    const float4 ro = co[i], rd = cd[i], rt = ct[i], h = hits[i];
+                    s = (unsigned int)as_i(ro.w);
+                    level = as_i(rd.w) & 0xFF;
+                    pending = ((unsigned int)as_i(rd.w)) >> 8;
+                    ray_o = mk3(ro.x, ro.y, ro.z);
+                    ray_d = mk3(rd.x, rd.y, rd.z);
+                    T = mk3(rt.x, rt.y, rt.z);
+                    hit.t = h.x; hit.v = h.y; hit.w = h.z; hit.tri = as_i(h.w);
+                }
+                unsigned int shaded = 0;
+                shade_entry<RING>(sc, P, B, tb, live, s, level, pending, ray_o, ray_d, T, hit, emit, shaded);
+                shaded_w += (unsigned int)__popcll(__ballot(shaded != 0));
+            }
+            n_c = emit.m_c;
+            n_s = emit.m_s;
+            cur = nxt;
+        }
+        pool_fence();
+    }
+
+    // ---- counters: one atomic per workgroup and counter ----------------------------------------------------
+    if (lane == 0) {
+        atomicAdd(&s_red[0], rays);
+        atomicAdd(&s_red[1], (unsigned long long)shaded_w);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (s_red[0]) atomicAdd(&ctr->ray_count, s_red[0]);
+        if (s_red[1]) atomicAdd(&ctr->shaded_hits, s_red[1]);
+    }
+    if (COUNT) {
+        atomicAdd(&ctr->node_visits, (unsigned long long)st.nodes);
+        atomicAdd(&ctr->tri_tests, (unsigned long long)st.tris);
+        atomicAdd(&ctr->wave_node_steps, (unsigned long long)st.wnodes);
+        atomicAdd(&ctr->wave_leaf_steps, (unsigned long long)st.wleaves);
+        atomicAdd(&ctr->wave_tri_steps, (unsigned long long)st.wtris);
+        atomicAdd(&ctr->wave_refills, (unsigned long long)st.wrefills);
+        atomicMax(&ctr->max_sp, (unsigned long long)st.max_sp);
+        atomicAdd(&ctr->culled, (unsigned long long)st.culled);
+    }
+}
+
+}  // namespace prt

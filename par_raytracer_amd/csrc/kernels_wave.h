@@ -351,53 +351,24 @@ PRT_D void wframe_load(const WaveBuffers & B, int level, unsigned int s, WFrame 
     }
 }
 
-// One lane per closest-hit result of queue `cur`; appends to queue `cur ^ 1` and to the shadow queue.
-template <bool RING, int BLOCK>
-__global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, DevParams P, WaveBuffers B, int cur, unsigned int n_closest,
-                                                 DevCounters * ctr) {
-    __shared__ unsigned int s_cnt[BLOCK / 64 + 1];
-    // Small read-only tables staged in LDS once per workgroup: every dependent global load removed from the
-    // per-hit chain (triangle -> material -> light -> direction table) is a memory round trip less per wave.
-    constexpr int LDS_MATS = 32, LDS_LIGHTS = 4;
-    __shared__ float4 s_diffuse[1024];                         // 16 KB: the Hammersley cosine-lobe directions
-    __shared__ DevMaterial s_mats[LDS_MATS];                    // 2 KB
-    __shared__ DevLight s_lights[LDS_LIGHTS];
-    const bool lds_mats = sc.material_count <= (unsigned int)LDS_MATS;
-    const bool lds_lights = sc.light_count <= (unsigned int)LDS_LIGHTS;
-    for (unsigned int k = threadIdx.x; k < 1024u; k += BLOCK) s_diffuse[k] = sc.diffuse_dirs[k];
-    if (lds_mats) {
-        const float4 * src = reinterpret_cast<const float4 *>(sc.materials);
-        float4 * dst = reinterpret_cast<float4 *>(s_mats);
-        for (unsigned int k = threadIdx.x; k < sc.material_count * 4u; k += BLOCK) dst[k] = src[k];
-    }
-    if (lds_lights) {
-        const float4 * src = reinterpret_cast<const float4 *>(sc.lights);
-        float4 * dst = reinterpret_cast<float4 *>(s_lights);
-        for (unsigned int k = threadIdx.x; k < sc.light_count * 3u; k += BLOCK) dst[k] = src[k];
-    }
-    __syncthreads();
-    const unsigned int i = blockIdx.x * BLOCK + threadIdx.x;
-    const bool live = i < n_closest;
-    const int depth = (int)P.bounce_depth;
-    const int nxt = cur ^ 1;
+// What k_shade reads besides the queues: small read-only tables (global, or staged in LDS by the caller).
+struct ShadeTables {
+    const float4 * diffuse;          // 1024 Hammersley cosine-lobe directions (tangent space)
+    const DevMaterial * materials;
+    const DevLight * lights;
+};
 
-    unsigned int s = 0;
-    int level = 0;
-    unsigned int pending = 0;
-    f3 ray_o = mk3(0, 0, 0), ray_d = mk3(0, 0, 1), T = mk3(0, 0, 0);
-    HitRec hit;
-    hit.t = 0.0f; hit.v = hit.w = 0.0f; hit.tri = -1;
+// One closest-hit result -> the sample's next rays.  `live` lanes process (s, level, pending, ray, T, hit); every
+// lane of the calling group must call it (the emitter aggregates appends).  emit.shadow(...) is called once per
+// light by every lane, emit.closest(...) once at the end.
+template <bool RING, class Emit>
+PRT_D void shade_entry(const DevScene & sc, const DevParams & P, const WaveBuffers & B, const ShadeTables & tb, bool live,
+                       unsigned int s, int level, unsigned int pending, f3 ray_o, f3 ray_d, f3 T, const HitRec & hit, Emit & emit,
+                       unsigned int & shaded) {
+    const int depth = (int)P.bounce_depth;
     Rng rng;
     rng.chain = rng.prev = rng.seed0 = 0; rng.k = 0;
     if (live) {
-        const float4 ro = B.rq_o[cur][i], rd = B.rq_d[cur][i], rt = B.rq_t[cur][i], h = B.hits[i];
-        s = (unsigned int)as_i(ro.w);
-        level = as_i(rd.w) & 0xFF;
-        pending = ((unsigned int)as_i(rd.w)) >> 8;
-        ray_o = mk3(ro.x, ro.y, ro.z);
-        ray_d = mk3(rd.x, rd.y, rd.z);
-        T = mk3(rt.x, rt.y, rt.z);
-        hit.t = h.x; hit.v = h.y; hit.w = h.z; hit.tri = as_i(h.w);
         const ulonglong2 rs = B.rng[s];
         rng.chain = rs.x; rng.prev = rs.y;
         if (RING) { const ulonglong2 ra = B.rng_aux[s]; rng.seed0 = ra.x; rng.k = (u32)ra.y; }
@@ -409,7 +380,6 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, DevParams P, WaveB
     bool emit_closest = false;
     f3 next_o = ray_o, next_d = ray_d, next_T = T;
     int next_level = 0;
-    unsigned int shaded = 0;
 
     // ---- step 1: the hit (or miss) of the ray that just came back ----------------------------------------
     enum { M_NEXT_CHILD, M_ENTER, M_RETURN_UP, M_DONE };
@@ -420,7 +390,7 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, DevParams P, WaveB
     bool want_shadow = false;
     bool f_held = false;
     f3 T_own = T;
-    DevMaterial mat = lds_mats ? s_mats[0] : sc.materials[0];
+    DevMaterial mat = tb.materials[0];
     if (live) {
         if (hit.tri < 0) {                                                         // raytracer.cpp:573-575
             add = add + T * P.background;
@@ -433,7 +403,7 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, DevParams P, WaveB
             const float4 s0 = sp[0], s1 = sp[1], s2 = sp[2], s3 = sp[3];
             const f3 gn = normalize3(mk3(s2.y, s2.z, s2.w));                        // raytracer.cpp:122 (n = Cross(ab, ac))
             const int m = as_i(s3.w);
-            mat = lds_mats ? s_mats[m] : sc.materials[m];
+            mat = tb.materials[m];
             const float alpha = mat.alpha;
             if (mat.alpha <= 1.0f && alpha <= 0.05f) {                              // raytracer.cpp:443-453
                 next_o = pos + ray_d * P.ray_bias * 2.0f;
@@ -475,7 +445,7 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, DevParams P, WaveB
         float dist_sq = -1.0f;
         int kind = WF_KIND_SHADOW_ANY;
         if (want_shadow) {
-            const DevLight L = lds_lights ? s_lights[li] : sc.lights[li];
+            const DevLight L = tb.lights[li];
             f3 light_color = mk3(L.color[0], L.color[1], L.color[2]);
             f3 light_vector;
             if (L.type == 0) {
@@ -497,23 +467,14 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, DevParams P, WaveB
             so = f.hit_p;
             sd = light_vector;
         }
-        const unsigned int slot = block_append<BLOCK / 64>(B.counts + 1, want_shadow, s_cnt);
-        if (want_shadow) {
-            B.sq_o[slot] = make_float4(so.x, so.y, so.z, as_f((int)s));
-            if (kind == WF_KIND_SHADOW_DIST) {
-                B.sq_d[slot] = make_float4(sd.x, sd.y, sd.z, 0.0f);
-                B.sq_c[slot] = make_float4(contrib.x, contrib.y, contrib.z, dist_sq);
-            } else {
-                B.sq_c[slot] = make_float4(contrib.x, contrib.y, contrib.z, -(float)(li + 1u));   // directional light li
-            }
-        }
+        emit.shadow(want_shadow, s, so, sd, contrib, kind == WF_KIND_SHADOW_DIST ? dist_sq : -(float)(li + 1u), kind);
     }
 
     // ---- step 2: walk the bounce tree in depth-first order until the next ray or the end of the sample ----
     while (mode != M_DONE) {
         if (mode == M_NEXT_CHILD) {                       // frame f at `level` spawns its next child, if any
             const int iters = depth - level;
-            const DevMaterial fm = lds_mats ? s_mats[f.mat] : sc.materials[f.mat];
+            const DevMaterial fm = tb.materials[f.mat];
             const f3 own = f.alpha < 1.0f ? f.T_in * f.alpha : f.T_in;
             // which child comes next (cheap), then ONE copy of the expensive direction code for both lobes
             int kind = -1;                                                          // 0 diffuse, 1 specular, 2 alpha continuation
@@ -538,7 +499,7 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, DevParams P, WaveB
                 float4 ts;
                 if (kind == 0) {
                     const unsigned int series_i = (unsigned int)(rng_next<RING>(rng, ring, ring_stride) % 1024ull);
-                    ts = s_diffuse[series_i];
+                    ts = tb.diffuse[series_i];
                 } else {
                     ts = sc.spec_dirs[(size_t)f.mat * sc.spec_samples + (unsigned int)f.idx];
                 }
@@ -595,12 +556,85 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, DevParams P, WaveB
         B.rng[s] = make_ulonglong2(rng.chain, rng.prev);
         if (RING) B.rng_aux[s] = make_ulonglong2(rng.seed0, (u64)rng.k);
     }
-    const unsigned int slot = block_append<BLOCK / 64>(B.counts + 0, emit_closest, s_cnt);
-    if (emit_closest) {
-        B.rq_o[nxt][slot] = make_float4(next_o.x, next_o.y, next_o.z, as_f((int)s));
-        B.rq_d[nxt][slot] = make_float4(next_d.x, next_d.y, next_d.z, as_f(next_level | (int)(pending << 8)));
-        B.rq_t[nxt][slot] = make_float4(next_T.x, next_T.y, next_T.z, 0.0f);
+    emit.closest(emit_closest, s, next_o, next_d, next_T, next_level, pending);
+}
+
+// Emitter of k_shade: workgroup-aggregated appends to the global next-round queues.
+template <int BLOCK>
+struct QueueEmit {
+    const WaveBuffers & B;
+    int nxt;
+    unsigned int * s_cnt;
+    PRT_D void shadow(bool want, unsigned int s, f3 o, f3 d, f3 contrib, float w, int kind) const {
+        const unsigned int slot = block_append<BLOCK / 64>(B.counts + 1, want, s_cnt);
+        if (want) {
+            B.sq_o[slot] = make_float4(o.x, o.y, o.z, as_f((int)s));
+            if (kind == WF_KIND_SHADOW_DIST) B.sq_d[slot] = make_float4(d.x, d.y, d.z, 0.0f);
+            B.sq_c[slot] = make_float4(contrib.x, contrib.y, contrib.z, w);      // w >= 0: point light distance^2; < 0: -(light + 1)
+        }
     }
+    PRT_D void closest(bool want, unsigned int s, f3 o, f3 d, f3 T, int level, unsigned int pending) const {
+        const unsigned int slot = block_append<BLOCK / 64>(B.counts + 0, want, s_cnt);
+        if (want) {
+            B.rq_o[nxt][slot] = make_float4(o.x, o.y, o.z, as_f((int)s));
+            B.rq_d[nxt][slot] = make_float4(d.x, d.y, d.z, as_f(level | (int)(pending << 8)));
+            B.rq_t[nxt][slot] = make_float4(T.x, T.y, T.z, 0.0f);
+        }
+    }
+};
+
+// One lane per closest-hit result of queue `cur`; appends to queue `cur ^ 1` and to the shadow queue.
+template <bool RING, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, DevParams P, WaveBuffers B, int cur, unsigned int n_closest,
+                                                 DevCounters * ctr) {
+    __shared__ unsigned int s_cnt[BLOCK / 64 + 1];
+    // Small read-only tables staged in LDS once per workgroup: every dependent global load removed from the
+    // per-hit chain (triangle -> material -> light -> direction table) is a memory round trip less per wave.
+    constexpr int LDS_MATS = 32, LDS_LIGHTS = 4;
+    __shared__ float4 s_diffuse[1024];                         // 16 KB: the Hammersley cosine-lobe directions
+    __shared__ DevMaterial s_mats[LDS_MATS];                    // 2 KB
+    __shared__ DevLight s_lights[LDS_LIGHTS];
+    const bool lds_mats = sc.material_count <= (unsigned int)LDS_MATS;
+    const bool lds_lights = sc.light_count <= (unsigned int)LDS_LIGHTS;
+    for (unsigned int k = threadIdx.x; k < 1024u; k += BLOCK) s_diffuse[k] = sc.diffuse_dirs[k];
+    if (lds_mats) {
+        const float4 * src = reinterpret_cast<const float4 *>(sc.materials);
+        float4 * dst = reinterpret_cast<float4 *>(s_mats);
+        for (unsigned int k = threadIdx.x; k < sc.material_count * 4u; k += BLOCK) dst[k] = src[k];
+    }
+    if (lds_lights) {
+        const float4 * src = reinterpret_cast<const float4 *>(sc.lights);
+        float4 * dst = reinterpret_cast<float4 *>(s_lights);
+        for (unsigned int k = threadIdx.x; k < sc.light_count * 3u; k += BLOCK) dst[k] = src[k];
+    }
+    __syncthreads();
+    ShadeTables tb;
+    tb.diffuse = s_diffuse;
+    tb.materials = lds_mats ? s_mats : sc.materials;
+    tb.lights = lds_lights ? s_lights : sc.lights;
+
+    const unsigned int i = blockIdx.x * BLOCK + threadIdx.x;
+    const bool live = i < n_closest;
+    unsigned int s = 0;
+    int level = 0;
+    unsigned int pending = 0;
+    f3 ray_o = mk3(0, 0, 0), ray_d = mk3(0, 0, 1), T = mk3(0, 0, 0);
+    HitRec hit;
+    hit.t = 0.0f; hit.v = hit.w = 0.0f; hit.tri = -1;
+    if (live) {
+        const float4 ro = B.rq_o[cur][i], rd = B.rq_d[cur][i], rt = B.rq_t[cur][i], h = B.hits[i];
+        s = (unsigned int)as_i(ro.w);
+        level = as_i(rd.w) & 0xFF;
+        pending = ((unsigned int)as_i(rd.w)) >> 8;
+        ray_o = mk3(ro.x, ro.y, ro.z);
+        ray_d = mk3(rd.x, rd.y, rd.z);
+        T = mk3(rt.x, rt.y, rt.z);
+        hit.t = h.x; hit.v = h.y; hit.w = h.z; hit.tri = as_i(h.w);
+    }
+    QueueEmit<BLOCK> emit = { B, cur ^ 1, s_cnt };
+    unsigned int shaded = 0;
+    shade_entry<RING>(sc, P, B, tb, live, s, level, pending, ray_o, ray_d, T, hit, emit, shaded);
+
     // shaded-hit count: one atomic per workgroup
     {
         const unsigned int n = (unsigned int)__popcll(__ballot(shaded != 0));

@@ -21,6 +21,7 @@
 #include "kernels_mega.h"
 #include "kernels_wave.h"
 #include "kernels_persist.h"
+#include "kernels_pool.h"
 #include "kernels_debug.h"
 
 using namespace prt;
@@ -105,7 +106,8 @@ struct prt_ctx {
         hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr, ev_done = nullptr, ev_first = nullptr;
         unsigned int * host_counts = nullptr;   // pinned
     } chain[PRT_MAX_CHAINS];
-    DevBuf<unsigned int> wf_counts;       // persistent pipeline's sample counter
+    DevBuf<unsigned int> wf_counts;       // persistent / pool pipelines' sample counter
+    DevBuf<float4> pool_f4;               // pool pipeline: the waves' private ray lists
     int cu_count = 0;
     unsigned int stack_bound = 0;
     DevBuf<int> stack_spill;
@@ -448,6 +450,76 @@ int render_wavefront(prt_ctx * ctx, const DevCamera & cam, const DevParams & P, 
     return 0;
 }
 
+// The wave-pool pipeline (kernels_pool.h): one launch; per-sample arrays as in the wavefront pipeline (chain 0's
+// workspace, without the global queues), plus cap (+ cap * lights shadow) ray slots per resident wave.
+template <int BLOCK, int WAVES, bool LDSTAB, bool RING>
+int launch_pool(prt_ctx * ctx, bool count, const DevCamera & cam, DevParams P, unsigned int n_samples, unsigned int stack_entries) {
+    const size_t lds = (size_t)stack_entries * BLOCK * sizeof(int);
+    int per_cu = 0;
+    hipError_t oe = count ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_pool<BLOCK, WAVES, LDSTAB, RING, true>, BLOCK, lds)
+                          : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_pool<BLOCK, WAVES, LDSTAB, RING, false>, BLOCK, lds);
+    if (oe != hipSuccess || per_cu < 1) per_cu = 1;
+    per_cu = std::min(per_cu, 8);
+    if (const char * e = getenv("PRT_POOL_BLOCKS_PER_CU")) per_cu = std::max(1, std::min(per_cu, atoi(e)));
+    if (getenv("PRT_DEBUG_UTIL")) fprintf(stderr, "[prt] k_pool<%d,%d,%d>: %d blocks per CU\n", BLOCK, WAVES, (int)LDSTAB, per_cu);
+    const unsigned int max_blocks = (unsigned int)per_cu * (unsigned int)ctx->cu_count;
+    const unsigned int grid = std::max(1u, std::min(max_blocks, (n_samples + BLOCK - 1) / BLOCK));
+    const unsigned int waves = grid * (BLOCK / 64);
+    // slots per wave: half of a wave's fair share of the samples (measured on C4 shards: larger pools leave the
+    // waves unbalanced when the sample counter runs out, smaller ones trace at low lane utilisation); whole
+    // waves, 64..512
+    unsigned int cap = (n_samples / waves / 2u + 63u) / 64u * 64u;
+    cap = std::max(64u, std::min(512u, cap));
+    if (const char * e = getenv("PRT_POOL_CAP")) cap = (unsigned int)std::max(64, std::min(4096, atoi(e) / 64 * 64));
+    const unsigned int n_lights = std::max(1u, ctx->scene.light_count);
+    const unsigned int scap = cap * n_lights;
+
+    prt_ctx::ChainWs & w = ctx->chain[0];
+    const size_t N = n_samples;
+    const unsigned int levels = std::max(1u, P.bounce_depth);
+    const unsigned int fr4 = RING ? 5u : 4u;
+    HIP_TRY(ctx, w.f4.ensure((size_t)levels * fr4 * N));
+    HIP_TRY(ctx, w.rng.ensure(RING ? 2 * N : N));
+    HIP_TRY(ctx, ctx->pool_f4.ensure((size_t)waves * (7u * (size_t)cap + 3u * (size_t)scap)));
+    HIP_TRY(ctx, ctx->wf_counts.ensure(16));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->wf_counts.p, 0, 16, ctx->stream));
+    if (ctx->stack_bound > stack_entries) {
+        const size_t lanes = (size_t)grid * BLOCK;
+        HIP_TRY(ctx, ctx->stack_spill.ensure((size_t)ctx->stack_bound * lanes));
+        P.stack_spill = ctx->stack_spill.p;
+        P.stack_spill_stride = (unsigned int)lanes;
+    }
+    WaveBuffers B;
+    memset(&B, 0, sizeof(B));
+    B.n_samples = n_samples;
+    B.sample_base = 0;
+    B.accum = ctx->sample_rgb.p;
+    B.rng = w.rng.p;
+    B.rng_aux = RING ? w.rng.p + N : nullptr;
+    B.ring = RING ? ctx->ring_ws.p : nullptr;
+    B.frames = w.f4.p;
+    PoolBuffers Q;
+    Q.cq = ctx->pool_f4.p;
+    Q.hits = Q.cq + (size_t)waves * 6u * cap;
+    Q.sq = Q.hits + (size_t)waves * cap;
+    Q.head = ctx->wf_counts.p;
+    Q.cap = cap;
+    Q.scap = scap;
+    Q.topup_min = std::max(64u, cap / 4u);
+    if (const char * e = getenv("PRT_POOL_TOPUP")) Q.topup_min = (unsigned int)std::max(1, std::min((int)cap, atoi(e)));
+    int keep_min = 40, node_min = 32;
+    if (const char * e = getenv("PRT_KEEP_MIN")) keep_min = std::max(1, std::min(64, atoi(e)));
+    if (const char * e = getenv("PRT_NODE_MIN")) node_min = std::max(0, std::min(64, atoi(e)));
+    const int multi_light = ctx->scene.light_count > 1 ? 1 : 0;
+    if (count)
+        hipLaunchKernelGGL((k_pool<BLOCK, WAVES, LDSTAB, RING, true>), dim3(grid), dim3(BLOCK), lds, ctx->stream, ctx->scene, cam, P, B, Q, keep_min, node_min,
+                           multi_light, ctx->counters.p);
+    else
+        hipLaunchKernelGGL((k_pool<BLOCK, WAVES, LDSTAB, RING, false>), dim3(grid), dim3(BLOCK), lds, ctx->stream, ctx->scene, cam, P, B, Q, keep_min, node_min,
+                           multi_light, ctx->counters.p);
+    return 0;
+}
+
 // Renders the pixel set into d_out (device, float4 per pixel, packed in local pixel order).  Synchronous.
 int render_pixels(prt_ctx * ctx, const prt_camera * cam_in, const prt_params * params, uint32_t width, uint32_t height,
                   const PixelSet & px, float4 * d_out, prt_counters * counters) {
@@ -516,8 +588,16 @@ int render_pixels(prt_ctx * ctx, const prt_camera * cam_in, const prt_params * p
     P.stack_spill_stride = 0;
 
     unsigned int pipeline = params->pipeline & PRT_PIPELINE_MASK;
-    if (pipeline == PRT_PIPELINE_DEFAULT) pipeline = PRT_PIPELINE_WAVEFRONT;
-    if (pipeline != PRT_PIPELINE_MEGAKERNEL && pipeline != PRT_PIPELINE_WAVEFRONT && pipeline != PRT_PIPELINE_PERSISTENT) { ctx->error = "prt_render: unknown pipeline"; return -1; }
+    if (pipeline == PRT_PIPELINE_DEFAULT) {
+        // Measured on MI355X (tools/pool_cross.py, tools/pool_scene_cross.py): the wavefront pipeline's steady state is
+        // ~15 % faster (its k_trace runs 6 waves per SIMD, k_pool 4), but each of its ~8 rounds costs a launch ramp, a
+        // drain tail and a host round trip, ~1 ms per frame in total.  Below ~5 M samples (a quarter of 1080p x 8 spp,
+        // i.e. every shard of a 4..8 GPU run) the single-launch pool pipeline wins, by up to 2x on small frames.
+        unsigned long long pool_max = 5000000ull;
+        if (const char * e = getenv("PRT_POOL_MAX_SAMPLES")) pool_max = strtoull(e, nullptr, 10);
+        pipeline = (unsigned long long)px.n_pixels * params->spp <= pool_max ? PRT_PIPELINE_POOL : PRT_PIPELINE_WAVEFRONT;
+    }
+    if (pipeline != PRT_PIPELINE_MEGAKERNEL && pipeline != PRT_PIPELINE_WAVEFRONT && pipeline != PRT_PIPELINE_PERSISTENT && pipeline != PRT_PIPELINE_POOL) { ctx->error = "prt_render: unknown pipeline"; return -1; }
 
     {
         const unsigned int spill_entries = ctx->stack_bound;        // the slow stack holds the whole bound
@@ -569,6 +649,18 @@ int render_pixels(prt_ctx * ctx, const prt_camera * cam_in, const prt_params * p
         hipLaunchKernelGGL(k_resolve, dim3((px.n_pixels + 255) / 256), dim3(256), 0, stream, ctx->sample_rgb.p, d_out, px.n_pixels, P.spp);
         HIP_TRY(ctx, hipGetLastError());
         launches = 1;
+    } else if (n_samples && pipeline == PRT_PIPELINE_POOL) {
+        HIP_TRY(ctx, hipEventRecord(ctx->ev[2], stream));
+        // 512-thread blocks, 4 waves per SIMD (128 VGPRs), direction table in LDS.  Measured alternatives: 5 waves
+        // (96 VGPRs, 93 dwords spilled) 24.2 ms and 6 waves (80 VGPRs, 154 spilled) 29.5 ms against 17.3 ms on a C4 frame.
+        int rc = ring ? launch_pool<512, 4, true, true>(ctx, count_visits, cam, P, n_samples, stack_entries)
+                      : launch_pool<512, 4, true, false>(ctx, count_visits, cam, P, n_samples, stack_entries);
+        if (rc) return rc;
+        HIP_TRY(ctx, hipGetLastError());
+        HIP_TRY(ctx, hipEventRecord(ctx->ev[3], stream));
+        hipLaunchKernelGGL(k_resolve, dim3((px.n_pixels + 255) / 256), dim3(256), 0, stream, ctx->sample_rgb.p, d_out, px.n_pixels, P.spp);
+        HIP_TRY(ctx, hipGetLastError());
+        launches = 1;
     } else if (n_samples) {
         int rc = render_wavefront(ctx, cam, P, ring, count_visits, n_samples, lds, &host_ray_count, &trace_ms_accum, &launches);
         if (rc) return rc;
@@ -583,7 +675,7 @@ int render_pixels(prt_ctx * ctx, const prt_camera * cam_in, const prt_params * p
         HIP_TRY(ctx, hipMemcpy(&h, ctx->counters.p, sizeof(h), hipMemcpyDeviceToHost));
         float ms = 0.0f, trace_ms = 0.0f;
         HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
-        if (pipeline == PRT_PIPELINE_MEGAKERNEL || pipeline == PRT_PIPELINE_PERSISTENT) {
+        if (pipeline != PRT_PIPELINE_WAVEFRONT) {
             if (launches) HIP_TRY(ctx, hipEventElapsedTime(&trace_ms, ctx->ev[2], ctx->ev[3]));
         } else {
             trace_ms = trace_ms_accum;
@@ -608,6 +700,7 @@ int render_pixels(prt_ctx * ctx, const prt_camera * cam_in, const prt_params * p
         counters->render_ms = ms;
         counters->trace_kernel_ms = trace_ms;
         counters->trace_kernel_launches = launches;
+        counters->pipeline = pipeline;
     }
     return 0;
 }
@@ -671,7 +764,7 @@ void prt_destroy(prt_ctx * ctx) {
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     ctx->nodes.release(); ctx->tris.release(); ctx->shade.release(); ctx->diffuse_dirs.release(); ctx->spec_dirs.release();
     ctx->tri_rank.release(); ctx->materials.release(); ctx->lights.release();
-    ctx->sample_rgb.release(); ctx->frame_out.release(); ctx->counters.release(); ctx->ring_ws.release(); ctx->pixel_list.release(); ctx->wf_counts.release(); ctx->stack_spill.release();
+    ctx->sample_rgb.release(); ctx->frame_out.release(); ctx->counters.release(); ctx->ring_ws.release(); ctx->pixel_list.release(); ctx->wf_counts.release(); ctx->stack_spill.release(); ctx->pool_f4.release();
     for (int c = 0; c < PRT_MAX_CHAINS; ++c) {
         prt_ctx::ChainWs & w = ctx->chain[c];
         w.f4.release(); w.rng.release(); w.counts.release(); w.overflow.release(); w.slow_stack.release();

@@ -88,6 +88,7 @@ int RenderFlat(const void * cache_key, const prt_scene_desc * desc, const prt_ca
         if (ctr[(size_t)g].render_ms > sum.render_ms) sum.render_ms = ctr[(size_t)g].render_ms;          // GPUs run concurrently
         if (ctr[(size_t)g].trace_kernel_ms > sum.trace_kernel_ms) sum.trace_kernel_ms = ctr[(size_t)g].trace_kernel_ms;
         sum.trace_kernel_launches += ctr[(size_t)g].trace_kernel_launches;
+        sum.pipeline = ctr[(size_t)g].pipeline;
     }
     if (total) *total = sum;
     return 0;

@@ -28,7 +28,7 @@ def _render_fixture(gpu_renderer_factory, name, pipeline=0):
     return g, img, ctr
 
 
-PIPELINES = {"megakernel": 1, "wavefront": 2, "persistent": 3}
+PIPELINES = {"megakernel": 1, "wavefront": 2, "persistent": 3, "pool": 4}
 
 
 @pytest.mark.parametrize("pipeline", sorted(PIPELINES))
@@ -105,6 +105,23 @@ def test_counting_variant_same_pixels(gpu_renderer_factory):
     b, cb = r.render(cam, p2, w, h)
     assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
     assert ca.ray_count == cb.ray_count and cb.node_visits > 0 and cb.tri_tests > 0 and ca.node_visits == 0
+
+
+def test_default_pipeline_picks_by_size_and_both_agree(gpu_renderer_factory, monkeypatch):
+    """PRT_PIPELINE_DEFAULT: the single-launch pool pipeline for small calls, the wavefront pipeline for large ones
+    (prt_counters.pipeline says which ran); single-light scenes come out bit-identical either way."""
+    g = load_golden("terrain64_d3")
+    r = gpu_renderer_factory(str(g["scene"]), 0)
+    w, h = int(g["width"]), int(g["height"])
+    cam, p = camera_and_params(g)
+    a, ca = r.render(cam, p, w, h)
+    assert ca.pipeline == PIPELINES["pool"]
+    monkeypatch.setenv("PRT_POOL_MAX_SAMPLES", "0")
+    b, cb = r.render(cam, p, w, h)
+    monkeypatch.delenv("PRT_POOL_MAX_SAMPLES")
+    assert cb.pipeline == PIPELINES["wavefront"]
+    assert ca.ray_count == cb.ray_count == int(g["ray_count"])
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
 
 
 @pytest.mark.parametrize("pipeline", sorted(PIPELINES))
