@@ -92,9 +92,11 @@ struct DevParams {
     // traversal stack: LDS entries per lane, then a global spill column per lane (dev_trace.h TravStack)
     int * stack_spill;
     unsigned int stack_lds_entries, stack_spill_stride;
+    unsigned int local_base;                    // large calls run in passes of bounded workspace (prt_api.hip render_pixels)
 };
 
 PRT_HD unsigned int pixel_of_local(const DevParams & P, unsigned int lp) {
+    lp += P.local_base;                         // this pass's first pixel within the call's pixel set
     if (P.pixel_list) return P.pixel_list[lp];
     if (P.shard_nranks <= 1) return P.first_pixel + lp;
     const unsigned int row = lp / P.width, x = lp - row * P.width;

@@ -568,12 +568,46 @@ int render_pixels(prt_ctx * ctx, const prt_camera * cam_in, const prt_params * p
     const bool ring = ctx->any_translucent || max_rng_draws(P.bounce_depth, P.reflection_samples, P.spec_samples) > 15;
     const int levels = (int)P.bounce_depth + 1;
 
-    const size_t n_samples64 = (size_t)px.n_pixels * P.spp;
-    if (n_samples64 > 0x7FFFFFFFull) { ctx->error = "prt_render: more than 2^31 samples in one call; split the pixel range"; return -1; }
-    const unsigned int n_samples = (unsigned int)n_samples64;
+    unsigned int pipeline = params->pipeline & PRT_PIPELINE_MASK;
+    if (pipeline == PRT_PIPELINE_DEFAULT) {
+        // Measured on MI355X (tools/pool_cross.py, tools/pool_scene_cross.py): the wavefront pipeline's steady state is
+        // ~15 % faster (its k_trace runs 6 waves per SIMD, k_pool 4), but each of its ~8 rounds costs a launch ramp, a
+        // drain tail and a host round trip, ~1 ms per frame in total.  Below ~5 M samples (a quarter of 1080p x 8 spp,
+        // i.e. every shard of a 4..8 GPU run) the single-launch pool pipeline wins, by up to 2x on small frames.
+        unsigned long long pool_max = 5000000ull;
+        if (const char * e = getenv("PRT_POOL_MAX_SAMPLES")) pool_max = strtoull(e, nullptr, 10);
+        pipeline = (unsigned long long)px.n_pixels * params->spp <= pool_max ? PRT_PIPELINE_POOL : PRT_PIPELINE_WAVEFRONT;
+    }
+    if (pipeline != PRT_PIPELINE_MEGAKERNEL && pipeline != PRT_PIPELINE_WAVEFRONT && pipeline != PRT_PIPELINE_PERSISTENT && pipeline != PRT_PIPELINE_POOL) { ctx->error = "prt_render: unknown pipeline"; return -1; }
+
+    // Passes.  The per-sample workspace (radiance, RNG, pending frames, ray queues) is 100 B .. 1 KB per sample, so a
+    // 4K x 64 spp frame (530 M samples) does not fit any GPU in one piece: the call's pixel set is rendered in passes of
+    // whole pixels, each at most 64 M samples and at most 64 GB of workspace (PRT_PASS_SAMPLES / PRT_PASS_MB override).
+    // One pass for everything up to 4K x 8 spp.
+    const unsigned long long total_samples = (unsigned long long)px.n_pixels * P.spp;
+    unsigned int pass_pixels = px.n_pixels;
+    {
+        const unsigned long long lv = std::max(1u, P.bounce_depth), fr4 = ring ? 5 : 4, nl = std::max(1u, ctx->scene.light_count);
+        unsigned long long per_sample = 16 + (ring && pipeline != PRT_PIPELINE_PERSISTENT ? 128 : 0);
+        if (pipeline == PRT_PIPELINE_WAVEFRONT) per_sample += (lv * fr4 + 7 + 3 * nl) * 16 + (ring ? 32 : 16) + 4 * (1 + nl);
+        if (pipeline == PRT_PIPELINE_POOL) per_sample += lv * fr4 * 16 + (ring ? 32 : 16);
+        if (pipeline == PRT_PIPELINE_MEGAKERNEL && ctx->stack_bound > 24) per_sample += 4ull * ctx->stack_bound;
+        unsigned long long max_samples = 64ull << 20, max_mb = 64ull << 10;
+        if (const char * e = getenv("PRT_PASS_SAMPLES")) max_samples = std::max(1ull, strtoull(e, nullptr, 10));
+        if (const char * e = getenv("PRT_PASS_MB")) max_mb = std::max(1ull, strtoull(e, nullptr, 10));
+        max_samples = std::min(max_samples, std::max(1ull, (max_mb << 20) / per_sample));
+        max_samples = std::min(max_samples, 0x7FFFFFFFull);
+        if (total_samples > max_samples) {
+            unsigned long long pp = std::max(1ull, max_samples / P.spp);
+            if (pp > 64) pp = pp / 64 * 64;                                 // passes start on a wave boundary
+            pass_pixels = (unsigned int)std::min<unsigned long long>(pp, px.n_pixels);
+        }
+    }
+    const size_t n_samples64 = (size_t)pass_pixels * P.spp;                 // samples of the largest pass
+    if (n_samples64 > 0x7FFFFFFFull) { ctx->error = "prt_render: spp too large for one pixel per pass"; return -1; }
     HIP_TRY(ctx, ctx->sample_rgb.ensure(n_samples64));
     HIP_TRY(ctx, ctx->counters.ensure(1));
-    if (ring && (params->pipeline & PRT_PIPELINE_MASK) != PRT_PIPELINE_PERSISTENT) HIP_TRY(ctx, ctx->ring_ws.ensure(n_samples64 * 16));
+    if (ring && pipeline != PRT_PIPELINE_PERSISTENT) HIP_TRY(ctx, ctx->ring_ws.ensure(n_samples64 * 16));
 
     // Traversal stack: LDS column of up to STACK_LDS_CAP entries per lane (occupancy); rays that would need more
     // - 3 pushes per 4-wide level are possible, nothing real comes close - are re-traced on a full-height global
@@ -587,17 +621,6 @@ int render_pixels(prt_ctx * ctx, const prt_camera * cam_in, const prt_params * p
     P.stack_spill = nullptr;
     P.stack_spill_stride = 0;
 
-    unsigned int pipeline = params->pipeline & PRT_PIPELINE_MASK;
-    if (pipeline == PRT_PIPELINE_DEFAULT) {
-        // Measured on MI355X (tools/pool_cross.py, tools/pool_scene_cross.py): the wavefront pipeline's steady state is
-        // ~15 % faster (its k_trace runs 6 waves per SIMD, k_pool 4), but each of its ~8 rounds costs a launch ramp, a
-        // drain tail and a host round trip, ~1 ms per frame in total.  Below ~5 M samples (a quarter of 1080p x 8 spp,
-        // i.e. every shard of a 4..8 GPU run) the single-launch pool pipeline wins, by up to 2x on small frames.
-        unsigned long long pool_max = 5000000ull;
-        if (const char * e = getenv("PRT_POOL_MAX_SAMPLES")) pool_max = strtoull(e, nullptr, 10);
-        pipeline = (unsigned long long)px.n_pixels * params->spp <= pool_max ? PRT_PIPELINE_POOL : PRT_PIPELINE_WAVEFRONT;
-    }
-    if (pipeline != PRT_PIPELINE_MEGAKERNEL && pipeline != PRT_PIPELINE_WAVEFRONT && pipeline != PRT_PIPELINE_PERSISTENT && pipeline != PRT_PIPELINE_POOL) { ctx->error = "prt_render: unknown pipeline"; return -1; }
 
     {
         const unsigned int spill_entries = ctx->stack_bound;        // the slow stack holds the whole bound
@@ -619,53 +642,59 @@ int render_pixels(prt_ctx * ctx, const prt_camera * cam_in, const prt_params * p
     unsigned int launches = 0;
     unsigned long long host_ray_count = 0;
     float trace_ms_accum = 0.0f;
-    if (n_samples && pipeline == PRT_PIPELINE_MEGAKERNEL) {
-        const unsigned int grid = (n_samples + BLOCK - 1) / BLOCK;
-        HIP_TRY(ctx, hipEventRecord(ctx->ev[2], stream));
-        if (!ring && levels <= 3) launch_mega<3, false>(ctx, count_visits, grid, lds, cam, P, n_samples);
-        else if (levels <= 9) launch_mega<9, true>(ctx, count_visits, grid, lds, cam, P, n_samples);
-        else launch_mega<17, true>(ctx, count_visits, grid, lds, cam, P, n_samples);
-        HIP_TRY(ctx, hipGetLastError());
-        HIP_TRY(ctx, hipEventRecord(ctx->ev[3], stream));
-        hipLaunchKernelGGL(k_resolve, dim3((px.n_pixels + 255) / 256), dim3(256), 0, stream, ctx->sample_rgb.p, d_out, px.n_pixels, P.spp);
-        HIP_TRY(ctx, hipGetLastError());
-        launches = 1;
-    } else if (n_samples && pipeline == PRT_PIPELINE_PERSISTENT) {
-        HIP_TRY(ctx, ctx->wf_counts.ensure(16));
-        HIP_TRY(ctx, hipMemsetAsync(ctx->wf_counts.p, 0, 16, stream));
-        int keep_min = 40, node_min = 32;
-        if (const char * e = getenv("PRT_KEEP_MIN")) keep_min = std::max(1, std::min(64, atoi(e)));
-        if (const char * e = getenv("PRT_NODE_MIN")) node_min = std::max(0, std::min(64, atoi(e)));
-        int blocks_cap = 8;
-        if (const char * e = getenv("PRT_TRACE_BLOCKS_PER_CU")) blocks_cap = std::max(1, std::min(8, atoi(e)));
-        HIP_TRY(ctx, hipEventRecord(ctx->ev[2], stream));
+    const bool single_launch = pipeline != PRT_PIPELINE_WAVEFRONT;
+    for (unsigned int p0 = 0; p0 < px.n_pixels; p0 += pass_pixels) {
+        const unsigned int n_px = std::min(pass_pixels, px.n_pixels - p0);
+        const unsigned int n_samples = n_px * P.spp;
+        const bool last_pass = p0 + n_px == px.n_pixels;
+        P.local_base = p0;
+        if (single_launch) HIP_TRY(ctx, hipEventRecord(ctx->ev[2], stream));
         int rc = 0;
-        if (!ring && levels <= 3) rc = launch_persistent<3, false>(ctx, count_visits, lds, cam, P, n_samples, keep_min, node_min, blocks_cap);
-        else if (levels <= 9) rc = launch_persistent<9, true>(ctx, count_visits, lds, cam, P, n_samples, keep_min, node_min, blocks_cap);
-        else rc = launch_persistent<17, true>(ctx, count_visits, lds, cam, P, n_samples, keep_min, node_min, blocks_cap);
-        if (rc) return rc;
-        HIP_TRY(ctx, hipGetLastError());
-        HIP_TRY(ctx, hipEventRecord(ctx->ev[3], stream));
-        hipLaunchKernelGGL(k_resolve, dim3((px.n_pixels + 255) / 256), dim3(256), 0, stream, ctx->sample_rgb.p, d_out, px.n_pixels, P.spp);
-        HIP_TRY(ctx, hipGetLastError());
-        launches = 1;
-    } else if (n_samples && pipeline == PRT_PIPELINE_POOL) {
-        HIP_TRY(ctx, hipEventRecord(ctx->ev[2], stream));
-        // 512-thread blocks, 4 waves per SIMD (128 VGPRs), direction table in LDS.  Measured alternatives: 5 waves
-        // (96 VGPRs, 93 dwords spilled) 24.2 ms and 6 waves (80 VGPRs, 154 spilled) 29.5 ms against 17.3 ms on a C4 frame.
-        int rc = ring ? launch_pool<512, 4, true, true>(ctx, count_visits, cam, P, n_samples, stack_entries)
+        if (pipeline == PRT_PIPELINE_MEGAKERNEL) {
+            const unsigned int grid = (n_samples + BLOCK - 1) / BLOCK;
+            if (!ring && levels <= 3) launch_mega<3, false>(ctx, count_visits, grid, lds, cam, P, n_samples);
+            else if (levels <= 9) launch_mega<9, true>(ctx, count_visits, grid, lds, cam, P, n_samples);
+            else launch_mega<17, true>(ctx, count_visits, grid, lds, cam, P, n_samples);
+            launches += 1;
+        } else if (pipeline == PRT_PIPELINE_PERSISTENT) {
+            HIP_TRY(ctx, ctx->wf_counts.ensure(16));
+            HIP_TRY(ctx, hipMemsetAsync(ctx->wf_counts.p, 0, 16, stream));
+            int keep_min = 40, node_min = 32;
+            if (const char * e = getenv("PRT_KEEP_MIN")) keep_min = std::max(1, std::min(64, atoi(e)));
+            if (const char * e = getenv("PRT_NODE_MIN")) node_min = std::max(0, std::min(64, atoi(e)));
+            int blocks_cap = 8;
+            if (const char * e = getenv("PRT_TRACE_BLOCKS_PER_CU")) blocks_cap = std::max(1, std::min(8, atoi(e)));
+            if (!ring && levels <= 3) rc = launch_persistent<3, false>(ctx, count_visits, lds, cam, P, n_samples, keep_min, node_min, blocks_cap);
+            else if (levels <= 9) rc = launch_persistent<9, true>(ctx, count_visits, lds, cam, P, n_samples, keep_min, node_min, blocks_cap);
+            else rc = launch_persistent<17, true>(ctx, count_visits, lds, cam, P, n_samples, keep_min, node_min, blocks_cap);
+            launches += 1;
+        } else if (pipeline == PRT_PIPELINE_POOL) {
+            // 512-thread blocks, 4 waves per SIMD (128 VGPRs), direction table in LDS.  Measured alternatives: 5 waves
+            // (96 VGPRs, 93 dwords spilled) 24.2 ms and 6 waves (80 VGPRs, 154 spilled) 29.5 ms against 17.3 ms on a C4 frame.
+            rc = ring ? launch_pool<512, 4, true, true>(ctx, count_visits, cam, P, n_samples, stack_entries)
                       : launch_pool<512, 4, true, false>(ctx, count_visits, cam, P, n_samples, stack_entries);
+            launches += 1;
+        } else {
+            unsigned long long rays = 0;
+            float tms = 0.0f;
+            unsigned int nl = 0;
+            rc = render_wavefront(ctx, cam, P, ring, count_visits, n_samples, lds, &rays, &tms, &nl);
+            host_ray_count += rays;
+            trace_ms_accum += tms;
+            launches += nl;
+        }
         if (rc) return rc;
         HIP_TRY(ctx, hipGetLastError());
-        HIP_TRY(ctx, hipEventRecord(ctx->ev[3], stream));
-        hipLaunchKernelGGL(k_resolve, dim3((px.n_pixels + 255) / 256), dim3(256), 0, stream, ctx->sample_rgb.p, d_out, px.n_pixels, P.spp);
+        if (single_launch) HIP_TRY(ctx, hipEventRecord(ctx->ev[3], stream));
+        hipLaunchKernelGGL(k_resolve, dim3((n_px + 255) / 256), dim3(256), 0, stream, ctx->sample_rgb.p, d_out + p0, n_px, P.spp);
         HIP_TRY(ctx, hipGetLastError());
-        launches = 1;
-    } else if (n_samples) {
-        int rc = render_wavefront(ctx, cam, P, ring, count_visits, n_samples, lds, &host_ray_count, &trace_ms_accum, &launches);
-        if (rc) return rc;
-        hipLaunchKernelGGL(k_resolve, dim3((px.n_pixels + 255) / 256), dim3(256), 0, stream, ctx->sample_rgb.p, d_out, px.n_pixels, P.spp);
-        HIP_TRY(ctx, hipGetLastError());
+        if (single_launch && (counters || !last_pass)) {
+            // the next pass reuses ev[2] / ev[3] (and the workspace is stream ordered anyway): take this pass's time now
+            float tms = 0.0f;
+            HIP_TRY(ctx, hipEventSynchronize(ctx->ev[3]));
+            HIP_TRY(ctx, hipEventElapsedTime(&tms, ctx->ev[2], ctx->ev[3]));
+            trace_ms_accum += tms;
+        }
     }
     HIP_TRY(ctx, hipEventRecord(ctx->ev[1], stream));
     HIP_TRY(ctx, hipEventSynchronize(ctx->ev[1]));
@@ -673,15 +702,11 @@ int render_pixels(prt_ctx * ctx, const prt_camera * cam_in, const prt_params * p
     if (counters) {
         DevCounters h;
         HIP_TRY(ctx, hipMemcpy(&h, ctx->counters.p, sizeof(h), hipMemcpyDeviceToHost));
-        float ms = 0.0f, trace_ms = 0.0f;
+        float ms = 0.0f;
+        const float trace_ms = trace_ms_accum;
         HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
-        if (pipeline != PRT_PIPELINE_WAVEFRONT) {
-            if (launches) HIP_TRY(ctx, hipEventElapsedTime(&trace_ms, ctx->ev[2], ctx->ev[3]));
-        } else {
-            trace_ms = trace_ms_accum;
-            h.ray_count = host_ray_count;
-        }
-        if (pipeline != PRT_PIPELINE_WAVEFRONT) host_ray_count = h.ray_count;
+        if (pipeline == PRT_PIPELINE_WAVEFRONT) h.ray_count = host_ray_count;      // every queued ray is one TraceRay call
+        else host_ray_count = h.ray_count;
         if (getenv("PRT_DEBUG_UTIL") && h.wave_node_steps)
             fprintf(stderr, "[prt] lane utilisation: node loop %.1f%% (%llu wave steps), triangle tests %.1f%% (%llu wave steps, %llu leaf visits), %llu refills (%.1f rays each)\n",
                     100.0 * (double)h.node_visits / (64.0 * (double)h.wave_node_steps), (unsigned long long)h.wave_node_steps,

@@ -107,6 +107,32 @@ def test_counting_variant_same_pixels(gpu_renderer_factory):
     assert ca.ray_count == cb.ray_count and cb.node_visits > 0 and cb.tri_tests > 0 and ca.node_visits == 0
 
 
+@pytest.mark.parametrize("pipeline", sorted(PIPELINES))
+def test_multi_pass_rendering_is_invisible(gpu_renderer_factory, pipeline, monkeypatch):
+    """Calls whose per-sample workspace would not fit are rendered in passes of whole pixels (4K x 64 spp = 530 M
+    samples needs them); forced here with a tiny pass size: full frame, a row shard and a pixel list must not change."""
+    g = load_golden("terrain64_d3")
+    r = gpu_renderer_factory(str(g["scene"]), 0)
+    cam, p = camera_and_params(g, PIPELINES[pipeline])
+    w, h = int(g["width"]), int(g["height"])
+    px = np.arange(7, w * h, 13, dtype=np.uint32)
+    ref, c_ref = r.render(cam, p, w, h)
+    ref_shard, cs_ref = r.render_shard(cam, p, w, h, 8, 1, 3)
+    ref_px, cp_ref = r.render_pixels(cam, p, w, h, px)
+    monkeypatch.setenv("PRT_PASS_SAMPLES", str(150 * int(p.spp) + 3))
+    got, c_got = r.render(cam, p, w, h)
+    got_shard, cs_got = r.render_shard(cam, p, w, h, 8, 1, 3)
+    got_px, cp_got = r.render_pixels(cam, p, w, h, px)
+    monkeypatch.delenv("PRT_PASS_SAMPLES")
+    assert len(px) > 300, "several passes of 128 pixels each, also for the pixel list"
+    assert np.array_equal(ref.view(np.uint32), got.view(np.uint32)) and c_ref.ray_count == c_got.ray_count
+    assert np.array_equal(ref_shard.view(np.uint32), got_shard.view(np.uint32)) and cs_ref.ray_count == cs_got.ray_count
+    assert np.array_equal(ref_px.view(np.uint32), got_px.view(np.uint32)) and cp_ref.ray_count == cp_got.ray_count
+    assert c_got.shaded_hits == c_ref.shaded_hits
+    if pipeline != "wavefront":
+        assert c_got.trace_kernel_launches > c_ref.trace_kernel_launches == 1
+
+
 def test_default_pipeline_picks_by_size_and_both_agree(gpu_renderer_factory, monkeypatch):
     """PRT_PIPELINE_DEFAULT: the single-launch pool pipeline for small calls, the wavefront pipeline for large ones
     (prt_counters.pipeline says which ran); single-light scenes come out bit-identical either way."""
