@@ -47,6 +47,14 @@ int prt_host_write_image(const float * rgba, uint32_t width, uint32_t height, co
 /* The tone map alone (for byte-level tests): rgba8_out is width*height*4 bytes. */
 float prt_host_tonemap(const float * rgba, uint32_t width, uint32_t height, uint8_t * rgba8_out);
 
+
+/* LoadTexture (obj_parser.cpp:197-213): decodes an image file to `channels` interleaved bytes per pixel, rows top
+ * to bottom - the byte layout texture.cpp:17-51 indexes.  NULL (message via prt_host_last_error) when the file
+ * is missing or in a format the decoder rejects; the reference leaves the material's slot empty then.  The
+ * result is freed with prt_host_free_texture. */
+uint8_t * prt_host_load_texture(const char * filename, uint32_t * size_x, uint32_t * size_y, uint32_t * channels);
+void prt_host_free_texture(uint8_t * texels);
+
 #ifdef __cplusplus
 }
 #endif

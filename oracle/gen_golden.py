@@ -44,6 +44,9 @@ FIXTURES = {
     "icosphere_l3_two_lights": dict(scene="icosphere_l3", width=64, height=48, spp=2, lattice=1, light_mode=1),
     "terrain64_d3": dict(scene="terrain_64", width=80, height=60, spp=2, lattice=1, depth=3),
     "terrain192_d2": dict(scene="terrain_192", width=160, height=90, spp=4, lattice=1),
+    # row N1: texture / alpha / bump path (14 texture files in 9 encodings; alpha holes, translucency, bump frames)
+    "gallery_160x120": dict(scene="textured_gallery", width=160, height=120, spp=4, lattice=1),
+    "gallery_two_lights_d4": dict(scene="textured_gallery", width=96, height=72, spp=2, lattice=1, depth=4, light_mode=1, rs=2, ss=2),
 }
 
 
@@ -83,7 +86,12 @@ def generate(name: str, cfg: dict, scene_cache: dict) -> None:
         out["sphere_group"] = np.frombuffer(sc["sphere_group"], dtype=np.int32).copy()
         out["group_index_counts"] = np.frombuffer(sc["group_index_counts"], dtype=np.uint32).copy()
         # loader check without storing the whole mesh: exact byte sums of what the reference parsed
-        for k in ("positions", "texcoords", "normals", "idx_positions", "idx_texcoords", "idx_normals", "group_materials"):
+        if len(sc.get("group_texture_bytes", b"")):
+            out["group_texture_dims"] = np.frombuffer(sc["group_texture_dims"], dtype=np.uint32).copy()
+        for k in ("positions", "texcoords", "normals", "idx_positions", "idx_texcoords", "idx_normals", "group_materials",
+                  "tangents", "group_texture_bytes"):
+            if k not in sc:
+                continue
             a = np.frombuffer(sc[k], dtype=np.uint8)
             out["sum_" + k] = np.array([a.size, int(a.astype(np.uint64).sum()),
                                         int((a.astype(np.uint64) * (np.arange(a.size, dtype=np.uint64) % 251 + 1)).sum() % (1 << 62))],

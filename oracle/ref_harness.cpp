@@ -278,6 +278,26 @@ void DumpScene(const char * path, Mesh * mesh, BoundingHierarchy * h, Scene * sc
         names += mg->name ? mg->name : "";
         names += "\n";
     }
+    // texture slots of every group's material as the reference decoded them: (size_x, size_y, channels) + texel bytes,
+    // slot order ambient, diffuse, specular, alpha, bump (the bump slot holds the CONVERTED normal map)
+    {
+        std::vector<u32> tex_dims;
+        std::vector<u8> tex_bytes;
+        for (u32 g = 0; g < mesh->groups.size(); ++g) {
+            Material * m = mesh->groups[g].material ? mesh->groups[g].material : scene->default_mat;
+            Texture * slots[5] = { m->ambient_texture, m->diffuse_texture, m->specular_texture, m->alpha_texture, m->bump_texture };
+            for (u32 k = 0; k < 5; ++k) {
+                Texture * t = slots[k];
+                tex_dims.push_back(t ? t->size_x : 0);
+                tex_dims.push_back(t ? t->size_y : 0);
+                tex_dims.push_back(t ? t->channels : 0);
+                if (t) tex_bytes.insert(tex_bytes.end(), t->texels, t->texels + (size_t)t->size_x * t->size_y * t->channels);
+            }
+        }
+        out.PutVec("group_texture_dims", tex_dims);
+        out.PutVec("group_texture_bytes", tex_bytes);
+    }
+    out.Put("tangents", mesh->tangents.empty() ? NULL : &mesh->tangents[0], mesh->tangents.size() * sizeof(Vector3));
     out.PutVec("group_index_counts", group_sizes);
     out.PutVec("idx_positions", idx_p);
     out.PutVec("idx_texcoords", idx_t);

@@ -68,6 +68,21 @@ class HostScene:
                                    list(m.diffuse_color) + list(m.specular_color)
                                    for m in (d.materials[i] for i in range(d.material_count))], dtype=np.float32),
         }
+        out["tangents"] = (f(d.tangents, d.normal_count * 3, np.float32).reshape(-1, 3) if d.tangents
+                           else np.zeros((0, 3), dtype=np.float32))
+        # texture slots per group, in the reference's slot order (ambient, diffuse, specular, alpha, bump)
+        dims, blobs = [], []
+        for g in range(d.group_count):
+            m = d.materials[d.groups[g].material]
+            for slot in (m.ambient_texture, m.diffuse_texture, m.specular_texture, m.alpha_texture, m.bump_texture):
+                if slot < 0:
+                    dims += [0, 0, 0]
+                else:
+                    t = d.textures[slot]
+                    dims += [t.size_x, t.size_y, t.channels]
+                    blobs.append(np.ctypeslib.as_array(t.texels, shape=(t.size_x * t.size_y * t.channels,)).copy())
+        out["group_texture_dims"] = np.array(dims, dtype=np.uint32)
+        out["group_texture_bytes"] = np.concatenate(blobs) if blobs else np.zeros(0, dtype=np.uint8)
         return out
 
     def close(self):

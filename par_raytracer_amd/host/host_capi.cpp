@@ -100,6 +100,22 @@ void prt_host_default_params(uint32_t spp, uint64_t seed, prt_params * out) {
     gParams = saved;
 }
 
+uint8_t * prt_host_load_texture(const char * filename, uint32_t * size_x, uint32_t * size_y, uint32_t * channels) {
+    Texture * t = filename ? LoadTexture(filename) : NULL;
+    if (!t) {
+        gHostError = std::string("prt_host_load_texture: ") + (filename ? TextureLoadError() : "null file name");
+        return NULL;
+    }
+    if (size_x) *size_x = t->size_x;
+    if (size_y) *size_y = t->size_y;
+    if (channels) *channels = t->channels;
+    uint8_t * texels = t->texels;
+    free(t);
+    return texels;
+}
+
+void prt_host_free_texture(uint8_t * texels) { free(texels); }
+
 float prt_host_tonemap(const float * rgba, uint32_t width, uint32_t height, uint8_t * rgba8_out) {
     Framebuffer fb;
     fb.pixels = (Vector4 *)rgba;

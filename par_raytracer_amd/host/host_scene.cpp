@@ -149,7 +149,20 @@ void PopulateSceneObjects(Scene * scene, BoundingHierarchy * h, Mesh * mesh, u32
 
 // -------------------------------------------------------------------------------------------------
 
-static prt_material ToPrtMaterial(const Material * m) {
+// Texture slot -> index into FlatScene::textures (one entry per distinct Texture object), -1 = none.
+static s32 TextureSlot(const Texture * t, std::map<const Texture *, s32> * index, std::vector<prt_texture> * out) {
+    if (!t) return -1;
+    std::map<const Texture *, s32>::iterator it = index->find(t);
+    if (it != index->end()) return it->second;
+    prt_texture pt;
+    pt.size_x = t->size_x; pt.size_y = t->size_y; pt.channels = t->channels; pt.texels = t->texels;
+    s32 slot = (s32)out->size();
+    out->push_back(pt);
+    (*index)[t] = slot;
+    return slot;
+}
+
+static prt_material ToPrtMaterial(const Material * m, std::map<const Texture *, s32> * tex_index, std::vector<prt_texture> * textures) {
     prt_material o;
     memset(&o, 0, sizeof(o));
     o.specular_intensity = m->specular_intensity;
@@ -158,7 +171,11 @@ static prt_material ToPrtMaterial(const Material * m) {
     const Vector4 * src[3] = { &m->ambient_color, &m->diffuse_color, &m->specular_color };
     float * dst[3] = { o.ambient_color, o.diffuse_color, o.specular_color };
     for (int k = 0; k < 3; ++k) { dst[k][0] = src[k]->x; dst[k][1] = src[k]->y; dst[k][2] = src[k]->z; dst[k][3] = src[k]->w; }
-    o.ambient_texture = o.diffuse_texture = o.specular_texture = o.alpha_texture = o.bump_texture = -1;
+    o.ambient_texture = TextureSlot(m->ambient_texture, tex_index, textures);
+    o.diffuse_texture = TextureSlot(m->diffuse_texture, tex_index, textures);
+    o.specular_texture = TextureSlot(m->specular_texture, tex_index, textures);
+    o.alpha_texture = TextureSlot(m->alpha_texture, tex_index, textures);
+    o.bump_texture = TextureSlot(m->bump_texture, tex_index, textures);
     return o;
 }
 
@@ -189,7 +206,8 @@ void FlattenScene(const Scene * scene, FlatScene * out) {
     // materials: 0 = scene default, then every distinct material the object list references, in the
     // order groups appear in the mesh.
     std::map<const Material *, s32> mat_index;
-    out->materials.push_back(ToPrtMaterial(scene->default_mat));
+    std::map<const Texture *, s32> tex_index;
+    out->materials.push_back(ToPrtMaterial(scene->default_mat, &tex_index, &out->textures));
     mat_index[scene->default_mat] = 0;
 
     std::map<const MeshGroup *, s32> group_index;
@@ -198,7 +216,7 @@ void FlattenScene(const Scene * scene, FlatScene * out) {
         const Material * m = mg->material ? mg->material : scene->default_mat;
         if (!mat_index.count(m)) {
             mat_index[m] = (s32)out->materials.size();
-            out->materials.push_back(ToPrtMaterial(m));
+            out->materials.push_back(ToPrtMaterial(m, &tex_index, &out->textures));
         }
         prt_group pg;
         pg.first_index = (u32)out->idx_positions.size();
@@ -246,7 +264,8 @@ void FlattenScene(const Scene * scene, FlatScene * out) {
     d.index_count = (u32)out->idx_positions.size();
     d.groups = out->groups.data();         d.group_count = (u32)out->groups.size();
     d.materials = out->materials.data();   d.material_count = (u32)out->materials.size();
-    d.textures = NULL;                     d.texture_count = 0;
+    d.textures = out->textures.empty() ? NULL : out->textures.data();
+    d.texture_count = (u32)out->textures.size();
     d.lights = out->lights.data();         d.light_count = (u32)out->lights.size();
     d.spheres = out->spheres.data();
     d.sphere_group = out->sphere_group.data();

@@ -1,0 +1,346 @@
+// image_in.cpp - texture image decoders behind LoadTexture (obj_parser.cpp:197-213).
+//
+// The reference decodes textures with a third-party single-header library (lib/stb_image.h, not part of this
+// repository).  This file is a fresh decoder for the formats scenes of this kind ship with; what it must
+// reproduce is that library's OUTPUT CONVENTION for `stbi_load(name, &x, &y, &channels, 0)`, because the hot
+// path indexes the bytes directly (texture.cpp:17-51):
+//   * rows top to bottom, pixels left to right, `channels` interleaved bytes per pixel, channels = what the file
+//     stores (1 grey, 2 grey+alpha, 3 RGB, 4 RGBA); palettes are expanded to RGB (RGBA with a tRNS chunk);
+//   * PNG  8-bit and 16-bit (high byte kept) samples, all five scanline filters, non-interlaced;
+//   * TGA  types 2 / 3 (raw) and 10 / 11 (run-length), 8 / 24 / 32 bits, BGR(A) -> RGB(A), bottom-up files
+//          flipped to top-down;
+//   * BMP  24-bit uncompressed, BGR -> RGB, bottom-up flipped;
+//   * PNM  binary P5 (grey) / P6 (RGB), maxval <= 255.
+// Anything else (JPEG, interlaced PNG, 1/2/4-bit PNG, colour-mapped TGA ...) is reported and the texture slot
+// stays empty, which is how the reference treats a file its decoder rejects (obj_parser.cpp:201-204).
+// tests/test_host_side.py compares the decoded bytes with the reference's on generated files of every kind.
+#include <zlib.h>
+
+#include <cctype>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "prt_scene.h"
+
+namespace {
+
+std::string gImageError;
+
+bool Fail(const char * why) {
+    gImageError = why;
+    return false;
+}
+
+struct Bytes {
+    std::vector<u8> data;
+    bool Read(const char * path) {
+        FILE * f = fopen(path, "rb");
+        if (!f) return Fail("cannot open file");
+        fseek(f, 0, SEEK_END);
+        long n = ftell(f);
+        fseek(f, 0, SEEK_SET);
+        if (n < 0) { fclose(f); return Fail("cannot size file"); }
+        data.resize((size_t)n);
+        size_t got = n ? fread(data.data(), 1, (size_t)n, f) : 0;
+        fclose(f);
+        return got == (size_t)n ? true : Fail("short read");
+    }
+};
+
+u32 Be32(const u8 * p) { return ((u32)p[0] << 24) | ((u32)p[1] << 16) | ((u32)p[2] << 8) | (u32)p[3]; }
+u32 Le16(const u8 * p) { return (u32)p[0] | ((u32)p[1] << 8); }
+u32 Le32(const u8 * p) { return (u32)p[0] | ((u32)p[1] << 8) | ((u32)p[2] << 16) | ((u32)p[3] << 24); }
+
+struct Image {
+    u32 w = 0, h = 0, channels = 0;
+    std::vector<u8> px;
+};
+
+// ---- PNG ------------------------------------------------------------------------------------------------
+int Paeth(int a, int b, int c) {
+    int p = a + b - c;
+    int pa = abs(p - a), pb = abs(p - b), pc = abs(p - c);
+    if (pa <= pb && pa <= pc) return a;
+    if (pb <= pc) return b;
+    return c;
+}
+
+bool DecodePng(const std::vector<u8> & d, Image * out) {
+    static const u8 sig[8] = { 0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A };
+    if (d.size() < 8 || memcmp(d.data(), sig, 8) != 0) return Fail("not a PNG");
+    u32 w = 0, h = 0, depth = 0, ctype = 0, interlace = 0;
+    std::vector<u8> idat, palette, trns;
+    bool have_header = false;
+    size_t pos = 8;
+    while (pos + 12 <= d.size()) {
+        u32 len = Be32(&d[pos]);
+        const u8 * tag = &d[pos + 4];
+        const u8 * body = &d[pos + 8];
+        if (pos + 12 + (size_t)len > d.size()) return Fail("PNG chunk runs past the end of the file");
+        if (!memcmp(tag, "IHDR", 4)) {
+            if (len != 13) return Fail("bad IHDR");
+            w = Be32(body); h = Be32(body + 4); depth = body[8]; ctype = body[9]; interlace = body[12];
+            have_header = true;
+        } else if (!memcmp(tag, "PLTE", 4)) {
+            palette.assign(body, body + len);
+        } else if (!memcmp(tag, "tRNS", 4)) {
+            trns.assign(body, body + len);
+        } else if (!memcmp(tag, "IDAT", 4)) {
+            idat.insert(idat.end(), body, body + len);
+        } else if (!memcmp(tag, "IEND", 4)) {
+            break;
+        }
+        pos += 12 + (size_t)len;
+    }
+    if (!have_header || !w || !h) return Fail("PNG without a header");
+    if (interlace) return Fail("interlaced PNG is not supported");
+    if (depth != 8 && depth != 16) return Fail("PNG bit depth other than 8 / 16 is not supported");
+    u32 file_ch = 0;
+    switch (ctype) {
+        case 0: file_ch = 1; break;
+        case 2: file_ch = 3; break;
+        case 3: file_ch = 1; break;
+        case 4: file_ch = 2; break;
+        case 6: file_ch = 4; break;
+        default: return Fail("bad PNG colour type");
+    }
+    if (ctype == 3 && depth != 8) return Fail("PNG palette index depth other than 8 is not supported");
+    if (ctype != 3 && !trns.empty()) return Fail("PNG colour-key transparency is not supported");
+    const size_t bps = depth / 8;                              // bytes per sample
+    const size_t bpp = bps * file_ch;                          // bytes per pixel in the filtered stream
+    const size_t stride = (size_t)w * bpp;
+    std::vector<u8> raw((stride + 1) * (size_t)h);
+    uLongf raw_len = (uLongf)raw.size();
+    int zr = uncompress(raw.data(), &raw_len, idat.data(), (uLong)idat.size());
+    if (zr != Z_OK || raw_len != raw.size()) return Fail("PNG data does not inflate to the image size");
+    std::vector<u8> img(stride * (size_t)h);
+    for (u32 y = 0; y < h; ++y) {
+        const u8 * src = &raw[(stride + 1) * (size_t)y];
+        u8 * dst = &img[stride * (size_t)y];
+        const u8 * up = y ? dst - stride : NULL;
+        const u8 filter = src[0];
+        ++src;
+        for (size_t i = 0; i < stride; ++i) {
+            int a = i >= bpp ? dst[i - bpp] : 0;
+            int b = up ? up[i] : 0;
+            int c = (up && i >= bpp) ? up[i - bpp] : 0;
+            int v = src[i];
+            switch (filter) {
+                case 0: break;
+                case 1: v += a; break;
+                case 2: v += b; break;
+                case 3: v += (a + b) >> 1; break;
+                case 4: v += Paeth(a, b, c); break;
+                default: return Fail("bad PNG filter");
+            }
+            dst[i] = (u8)v;
+        }
+    }
+    out->w = w;
+    out->h = h;
+    if (ctype == 3) {
+        const bool with_alpha = !trns.empty();
+        out->channels = with_alpha ? 4 : 3;
+        out->px.resize((size_t)w * h * out->channels);
+        for (size_t i = 0; i < (size_t)w * h; ++i) {
+            u32 idx = img[i];
+            u8 * o = &out->px[i * out->channels];
+            for (int k = 0; k < 3; ++k) o[k] = (size_t)idx * 3 + k < palette.size() ? palette[(size_t)idx * 3 + k] : 0;
+            if (with_alpha) o[3] = idx < trns.size() ? trns[idx] : 255;
+        }
+    } else {
+        out->channels = file_ch;
+        out->px.resize((size_t)w * h * file_ch);
+        if (bps == 1) {
+            out->px = img;
+        } else {
+            for (size_t i = 0; i < out->px.size(); ++i) out->px[i] = img[2 * i];      // 16 bit: the high byte
+        }
+    }
+    return true;
+}
+
+// ---- TGA ------------------------------------------------------------------------------------------------
+bool DecodeTga(const std::vector<u8> & d, Image * out) {
+    if (d.size() < 18) return Fail("TGA header truncated");
+    const u32 id_len = d[0], cmap_type = d[1], type = d[2];
+    const u32 w = Le16(&d[12]), h = Le16(&d[14]), bits = d[16], desc = d[17];
+    if (cmap_type != 0) return Fail("colour-mapped TGA is not supported");
+    const bool rle = type == 10 || type == 11;
+    const bool grey = type == 3 || type == 11;
+    if (!(type == 2 || type == 3 || rle)) return Fail("unsupported TGA image type");
+    if (!w || !h) return Fail("empty TGA");
+    if (grey ? bits != 8 : (bits != 24 && bits != 32)) return Fail("unsupported TGA pixel depth");
+    const u32 ch = bits / 8;
+    size_t pos = 18 + (size_t)id_len;
+    std::vector<u8> px((size_t)w * h * ch);
+    const size_t n_px = (size_t)w * h;
+    if (!rle) {
+        if (pos + n_px * ch > d.size()) return Fail("TGA pixel data truncated");
+        memcpy(px.data(), &d[pos], n_px * ch);
+    } else {
+        size_t i = 0;
+        while (i < n_px) {
+            if (pos >= d.size()) return Fail("TGA run-length data truncated");
+            const u32 head = d[pos++];
+            const size_t count = (head & 127u) + 1u;
+            if (i + count > n_px) return Fail("TGA run crosses the end of the image");
+            if (head & 128u) {
+                if (pos + ch > d.size()) return Fail("TGA run-length data truncated");
+                for (size_t k = 0; k < count; ++k) memcpy(&px[(i + k) * ch], &d[pos], ch);
+                pos += ch;
+            } else {
+                if (pos + count * ch > d.size()) return Fail("TGA run-length data truncated");
+                memcpy(&px[i * ch], &d[pos], count * ch);
+                pos += count * ch;
+            }
+            i += count;
+        }
+    }
+    if (ch >= 3) for (size_t i = 0; i < n_px; ++i) std::swap(px[i * ch], px[i * ch + 2]);        // BGR(A) -> RGB(A)
+    const bool top_down = (desc & 0x20u) != 0;
+    out->w = w; out->h = h; out->channels = ch;
+    out->px.resize(px.size());
+    const size_t stride = (size_t)w * ch;
+    for (u32 y = 0; y < h; ++y) memcpy(&out->px[stride * y], &px[stride * (top_down ? y : h - 1 - y)], stride);
+    return true;
+}
+
+// ---- BMP ------------------------------------------------------------------------------------------------
+bool DecodeBmp(const std::vector<u8> & d, Image * out) {
+    if (d.size() < 54 || d[0] != 'B' || d[1] != 'M') return Fail("not a BMP");
+    const u32 offset = Le32(&d[10]), hsize = Le32(&d[14]);
+    if (hsize < 40) return Fail("unsupported BMP header");
+    const int32_t w = (int32_t)Le32(&d[18]);
+    const int32_t hs = (int32_t)Le32(&d[22]);
+    const u32 bits = Le16(&d[28]), comp = Le32(&d[30]);
+    if (bits != 24 || comp != 0) return Fail("only 24-bit uncompressed BMP is supported");
+    if (w <= 0 || hs == 0) return Fail("empty BMP");
+    const u32 h = (u32)(hs < 0 ? -hs : hs);
+    const size_t stride = (((size_t)w * 3) + 3) & ~(size_t)3;
+    if ((size_t)offset + stride * h > d.size()) return Fail("BMP pixel data truncated");
+    out->w = (u32)w; out->h = h; out->channels = 3;
+    out->px.resize((size_t)w * h * 3);
+    for (u32 y = 0; y < h; ++y) {
+        const u8 * src = &d[(size_t)offset + stride * (hs > 0 ? h - 1 - y : y)];
+        u8 * dst = &out->px[(size_t)w * 3 * y];
+        for (int32_t x = 0; x < w; ++x) { dst[3 * x] = src[3 * x + 2]; dst[3 * x + 1] = src[3 * x + 1]; dst[3 * x + 2] = src[3 * x]; }
+    }
+    return true;
+}
+
+// ---- PNM ------------------------------------------------------------------------------------------------
+bool PnmNumber(const std::vector<u8> & d, size_t * pos, u32 * value) {
+    for (;;) {
+        while (*pos < d.size() && isspace(d[*pos])) ++*pos;
+        if (*pos < d.size() && d[*pos] == '#') { while (*pos < d.size() && d[*pos] != '\n') ++*pos; continue; }
+        break;
+    }
+    if (*pos >= d.size() || !isdigit(d[*pos])) return false;
+    u32 v = 0;
+    while (*pos < d.size() && isdigit(d[*pos])) { v = v * 10 + (u32)(d[*pos] - '0'); ++*pos; }
+    *value = v;
+    return true;
+}
+
+bool DecodePnm(const std::vector<u8> & d, Image * out) {
+    if (d.size() < 3 || d[0] != 'P' || (d[1] != '5' && d[1] != '6')) return Fail("not a binary PGM / PPM");
+    const u32 ch = d[1] == '5' ? 1 : 3;
+    size_t pos = 2;
+    u32 w = 0, h = 0, maxval = 0;
+    if (!PnmNumber(d, &pos, &w) || !PnmNumber(d, &pos, &h) || !PnmNumber(d, &pos, &maxval)) return Fail("bad PNM header");
+    if (maxval == 0 || maxval > 255) return Fail("PNM maxval above 255 is not supported");
+    ++pos;                                                     // the single whitespace byte after maxval
+    if (!w || !h || pos + (size_t)w * h * ch > d.size()) return Fail("PNM pixel data truncated");
+    out->w = w; out->h = h; out->channels = ch;
+    out->px.assign(d.begin() + (long)pos, d.begin() + (long)(pos + (size_t)w * h * ch));
+    return true;
+}
+
+}  // namespace
+
+const char * TextureLoadError() { return gImageError.c_str(); }
+
+// obj_parser.cpp:197-213: NULL (with a message) when the decoder rejects the file.
+Texture * LoadTexture(const char * filename) {
+    Bytes file;
+    Image img;
+    bool ok = file.Read(filename);
+    if (ok) {
+        const std::vector<u8> & d = file.data;
+        if (d.size() >= 8 && d[0] == 0x89 && d[1] == 'P') ok = DecodePng(d, &img);
+        else if (d.size() >= 2 && d[0] == 'B' && d[1] == 'M') ok = DecodeBmp(d, &img);
+        else if (d.size() >= 2 && d[0] == 'P' && (d[1] == '5' || d[1] == '6')) ok = DecodePnm(d, &img);
+        else if (d.size() >= 3 && d[0] == 0xFF && d[1] == 0xD8) ok = Fail("JPEG is not supported");
+        else ok = DecodeTga(d, &img);                          // TGA has no signature: last
+    }
+    if (!ok) {
+        fprintf(stderr, "Failed to load image [%s] :: %s\n", filename, gImageError.c_str());
+        return NULL;
+    }
+    Texture * result = (Texture *)calloc(1, sizeof(Texture));
+    result->size_x = img.w;
+    result->size_y = img.h;
+    result->channels = img.channels;
+    result->texels = (u8 *)malloc(img.px.size());
+    memcpy(result->texels, img.px.data(), img.px.size());
+    return result;
+}
+
+void FreeTexture(Texture * t) {
+    if (!t) return;
+    free(t->texels);
+    free(t);
+}
+
+// ---- texture.cpp:85-143: height map -> tangent-space normal map ------------------------------------------
+namespace {
+
+float SrgbToLinear(float srgb) {                               // color.h:13-21
+    if (srgb <= 0.04045f) return srgb / 12.92f;
+    return powf((srgb + 0.055f) / 1.055f, 2.4f);
+}
+
+float LinearToSrgb(float linear) {                             // color.h:3-11
+    if (linear <= 0.0031308f) return 12.92f * linear;
+    return 1.055f * powf(linear, 1.0f / 2.4f) - 0.055f;
+}
+
+// GetTexel(...).x of texture.cpp:17-51: first channel, through the sRGB curve.
+float HeightAt(const Texture * t, u32 x, u32 y) {
+    const float one_over_255 = 1.0f / 255.0f;
+    u8 r = t->texels[((size_t)y * t->size_x + x) * t->channels];
+    return SrgbToLinear((float)r * one_over_255);
+}
+
+}  // namespace
+
+// Forward differences with wrap-around, slope scale 2.5, the normal stored sRGB-encoded in 3 bytes (truncated,
+// not rounded).  Note the reference's axes: the x component is the difference along +y of the image, y along +x.
+Texture * ConvertHeightMapToNormalMap(const Texture * height_map) {
+    Texture * result = (Texture *)calloc(1, sizeof(Texture));
+    result->size_x = height_map->size_x;
+    result->size_y = height_map->size_y;
+    result->channels = 3;
+    result->texels = (u8 *)calloc((size_t)result->size_x * result->size_y, 3);
+    for (u32 y = 0; y < result->size_y; ++y) {
+        for (u32 x = 0; x < result->size_x; ++x) {
+            u32 x1 = (x + 1) % result->size_x;
+            u32 y1 = (y + 1) % result->size_y;
+            float h00 = HeightAt(height_map, x, y);
+            float h10 = HeightAt(height_map, x1, y);
+            float h01 = HeightAt(height_map, x, y1);
+            float a = 2.5f;
+            Vector3 n = Normalize(Vector3((h01 - h00) * a, (h10 - h00) * a, 1.0f));
+            n = (n + Vector3(1.0f, 1.0f, 1.0f)) * 0.5f;                       // (-1, 1) -> (0, 1), texture.cpp:93
+            u8 * o = result->texels + ((size_t)y * result->size_x + x) * 3;
+            o[0] = (u8)(LinearToSrgb(n.x) * 255.0f);
+            o[1] = (u8)(LinearToSrgb(n.y) * 255.0f);
+            o[2] = (u8)(LinearToSrgb(n.z) * 255.0f);
+        }
+    }
+    return result;
+}

@@ -12,8 +12,7 @@
 //     alpha (:273-275); Ka/Kd/Ks/Ke get w = 1 (ReadColor, :108-112).
 // Differences, all in behaviour the reference leaves undefined: no chdir (paths are joined instead),
 // and malformed input (face before any `g`, statement before `newmtl`) is reported and skipped instead
-// of dereferencing NULL (:387-390).  Texture maps (`map_*`) are recorded by name only: the texture
-// path is a later row and the image decoder is third-party code outside this repo.
+// of dereferencing NULL (:387-390).  Texture maps (`map_*`) are decoded by image_in.cpp.
 #include <cctype>
 #include <cstdio>
 #include <cstdlib>
@@ -126,7 +125,21 @@ Vector4 ReadColourRecord(const char * p, u32 line) {
     return Vector4(rgb.x, rgb.y, rgb.z, 1.0f);
 }
 
-MaterialLibrary * ParseMTL(const std::string & path) {
+// map_* records (obj_parser.cpp:303-331).  The file name is the first token after the keyword; paths are
+// relative to the OBJ's directory (the reference chdir()s there, obj_parser.cpp:353).  A bump map is a height map
+// that is converted to a normal map on load (:322-329); an image the decoder rejects leaves the slot empty.
+Texture * LoadMap(const char * working_dir, const char * after_keyword, u32 line) {
+    char * name = CopyToken(after_keyword);
+    if (!name) {
+        fprintf(stderr, "mtl: texture map without a file name on line %u\n", line);
+        return NULL;
+    }
+    Texture * t = LoadTexture(JoinPath(working_dir, name).c_str());
+    free(name);
+    return t;
+}
+
+MaterialLibrary * ParseMTL(const char * working_dir, const std::string & path) {
     char * bytes = SlurpFile(path);
     MaterialLibrary * lib = new MaterialLibrary;
     if (!bytes) {
@@ -166,7 +179,18 @@ MaterialLibrary * ParseMTL(const std::string & path) {
             else if (p[1] == 's') mat->specular_color = ReadColourRecord(p + 2, line);
             else if (p[1] == 'e') mat->emissive_color = ReadColourRecord(p + 2, line);
         } else if (c == 'm' && StartsWith(p, "map_")) {
-            fprintf(stderr, "mtl: texture map on line %u ignored (texture path not built yet)\n", line);
+            const char * q = p + 4;
+            if (StartsWith(q, "Ka")) mat->ambient_texture = LoadMap(working_dir, q + 2, line);
+            else if (StartsWith(q, "Kd")) mat->diffuse_texture = LoadMap(working_dir, q + 2, line);
+            else if (StartsWith(q, "Ks")) mat->specular_texture = LoadMap(working_dir, q + 2, line);
+            else if (StartsWith(q, "d")) mat->alpha_texture = LoadMap(working_dir, q + 1, line);
+            else if (StartsWith(q, "bump")) {
+                Texture * height = LoadMap(working_dir, q + 4, line);
+                if (height) {                                   // (the reference dereferences NULL here)
+                    mat->bump_texture = ConvertHeightMapToNormalMap(height);
+                    FreeTexture(height);
+                }
+            }
         }
     }
     free(bytes);
@@ -231,7 +255,7 @@ Mesh * ParseOBJ(const char * working_dir, const char * filename, Matrix33 transf
                 mesh->groups[(size_t)current].material = m;
             } else if (StartsWith(p, "mtllib")) {
                 char * name = CopyToken(p + 6);
-                if (name && !mesh->material_library) mesh->material_library = ParseMTL(JoinPath(working_dir, name));
+                if (name && !mesh->material_library) mesh->material_library = ParseMTL(working_dir, JoinPath(working_dir, name));
                 free(name);
             }
             break;

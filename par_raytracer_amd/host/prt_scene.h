@@ -155,6 +155,10 @@ Camera MakeCamera(float fov, u32 width, u32 height);                      // mai
 Material * MakeMaterial(Vector4 color);                                   // main.cpp:506-517
 Scene InitScene();                                                        // main.cpp:519-535
 Mesh * ParseOBJ(const char * working_dir, const char * filename, Matrix33 transform);   // obj_parser.cpp:348-426
+Texture * LoadTexture(const char * filename);                             // obj_parser.cpp:197-213 (image_in.cpp)
+void FreeTexture(Texture * t);
+Texture * ConvertHeightMapToNormalMap(const Texture * height_map);        // texture.cpp:102-143
+const char * TextureLoadError();
 void CalculateTangents(Mesh * mesh);                                      // mesh.h:59-130
 void BuildHierarchy(BoundingHierarchy * h, Mesh * mesh);                  // bsphere.cpp:379-444
 void PopulateSceneObjects(Scene * scene, BoundingHierarchy * h, Mesh * mesh, u32 * out_total_tris);  // main.cpp:576-599

@@ -12,6 +12,7 @@ struct FlatScene {
     std::vector<u32> idx_positions, idx_texcoords, idx_normals;
     std::vector<prt_group> groups;
     std::vector<prt_material> materials;
+    std::vector<prt_texture> textures;          // texel pointers alias the Scene's Texture objects
     std::vector<prt_light> lights;
     std::vector<prt_bsphere> spheres;
     std::vector<s32> sphere_group;

@@ -31,6 +31,12 @@ class MtlMaterial:
     Ka: Tuple[float, float, float] = (0.75, 0.75, 0.75)
     Kd: Tuple[float, float, float] = (0.75, 0.75, 0.75)
     Ks: Tuple[float, float, float] = (1.0, 1.0, 1.0)
+    # texture maps: file names relative to the OBJ's directory (obj_parser.cpp:303-331); map_bump is a HEIGHT map
+    map_Ka: Optional[str] = None
+    map_Kd: Optional[str] = None
+    map_Ks: Optional[str] = None
+    map_d: Optional[str] = None
+    map_bump: Optional[str] = None
 
 
 @dataclass
@@ -51,6 +57,8 @@ class ObjScene:
     camera_position: Tuple[float, float, float] = (0.0, 1.5, 6.0)
     camera_facing: Tuple[float, float, float] = (0.0, -0.15, -1.0)
     fov: float = 60.0
+    # file name -> (uint8 image [h, w] or [h, w, c], encoding): see write_texture
+    textures: Dict[str, Tuple[np.ndarray, str]] = field(default_factory=dict)
 
     @property
     def n_tris(self) -> int:
@@ -95,8 +103,172 @@ def write_obj(scene: ObjScene, directory: str, obj_name: str = "sponza.obj") -> 
                 f.write("Ka %.9g %.9g %.9g\n" % tuple(m.Ka))
                 f.write("Kd %.9g %.9g %.9g\n" % tuple(m.Kd))
                 f.write("Ks %.9g %.9g %.9g\n" % tuple(m.Ks))
+                for key in ("map_Ka", "map_Kd", "map_Ks", "map_d", "map_bump"):
+                    if getattr(m, key):
+                        f.write("%s %s\n" % (key, getattr(m, key)))
                 f.write("\n")
+    for name, (img, enc) in scene.textures.items():
+        write_texture(os.path.join(directory, name), img, enc)
     return path
+
+
+# ----------------------------------------------------------------------------------------
+# texture image writers (test inputs for the loader's decoders; every variant the decoders accept)
+# ----------------------------------------------------------------------------------------
+
+def _png_chunk(tag: bytes, body: bytes) -> bytes:
+    import struct, zlib
+    return struct.pack(">I", len(body)) + tag + body + struct.pack(">I", zlib.crc32(tag + body) & 0xFFFFFFFF)
+
+
+def _png_filter_rows(raw: np.ndarray, bpp: int) -> bytes:
+    """raw: [h, stride] uint8 scanlines.  Rows cycle through the five PNG filter types so a decoder has to
+    implement all of them (None, Sub, Up, Average, Paeth)."""
+    h, stride = raw.shape
+    out = bytearray()
+    prev = np.zeros(stride, dtype=np.int32)
+    for y in range(h):
+        cur = raw[y].astype(np.int32)
+        a = np.concatenate([np.zeros(bpp, dtype=np.int32), cur[:-bpp]]) if stride > bpp else np.zeros(stride, dtype=np.int32)
+        b = prev
+        c = np.concatenate([np.zeros(bpp, dtype=np.int32), prev[:-bpp]]) if stride > bpp else np.zeros(stride, dtype=np.int32)
+        ft = y % 5
+        if ft == 0:
+            pred = np.zeros(stride, dtype=np.int32)
+        elif ft == 1:
+            pred = a
+        elif ft == 2:
+            pred = b
+        elif ft == 3:
+            pred = (a + b) >> 1
+        else:
+            pp = a + b - c
+            pa, pb, pc = np.abs(pp - a), np.abs(pp - b), np.abs(pp - c)
+            pred = np.where((pa <= pb) & (pa <= pc), a, np.where(pb <= pc, b, c))
+        out.append(ft)
+        out += ((cur - pred) & 0xFF).astype(np.uint8).tobytes()
+        prev = cur
+    return bytes(out)
+
+
+def write_png(path: str, img: np.ndarray, sixteen_bit: bool = False, palette: bool = False, palette_alpha: bool = False) -> None:
+    """8-bit grey / grey+alpha / RGB / RGBA PNG; `sixteen_bit` stores every sample as (v, 255 - v) big endian
+    (a decoder keeping the high byte recovers v); `palette` quantises an RGB(A) image to <= 256 colours."""
+    import struct, zlib
+    a = np.asarray(img, dtype=np.uint8)
+    if a.ndim == 2:
+        a = a[:, :, None]
+    h, w, c = a.shape
+    chunks = b""
+    if palette:
+        flat = a.reshape(-1, c)
+        colours, index = np.unique(flat, axis=0, return_inverse=True)
+        assert len(colours) <= 256, "too many colours for a palette"
+        ctype, depth, bpp = 3, 8, 1
+        raw = index.reshape(h, w).astype(np.uint8)
+        chunks += _png_chunk(b"PLTE", colours[:, :3].astype(np.uint8).tobytes())
+        if palette_alpha:
+            assert c == 4
+            chunks += _png_chunk(b"tRNS", colours[:, 3].astype(np.uint8).tobytes())
+    else:
+        ctype = {1: 0, 2: 4, 3: 2, 4: 6}[c]
+        if sixteen_bit:
+            depth, bpp = 16, 2 * c
+            raw = np.stack([a, 255 - a], axis=-1).reshape(h, w * c * 2)
+        else:
+            depth, bpp = 8, c
+            raw = a.reshape(h, w * c)
+    data = zlib.compress(_png_filter_rows(np.ascontiguousarray(raw), bpp), 6)
+    # two IDAT chunks: a decoder must concatenate them
+    cut = len(data) // 2
+    with open(path, "wb") as f:
+        f.write(b"\x89PNG\r\n\x1a\n")
+        f.write(_png_chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, depth, ctype, 0, 0, 0)))
+        f.write(chunks)
+        f.write(_png_chunk(b"IDAT", data[:cut]))
+        f.write(_png_chunk(b"IDAT", data[cut:]))
+        f.write(_png_chunk(b"IEND", b""))
+
+
+def write_tga(path: str, img: np.ndarray, rle: bool = False, top_down: bool = False) -> None:
+    """Grey (type 3 / 11), BGR or BGRA (type 2 / 10) TGA; bottom-up unless `top_down` (descriptor bit 5)."""
+    import struct
+    a = np.asarray(img, dtype=np.uint8)
+    if a.ndim == 2:
+        a = a[:, :, None]
+    h, w, c = a.shape
+    assert c in (1, 3, 4)
+    rows = a if top_down else a[::-1]
+    if c >= 3:
+        rows = rows[:, :, [2, 1, 0] + ([3] if c == 4 else [])]
+    px = np.ascontiguousarray(rows).reshape(-1, c)
+    itype = (3 if c == 1 else 2) + (8 if rle else 0)
+    header = struct.pack("<BBBHHBHHHHBB", 0, 0, itype, 0, 0, 0, 0, 0, w, h, 8 * c, (0x20 if top_down else 0) | (8 if c == 4 else 0))
+    body = bytearray()
+    if not rle:
+        body += px.tobytes()
+    else:
+        i, n = 0, len(px)
+        while i < n:
+            run = 1
+            while i + run < n and run < 128 and np.array_equal(px[i + run], px[i]):
+                run += 1
+            if run >= 2:
+                body.append(0x80 | (run - 1))
+                body += px[i].tobytes()
+                i += run
+            else:
+                j = i + 1
+                while j < n and j - i < 128 and not (j + 1 < n and np.array_equal(px[j], px[j + 1])):
+                    j += 1
+                body.append(j - i - 1)
+                body += px[i:j].tobytes()
+                i = j
+    with open(path, "wb") as f:
+        f.write(header)
+        f.write(bytes(body))
+
+
+def write_bmp(path: str, img: np.ndarray) -> None:
+    """24-bit uncompressed bottom-up BMP."""
+    import struct
+    a = np.asarray(img, dtype=np.uint8)
+    h, w, c = a.shape
+    assert c == 3
+    stride = (w * 3 + 3) & ~3
+    rows = np.zeros((h, stride), dtype=np.uint8)
+    rows[:, :w * 3] = a[::-1, :, ::-1].reshape(h, w * 3)
+    with open(path, "wb") as f:
+        f.write(b"BM" + struct.pack("<IHHI", 54 + stride * h, 0, 0, 54))
+        f.write(struct.pack("<IiiHHIIiiII", 40, w, h, 1, 24, 0, stride * h, 2835, 2835, 0, 0))
+        f.write(rows.tobytes())
+
+
+def write_pnm(path: str, img: np.ndarray) -> None:
+    """Binary PGM (grey) / PPM (RGB) with a comment line in the header."""
+    a = np.asarray(img, dtype=np.uint8)
+    if a.ndim == 2:
+        a = a[:, :, None]
+    h, w, c = a.shape
+    assert c in (1, 3)
+    with open(path, "wb") as f:
+        f.write(("P%d\n# generated\n%d %d\n255\n" % (5 if c == 1 else 6, w, h)).encode())
+        f.write(np.ascontiguousarray(a).tobytes())
+
+
+def write_texture(path: str, img: np.ndarray, encoding: str) -> None:
+    enc = {
+        "png": lambda: write_png(path, img),
+        "png16": lambda: write_png(path, img, sixteen_bit=True),
+        "png_palette": lambda: write_png(path, img, palette=True),
+        "png_palette_alpha": lambda: write_png(path, img, palette=True, palette_alpha=True),
+        "tga": lambda: write_tga(path, img),
+        "tga_top": lambda: write_tga(path, img, top_down=True),
+        "tga_rle": lambda: write_tga(path, img, rle=True),
+        "bmp": lambda: write_bmp(path, img),
+        "pnm": lambda: write_pnm(path, img),
+    }
+    enc[encoding]()
 
 
 # ----------------------------------------------------------------------------------------
@@ -339,6 +511,131 @@ def terrain(quads: int = 708, tiles: int = 32, size: float = 708.0, seed: int = 
 
 
 # ----------------------------------------------------------------------------------------
+# N1: textured gallery - every texture slot, every image encoding the loader decodes
+# ----------------------------------------------------------------------------------------
+
+def _quad(pos, nrm, uv, corners, normal, uvs):
+    """Append a quad (4 corners, counter-clockwise seen from `normal`) -> two triangles of vertex ids."""
+    base = len(pos)
+    for c, t in zip(corners, uvs):
+        pos.append(list(c)); nrm.append(list(normal)); uv.append(list(t))
+    return [[base, base + 1, base + 2], [base, base + 2, base + 3]]
+
+
+def textured_gallery(sphere_segments: int = 20, sphere_rings: int = 10) -> ObjScene:
+    """Row N1 of SURVEY.md 8f: ambient / diffuse / specular / alpha / bump maps (raytracer.cpp:439-502, 547-552).
+
+    A floor (tiled checker + bump, texture coordinates running negative and past 1), a lit right wall (RGBA
+    diffuse + specular map), a back wall (2x2 ambient map: the `size - 2` scale is 0 there), a translucent fence
+    whose alpha map has holes (alpha <= 0.05 passes the ray through with its bounce budget intact), a bumpy ball
+    and a panel with a palette texture.  Every image encoding image_in.cpp decodes appears once."""
+    rng = np.random.default_rng(20240611)
+    pos, nrm, uv = [], [], []
+    groups = []
+
+    def add(name, tris, material):
+        groups.append(ObjGroup(name, _faces_same_index(np.array(tris)), material))
+
+    # floor: y = 0, normal +y, uv tiled 3x with a negative origin
+    add("floor", _quad(pos, nrm, uv, [(-3, 0, 3), (3, 0, 3), (3, 0, -3), (-3, 0, -3)], (0, 1, 0),
+                       [(-1.25, -0.5), (1.75, -0.5), (1.75, 2.5), (-1.25, 2.5)]), "floor")
+    # right wall: x = 3, normal -x (lit by the default light)
+    add("right_wall", _quad(pos, nrm, uv, [(3, 0, 3), (3, 3, 3), (3, 3, -3), (3, 0, -3)], (-1, 0, 0),
+                            [(0, 0), (0, 1), (2, 1), (2, 0)]), "right_wall")
+    # left wall: x = -3, normal +x, untextured material
+    add("left_wall", _quad(pos, nrm, uv, [(-3, 0, -3), (-3, 3, -3), (-3, 3, 3), (-3, 0, 3)], (1, 0, 0),
+                           [(0, 0), (0, 1), (1, 1), (1, 0)]), "plain")
+    # back wall: z = -3, normal +z
+    add("back_wall", _quad(pos, nrm, uv, [(-3, 0, -3), (3, 0, -3), (3, 3, -3), (-3, 3, -3)], (0, 0, 1),
+                           [(0, 0), (1, 0), (1, 1), (0, 1)]), "back_wall")
+    # fence: z = 0.75, normal +z (towards the camera), alpha-mapped
+    add("fence", _quad(pos, nrm, uv, [(-1.6, 0, 0.75), (1.6, 0, 0.75), (1.6, 1.6, 0.75), (-1.6, 1.6, 0.75)], (0, 0, 1),
+                       [(0, 0), (2, 0), (2, 1), (0, 1)]), "fence")
+    # tilted panel on the left
+    add("panel", _quad(pos, nrm, uv, [(-2.6, 0.4, 0.2), (-1.2, 0.4, -0.9), (-1.2, 1.9, -0.9), (-2.6, 1.9, 0.2)],
+                       tuple(_normalize(np.array([[1.1, 0.0, 1.4]]))[0]),
+                       [(0, 0), (1, 0), (1, 1), (0, 1)]), "panel")
+    # ball behind the fence
+    c = np.array([0.5, 0.8, -0.9]); radius = 0.8
+    base = len(pos)
+    pos.append(list(c + [0, radius, 0])); nrm.append([0, 1, 0]); uv.append([0.5, 0.0])
+    for r in range(1, sphere_rings):
+        th = np.pi * r / sphere_rings
+        for sg in range(sphere_segments + 1):                      # seam duplicated so u runs 0..2 without a jump
+            ph = 2 * np.pi * sg / sphere_segments
+            n = np.array([np.sin(th) * np.cos(ph), np.cos(th), np.sin(th) * np.sin(ph)])
+            pos.append(list(c + radius * n)); nrm.append(list(n)); uv.append([2.0 * sg / sphere_segments, r / sphere_rings])    # v grows downwards: positive uv area, so tangents exist (mesh.h:93)
+    pos.append(list(c - [0, radius, 0])); nrm.append([0, -1, 0]); uv.append([0.5, 1.0])
+    south = len(pos) - 1
+
+    def ring(r, sg):
+        return base + 1 + (r - 1) * (sphere_segments + 1) + sg
+
+    tris = []
+    for sg in range(sphere_segments):
+        tris.append([base, ring(1, sg + 1), ring(1, sg)])
+    for r in range(1, sphere_rings - 1):
+        for sg in range(sphere_segments):
+            a, b = ring(r, sg), ring(r, sg + 1)
+            d, e = ring(r + 1, sg), ring(r + 1, sg + 1)
+            tris.append([a, b, e])
+            tris.append([a, e, d])
+    for sg in range(sphere_segments):
+        tris.append([south, ring(sphere_rings - 1, sg), ring(sphere_rings - 1, sg + 1)])
+    add("ball", tris, "ball")
+
+    # ---- images -------------------------------------------------------------------------------------------
+    def checker(h, w, cell, c0, c1):
+        yy, xx = np.mgrid[0:h, 0:w]
+        m = ((yy // cell + xx // cell) % 2).astype(bool)
+        img = np.where(m[:, :, None], np.array(c1, dtype=np.uint8), np.array(c0, dtype=np.uint8))
+        return (img.astype(np.int32) + rng.integers(-12, 13, size=img.shape)).clip(0, 255).astype(np.uint8)
+
+    def waves(h, w, fx, fy):
+        yy, xx = np.mgrid[0:h, 0:w]
+        v = 0.5 + 0.5 * np.sin(2 * np.pi * fx * xx / w) * np.cos(2 * np.pi * fy * yy / h)
+        return (v * 255).round().astype(np.uint8)
+
+    textures = {}
+    textures["floor_kd.png"] = (checker(64, 48, 8, (40, 60, 200), (230, 220, 190)), "png")                  # RGB, all 5 filters
+    textures["floor_bump.tga"] = (waves(48, 48, 3, 2), "tga_rle")                                             # grey, run-length
+    rgba = np.concatenate([checker(37, 29, 5, (220, 40, 40), (250, 240, 120)),
+                           rng.integers(0, 256, size=(37, 29, 1), dtype=np.uint8)], axis=2)
+    textures["wall_kd.png"] = (rgba, "png")                                                                   # RGBA
+    textures["wall_ks.ppm"] = (checker(32, 32, 4, (20, 20, 20), (255, 255, 255)), "pnm")                      # binary PPM
+    textures["back_ka.bmp"] = (np.array([[[255, 80, 20], [30, 200, 90]], [[10, 40, 250], [240, 240, 60]]], dtype=np.uint8), "bmp")   # 2x2
+    textures["back_kd.tga"] = (checker(40, 56, 7, (90, 160, 90), (200, 230, 200)), "tga")                     # BGR, bottom-up
+    holes = waves(64, 64, 4, 4)
+    holes[holes < 90] = 0                                                                                     # holes: alpha 0
+    textures["fence_d.pgm"] = (holes, "pnm")                                                                  # binary PGM
+    textures["fence_kd.png"] = (checker(32, 64, 4, (120, 90, 40), (180, 140, 70)), "png16")                   # 16-bit samples
+    pal = checker(48, 48, 6, (30, 30, 30), (240, 200, 40)) // 32 * 32                                         # few distinct colours
+    textures["panel_kd.png"] = (pal, "png_palette")
+    pal_a = np.concatenate([pal, (waves(48, 48, 2, 1) // 64 * 64)[:, :, None]], axis=2).astype(np.uint8)
+    textures["panel_ka.png"] = (pal_a, "png_palette_alpha")                                                    # palette + tRNS -> RGBA
+    textures["panel_d.tga"] = ((128 + waves(33, 31, 1, 2) // 2).astype(np.uint8), "tga_top")                  # grey, top-down
+    textures["ball_kd.tga"] = (np.concatenate([checker(32, 64, 8, (200, 200, 220), (60, 60, 160)),
+                                               np.full((32, 64, 1), 255, dtype=np.uint8)], axis=2), "tga_rle")   # BGRA, run-length
+    textures["ball_bump.png"] = (rng.integers(60, 200, size=(32, 32), dtype=np.uint8), "png")                 # grey PNG
+    textures["ball_ks.png"] = (rng.integers(0, 256, size=(16, 24, 2), dtype=np.uint8), "png")                 # grey + alpha: 2 channels -> (r, g, 0)
+
+    materials = [
+        MtlMaterial("floor", Ns=30.0, Ka=(0.6, 0.6, 0.6), Kd=(0.9, 0.9, 0.9), Ks=(0.3, 0.3, 0.3), map_Kd="floor_kd.png", map_bump="floor_bump.tga"),
+        MtlMaterial("right_wall", Ns=60.0, Ka=(0.5, 0.5, 0.5), Kd=(0.8, 0.8, 0.8), Ks=(0.1, 0.1, 0.1), map_Kd="wall_kd.png", map_Ks="wall_ks.ppm"),
+        MtlMaterial("plain", Ka=(0.4, 0.7, 0.4), Kd=(0.4, 0.7, 0.4), Ks=(0.2, 0.2, 0.2)),
+        MtlMaterial("back_wall", Ka=(1.0, 1.0, 1.0), Kd=(0.7, 0.7, 0.7), Ks=(0.0, 0.0, 0.0), map_Ka="back_ka.bmp", map_Kd="back_kd.tga"),
+        MtlMaterial("fence", Ns=5.0, d=0.9, Ka=(0.5, 0.4, 0.3), Kd=(1.0, 1.0, 1.0), Ks=(0.05, 0.05, 0.05), map_Kd="fence_kd.png", map_d="fence_d.pgm"),
+        MtlMaterial("panel", Ns=15.0, Ka=(0.8, 0.8, 0.8), Kd=(1.0, 1.0, 1.0), Ks=(0.4, 0.4, 0.4), map_Ka="panel_ka.png", map_Kd="panel_kd.png", map_d="panel_d.tga"),
+        MtlMaterial("ball", Ns=40.0, Ka=(0.5, 0.5, 0.6), Kd=(0.9, 0.9, 1.0), Ks=(0.6, 0.6, 0.6), map_Kd="ball_kd.tga", map_Ks="ball_ks.png", map_bump="ball_bump.png"),
+    ]
+    return ObjScene(
+        name="textured_gallery",
+        positions=np.array(pos, dtype=F32), texcoords=np.array(uv, dtype=F32), normals=np.array(nrm, dtype=F32),
+        groups=groups, materials=materials, textures=textures,
+        camera_position=(0.3, 1.4, 4.6), camera_facing=(-0.05, -0.18, -1.0), fov=60.0)
+
+
+# ----------------------------------------------------------------------------------------
 # registry: name -> (factory, render defaults)
 # ----------------------------------------------------------------------------------------
 
@@ -360,6 +657,7 @@ SCENES = {
     "terrain_1m": lambda: terrain(708, 32),
     "terrain_64": lambda: terrain(64, 4, size=64.0),          # 8,192 tris in 16 groups, CPU-test sized
     "terrain_192": lambda: terrain(192, 8, size=192.0),       # 73,728 tris in 64 groups
+    "textured_gallery": lambda: textured_gallery(),           # 192 tris, 7 materials, 14 texture files (row N1)
 }
 
 CONFIGS: Dict[str, RenderConfig] = {

@@ -78,6 +78,18 @@ def test_shard_rows_partition_the_frame():
 
 # ---- loader + hierarchy against the reference's parse of the same files ------------------------------------
 
+def _load_texture(lib, path):
+    """prt_host_load_texture -> uint8 array [h, w, c] or None."""
+    import ctypes as C
+    sx, sy, ch = C.c_uint32(), C.c_uint32(), C.c_uint32()
+    ptr = lib.prt_host_load_texture(path.encode(), C.byref(sx), C.byref(sy), C.byref(ch))
+    if not ptr:
+        return None
+    out = np.ctypeslib.as_array(ptr, shape=(sy.value, sx.value, ch.value)).copy()
+    lib.prt_host_free_texture(ptr)
+    return out
+
+
 def _sums(a):
     a = np.ascontiguousarray(a).view(np.uint8).reshape(-1)
     return np.array([a.size, int(a.astype(np.uint64).sum()),
@@ -97,6 +109,68 @@ def test_loader_and_hierarchy_bit_identical_to_reference(name):
     assert np.array_equal(a["sphere_group"], g["sphere_group"])
     assert np.array_equal(a["groups"][:, 1].astype(np.uint32), g["group_index_counts"])
     assert hs.n_tris == int(g["triangles"])
+
+
+def test_texture_decoders_and_tangents_bit_identical_to_reference():
+    """Row N1: the 14 texture files of the gallery scene (8/16-bit PNG in grey, RGB, RGBA, palette, palette + tRNS
+    with all five scanline filters and split IDAT; TGA raw / run-length / top-down, grey / BGR / BGRA; 24-bit BMP;
+    binary PGM / PPM) decode to the bytes the reference's decoder produced, the height maps convert to the same
+    normal maps (texture.cpp:102-143) and CalculateTangents (mesh.h:59-130) gives the same vectors."""
+    g = load_golden("gallery_160x120")
+    hs = host_scene("textured_gallery")
+    a = hs.arrays()
+    assert np.array_equal(a["group_texture_dims"], g["group_texture_dims"])
+    assert np.array_equal(_sums(a["group_texture_bytes"]), g["sum_group_texture_bytes"])
+    assert np.array_equal(_sums(a["tangents"]), g["sum_tangents"])
+    assert np.abs(a["tangents"]).sum() > 100.0, "floor and ball have real tangents"
+    for k in ("positions", "texcoords", "normals", "idx_positions", "idx_texcoords", "idx_normals"):
+        assert np.array_equal(_sums(a[k]), g["sum_" + k]), k
+    dims = a["group_texture_dims"].reshape(-1, 5, 3)
+    assert (dims[:, :, 0] > 0).sum() == 14 and set(np.unique(dims[:, :, 2])) == {0, 1, 2, 3, 4}
+
+
+def test_texture_writers_round_trip_through_the_loader(tmp_path):
+    """Every encoding of scenes.write_texture decodes to the array that was written (16-bit PNG keeps the high
+    byte; palette images come back as RGB / RGBA)."""
+    from par_raytracer_amd import scenes
+    rng = np.random.default_rng(5)
+    lib = capi.host_lib()
+    cases = [("png", 1), ("png", 2), ("png", 3), ("png", 4), ("png16", 1), ("png16", 3), ("png16", 4), ("tga", 1), ("tga", 3),
+             ("tga", 4), ("tga_top", 3), ("tga_rle", 1), ("tga_rle", 3), ("tga_rle", 4), ("bmp", 3), ("pnm", 1), ("pnm", 3)]
+    for enc, ch in cases:
+        img = rng.integers(0, 256, size=(13, 7, ch), dtype=np.uint8)
+        img[3:9, 1:6] = img[3, 1]                                   # runs, so the run-length packets are exercised
+        path = str(tmp_path / ("t_%s_%d.img" % (enc, ch)))
+        scenes.write_texture(path, img, enc)
+        got = _load_texture(lib, path)
+        assert got is not None, (enc, ch)
+        assert got.shape == img.shape and np.array_equal(got, img), (enc, ch)
+    few = (rng.integers(0, 4, size=(9, 11, 4), dtype=np.uint8) * 80).astype(np.uint8)
+    for enc, ch in (("png_palette", 3), ("png_palette_alpha", 4)):
+        path = str(tmp_path / ("p_%s.png" % enc))
+        scenes.write_texture(path, few[:, :, :ch], enc)
+        got = _load_texture(lib, path)
+        assert got is not None and np.array_equal(got, few[:, :, :ch]), enc
+
+
+def test_unsupported_images_leave_the_slot_empty_like_a_decoder_failure(tmp_path):
+    """obj_parser.cpp:201-204: a file the decoder rejects prints a message and yields no texture.  Same here for
+    JPEG, truncated files and missing files - no crash, and the material simply has no map."""
+    lib = capi.host_lib()
+    bad = tmp_path / "x.jpg"
+    bad.write_bytes(b"\xff\xd8\xff\xe0" + b"\0" * 64)
+    assert _load_texture(lib, str(bad)) is None
+    trunc = tmp_path / "t.png"
+    from par_raytracer_amd import scenes
+    scenes.write_texture(str(trunc), np.zeros((8, 8, 3), dtype=np.uint8), "png")
+    trunc.write_bytes(trunc.read_bytes()[:40])
+    assert _load_texture(lib, str(trunc)) is None
+    assert _load_texture(lib, str(tmp_path / "missing.tga")) is None
+    # a material whose map is missing still loads, untextured
+    (tmp_path / "scene.obj").write_text("mtllib scene.mtl\nv 0 0 0\nv 1 0 0\nv 0 1 0\nvt 0 0\nvn 0 0 1\ng a\nusemtl m\nf 1/1/1 2/1/1 3/1/1\n")
+    (tmp_path / "scene.mtl").write_text("newmtl m\nd 1\nKd 1 1 1\nmap_Kd nothing.png\nmap_bump nothing.tga\n")
+    hs = api.HostScene(str(tmp_path), "scene.obj")
+    assert hs.desc.contents.texture_count == 0 and hs.n_tris == 1
 
 
 def test_loader_matches_generator_arrays():

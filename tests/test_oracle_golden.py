@@ -16,7 +16,7 @@ from conftest import camera_and_params, host_scene, load_golden, scene_dir
 import oracle_py as orc
 
 FAST = ["c1_sphere_plane_256", "c2_cornell_128", "c2_cornell_512_l4", "cornell_point_light_d5",
-        "icosphere_l3_two_lights", "terrain64_d3"]
+        "icosphere_l3_two_lights", "terrain64_d3", "gallery_160x120", "gallery_two_lights_d4"]
 SLOW = ["terrain192_d2", "c3_icosphere_1080p_l24", "c4_terrain1m_1080p_l40"]
 
 
@@ -68,6 +68,7 @@ def test_lattice_is_a_subset_of_the_full_frame():
     ("cornell_box", 40, 30, 3, 4, 1, 1, 2, 99),
     ("sphere_plane", 48, 48, 2, 2, 2, 2, 1, 7),
     ("terrain_64", 32, 24, 2, 6, 0, 1, 1, 424242),
+    ("textured_gallery", 56, 40, 3, 5, 2, 1, 2, 31337),          # textures + point light + deep alpha chains
 ])
 def test_live_against_compiled_reference(scene, w, h, spp, depth, lm, rs, ss, seed):
     from par_raytracer_amd import api
