@@ -23,6 +23,8 @@
 //   tri_rank   u32 per triangle: position in the reference's own visit order (sphere tree DFS with c1
 //              first, then ascending index inside a group; raytracer.cpp:136, 208-209).  Only read when
 //              two hits have bit-equal t, to keep the reference's "first hit wins" (strict <, :149, :220)
+//   tri_uv, tri_tan  only for scenes with texture maps: 32 B of texture coordinates and 48 B of vertex tangents per
+//              triangle, same order; textures as RGBA8 texels + a 256-entry sRGB->linear table (dev_texture.h)
 //   materials  64 B each; lights 48 B each; diffuse_dirs 1024 x float4 (the Hammersley set of
 //              raytracer.cpp:519-521 pushed through cosf/sinf/sqrtf on the HOST, so no device
 //              transcendental ever feeds a direction); spec_dirs [material][spec_samples] likewise.
@@ -40,7 +42,17 @@ struct DevMaterial {          // 64 B
     float specular[3];
     float alpha;
     int flags;
-    int pad[3];
+    // texture slots, two 16-bit texture numbers per word (0xFFFF = none):
+    //   tex[0] = ambient | diffuse << 16    tex[1] = specular | alpha << 16    tex[2] = bump | 0xFFFF << 16
+    unsigned int tex[3];
+};
+
+enum { DEV_TEX_NONE = 0xFFFFu };
+
+struct DevTexture {           // 16 B
+    unsigned int first_texel;  // into DevScene::texels
+    unsigned int size_x, size_y;
+    unsigned int pad;
 };
 
 struct DevLight {             // 48 B
@@ -66,6 +78,12 @@ struct DevScene {
     unsigned int spec_samples;
     unsigned int tri_count;
     unsigned int node_count;
+    // texture path (only scenes with map_* records; NULL otherwise).  dev_texture.h
+    const DevTexture * textures;
+    const unsigned int * texels;     // RGBA8, every texture expanded to 4 channels by GetTexel's rules (texture.cpp:27-41)
+    const float * srgb_lut;          // 256 x Color_SRGBToLinear(i / 255), host powf
+    const float4 * tri_uv;           // 32 B per triangle: (uv0, uv1) (uv2, -)
+    const float4 * tri_tan;          // 48 B per triangle: the three vertex tangents, packed like the normals in `shade`
 };
 
 struct DevCamera {            // Camera (main.cpp:133-143) with the loop invariants of MakeCameraRay hoisted

@@ -69,7 +69,7 @@ struct PoolEmit {
 PRT_D void pool_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }
 
 // grid = resident blocks; dynamic LDS = stack_entries * BLOCK * 4 (traversal stack columns).
-template <int BLOCK, int WAVES, bool LDSTAB, bool RING, bool COUNT>
+template <int BLOCK, int WAVES, bool LDSTAB, bool RING, bool COUNT, bool TEX>
 __global__ __launch_bounds__(BLOCK, WAVES) void k_pool(DevScene sc, DevCamera cam, DevParams P, WaveBuffers B, PoolBuffers Q, int keep_min,
                                                  int node_min, int multi_light, DevCounters * ctr) {
     extern __shared__ int s_stack[];
@@ -283,7 +283,7 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_pool(DevScene sc, DevCamera ca
                     hit.t = h.x; hit.v = h.y; hit.w = h.z; hit.tri = as_i(h.w);
                 }
                 unsigned int shaded = 0;
-                shade_entry<RING>(sc, P, B, tb, live, s, level, pending, ray_o, ray_d, T, hit, emit, shaded);
+                shade_entry<RING, TEX>(sc, P, B, tb, live, s, level, pending, ray_o, ray_d, T, hit, emit, shaded);
                 shaded_w += (unsigned int)__popcll(__ballot(shaded != 0));
             }
             n_c = emit.m_c;

@@ -26,6 +26,7 @@
 
 #include "../../include/prt_key.h"
 #include "dev_shade.h"
+#include "dev_texture.h"
 
 namespace prt {
 
@@ -317,26 +318,32 @@ __global__ __launch_bounds__(256) void k_trace_overflow(DevScene sc, DevParams P
 // Pending frame record: FR4 float4 per (level, sample).
 //   f0 = (hit_p.xyz, mat)  f1 = (hit_n.xyz, stage | idx << 8)  f2 = (ray_d.xyz, alpha)  f3 = (T_in.xyz, w_diffuse)
 //   f4 = (hit_pos.xyz, -)   only when translucent materials exist (alpha continuation, raytracer.cpp:547-552)
+//   f5 = (Kd.xyz, -)  f6 = (Ks.xyz, -)   only for textured scenes: the hit's own colours (raytracer.cpp:455-462);
+//                                        untextured scenes re-read them from the material table instead
 struct WFrame {
-    f3 hit_p, hit_n, ray_d, T_in, hit_pos;
+    f3 hit_p, hit_n, ray_d, T_in, hit_pos, kd, ks;
     float alpha, w_diffuse;
     int mat, stage, idx;
 };
 
-template <bool RING>
+template <bool RING, bool TEX>
 PRT_D void wframe_save(const WaveBuffers & B, int level, unsigned int s, const WFrame & f) {
-    constexpr int FR4 = RING ? 5 : 4;
+    constexpr int FR4 = TEX ? 7 : RING ? 5 : 4;
     float4 * p = B.frames + ((size_t)level * FR4) * B.n_samples + s;
     p[0] = make_float4(f.hit_p.x, f.hit_p.y, f.hit_p.z, as_f(f.mat));
     p[(size_t)B.n_samples] = make_float4(f.hit_n.x, f.hit_n.y, f.hit_n.z, as_f(f.stage | (f.idx << 8)));
     p[(size_t)B.n_samples * 2] = make_float4(f.ray_d.x, f.ray_d.y, f.ray_d.z, f.alpha);
     p[(size_t)B.n_samples * 3] = make_float4(f.T_in.x, f.T_in.y, f.T_in.z, f.w_diffuse);
     if (RING) p[(size_t)B.n_samples * 4] = make_float4(f.hit_pos.x, f.hit_pos.y, f.hit_pos.z, 0.0f);
+    if (TEX) {
+        p[(size_t)B.n_samples * 5] = make_float4(f.kd.x, f.kd.y, f.kd.z, 0.0f);
+        p[(size_t)B.n_samples * 6] = make_float4(f.ks.x, f.ks.y, f.ks.z, 0.0f);
+    }
 }
 
-template <bool RING>
+template <bool RING, bool TEX>
 PRT_D void wframe_load(const WaveBuffers & B, int level, unsigned int s, WFrame & f) {
-    constexpr int FR4 = RING ? 5 : 4;
+    constexpr int FR4 = TEX ? 7 : RING ? 5 : 4;
     const float4 * p = B.frames + ((size_t)level * FR4) * B.n_samples + s;
     const float4 a = p[0], b = p[(size_t)B.n_samples], c = p[(size_t)B.n_samples * 2], d = p[(size_t)B.n_samples * 3];
     f.hit_p = mk3(a.x, a.y, a.z); f.mat = as_i(a.w);
@@ -348,6 +355,11 @@ PRT_D void wframe_load(const WaveBuffers & B, int level, unsigned int s, WFrame 
         f.hit_pos = mk3(e.x, e.y, e.z);
     } else {
         f.hit_pos = f.hit_p;
+    }
+    if (TEX) {
+        const float4 g = p[(size_t)B.n_samples * 5], h = p[(size_t)B.n_samples * 6];
+        f.kd = mk3(g.x, g.y, g.z);
+        f.ks = mk3(h.x, h.y, h.z);
     }
 }
 
@@ -361,7 +373,7 @@ struct ShadeTables {
 // One closest-hit result -> the sample's next rays.  `live` lanes process (s, level, pending, ray, T, hit); every
 // lane of the calling group must call it (the emitter aggregates appends).  emit.shadow(...) is called once per
 // light by every lane, emit.closest(...) once at the end.
-template <bool RING, class Emit>
+template <bool RING, bool TEX, class Emit>
 PRT_D void shade_entry(const DevScene & sc, const DevParams & P, const WaveBuffers & B, const ShadeTables & tb, bool live,
                        unsigned int s, int level, unsigned int pending, f3 ray_o, f3 ray_d, f3 T, const HitRec & hit, Emit & emit,
                        unsigned int & shaded) {
@@ -385,7 +397,7 @@ PRT_D void shade_entry(const DevScene & sc, const DevParams & P, const WaveBuffe
     enum { M_NEXT_CHILD, M_ENTER, M_RETURN_UP, M_DONE };
     int mode = M_DONE;
     WFrame f;
-    f.hit_p = f.hit_n = f.ray_d = f.T_in = f.hit_pos = mk3(0, 0, 0);
+    f.hit_p = f.hit_n = f.ray_d = f.T_in = f.hit_pos = f.kd = f.ks = mk3(0, 0, 0);
     f.alpha = 1.0f; f.w_diffuse = 0.0f; f.mat = 0; f.stage = WF_STAGE_DONE; f.idx = 0;
     bool want_shadow = false;
     bool f_held = false;
@@ -404,21 +416,61 @@ PRT_D void shade_entry(const DevScene & sc, const DevParams & P, const WaveBuffe
             const f3 gn = normalize3(mk3(s2.y, s2.z, s2.w));                        // raytracer.cpp:122 (n = Cross(ab, ac))
             const int m = as_i(s3.w);
             mat = tb.materials[m];
-            const float alpha = mat.alpha;
-            if (mat.alpha <= 1.0f && alpha <= 0.05f) {                              // raytracer.cpp:443-453
+            float alpha = mat.alpha;
+            const float bwy = hit.v, bwz = hit.w;
+            const float bwx = 1.0f - bwy - bwz;                                     // raytracer.cpp:120
+            f3 ka = mk3(mat.ambient[0], mat.ambient[1], mat.ambient[2]);
+            f.kd = mk3(mat.diffuse[0], mat.diffuse[1], mat.diffuse[2]);
+            f.ks = mk3(mat.specular[0], mat.specular[1], mat.specular[2]);
+            float tu = 0.0f, tv = 0.0f;
+            bool alpha_tested = mat.alpha <= 1.0f;                                  // raytracer.cpp:443
+            const bool any_tex = TEX && (mat.tex[0] & mat.tex[1] & mat.tex[2]) != 0xFFFFFFFFu;
+            if (TEX && any_tex) {
+                const float4 * up = sc.tri_uv + 2 * (size_t)hit.tri;
+                const float4 u01 = up[0], u2 = up[1];
+                tu = 0.0f + u01.x * bwx; tv = 0.0f + u01.y * bwx;                   // raytracer.cpp:439-442
+                tu = tu + u01.z * bwy; tv = tv + u01.w * bwy;
+                tu = tu + u2.x * bwz; tv = tv + u2.y * bwz;
+                const unsigned int alpha_tex = mat.tex[1] >> 16;
+                if (alpha_tex != DEV_TEX_NONE) {                                    // raytracer.cpp:444-446
+                    alpha *= tex_sample_r(sc, alpha_tex, tu, tv);
+                    alpha_tested = true;
+                }
+            }
+            if (alpha_tested && alpha <= 0.05f) {                                   // raytracer.cpp:443-453
                 next_o = pos + ray_d * P.ray_bias * 2.0f;
                 next_d = ray_d;
                 next_T = T;
                 next_level = level;
                 mode = M_ENTER;
             } else {
-                const float bwy = hit.v, bwz = hit.w;
-                const float bwx = 1.0f - bwy - bwz;                                 // raytracer.cpp:120
+                if (TEX && any_tex) {                                               // raytracer.cpp:455-462
+                    const unsigned int t_ka = mat.tex[0] & 0xFFFFu, t_kd = mat.tex[0] >> 16, t_ks = mat.tex[1] & 0xFFFFu;
+                    if (t_ka != DEV_TEX_NONE) ka = ka * tex_sample_rgb(sc, t_ka, tu, tv);
+                    if (t_kd != DEV_TEX_NONE) f.kd = f.kd * tex_sample_rgb(sc, t_kd, tu, tv);
+                    if (t_ks != DEV_TEX_NONE) f.ks = tex_sample_rgb(sc, t_ks, tu, tv);      // replaces Ks
+                }
                 f3 interp = mk3(0.0f, 0.0f, 0.0f);                                  // raytracer.cpp:464-467
                 interp = interp + mk3(s0.x, s0.y, s0.z) * bwx;
                 interp = interp + mk3(s0.w, s1.x, s1.y) * bwy;
                 interp = interp + mk3(s1.z, s1.w, s2.x) * bwz;
                 f.hit_n = normalize3(interp);
+                if (TEX && (mat.tex[2] & 0xFFFFu) != DEV_TEX_NONE) {                // raytracer.cpp:468-502
+                    const float4 * tp = sc.tri_tan + 3 * (size_t)hit.tri;
+                    const float4 t0 = tp[0], t1 = tp[1], t2 = tp[2];
+                    f3 tangent = mk3(0.0f, 0.0f, 0.0f);
+                    tangent = tangent + mk3(t0.x, t0.y, t0.z) * bwx;
+                    tangent = tangent + mk3(t0.w, t1.x, t1.y) * bwy;
+                    tangent = tangent + mk3(t1.z, t1.w, t2.x) * bwz;
+                    tangent = normalize3(tangent);
+                    const f3 bitangent = normalize3(cross3(f.hit_n, tangent));
+                    const f3 smp = tex_sample_rgb(sc, mat.tex[2] & 0xFFFFu, tu, tv);
+                    const f3 sn = smp * 2.0f - mk3(1.0f, 1.0f, 1.0f);
+                    // world_from_tangent_space * sn, columns (tangent, bitangent, normal), mathlib.h:697-709; not renormalised
+                    f.hit_n = mk3((tangent.x * sn.x + bitangent.x * sn.y) + f.hit_n.x * sn.z,
+                                  (tangent.y * sn.x + bitangent.y * sn.y) + f.hit_n.y * sn.z,
+                                  (tangent.z * sn.x + bitangent.z * sn.y) + f.hit_n.z * sn.z);
+                }
                 f.hit_pos = pos;
                 f.hit_p = pos + gn * P.ray_bias;                                    // raytracer.cpp:425
                 f.ray_d = ray_d;
@@ -432,7 +484,7 @@ PRT_D void shade_entry(const DevScene & sc, const DevParams & P, const WaveBuffe
                 f.stage = WF_STAGE_REFL;
                 f.idx = 0;
                 T_own = alpha < 1.0f ? T * alpha : T;                               // raytracer.cpp:551
-                add = add + T_own * (mk3(mat.ambient[0], mat.ambient[1], mat.ambient[2]) * 0.1f);   // raytracer.cpp:543
+                add = add + T_own * (ka * 0.1f);                                    // raytracer.cpp:543
                 want_shadow = true;
                 mode = M_NEXT_CHILD;
             }
@@ -462,8 +514,7 @@ PRT_D void shade_entry(const DevScene & sc, const DevParams & P, const WaveBuffe
             const float spec_cos = dot3(f.ray_d * -1.0f, reflect3(light_vector, f.hit_n));
             const f3 dd = light_color * 2.0f * ref_max(0.0f, dot3(f.hit_n, light_vector));
             const f3 ds = light_color * powf(ref_max(0.0f, spec_cos), mat.specular_intensity);
-            contrib = T_own * (dd * mk3(mat.diffuse[0], mat.diffuse[1], mat.diffuse[2]) * f.w_diffuse +
-                               ds * mk3(mat.specular[0], mat.specular[1], mat.specular[2]));
+            contrib = T_own * (dd * f.kd * f.w_diffuse + ds * f.ks);
             so = f.hit_p;
             sd = light_vector;
         }
@@ -505,8 +556,10 @@ PRT_D void shade_entry(const DevScene & sc, const DevParams & P, const WaveBuffe
                 }
                 next_d = tangent_to_world(f.hit_n, mk3(ts.x, ts.y, ts.z));
                 const float cw = kind == 0 ? ref_max(0.0f, dot3(f.hit_n, next_d)) : ref_max(0.0f, dot3(next_d, f.ray_d * -1.0f));
-                const f3 lobe = kind == 0 ? mk3(fm.diffuse[0], fm.diffuse[1], fm.diffuse[2]) * f.w_diffuse
-                                          : mk3(fm.specular[0], fm.specular[1], fm.specular[2]);
+                // the frame's colours: carried in the frame for textured scenes, else re-read from the material table
+                const f3 fkd = TEX ? f.kd : mk3(fm.diffuse[0], fm.diffuse[1], fm.diffuse[2]);
+                const f3 fks = TEX ? f.ks : mk3(fm.specular[0], fm.specular[1], fm.specular[2]);
+                const f3 lobe = kind == 0 ? fkd * f.w_diffuse : fks;
                 next_T = own * (lobe * cw);
                 next_o = f.hit_p;
                 f.idx++;
@@ -527,7 +580,7 @@ PRT_D void shade_entry(const DevScene & sc, const DevParams & P, const WaveBuffe
             if (!dead) {
                 // the child flies: park its parent frame if that still has children to spawn afterwards
                 if (f_held && f.stage != WF_STAGE_DONE) {
-                    wframe_save<RING>(B, level, s, f);
+                    wframe_save<RING, TEX>(B, level, s, f);
                     pending |= 1u << level;
                 }
                 emit_closest = true;
@@ -541,7 +594,7 @@ PRT_D void shade_entry(const DevScene & sc, const DevParams & P, const WaveBuffe
             if (pending == 0u) { mode = M_DONE; break; }
             level = 31 - __clz((int)pending);
             pending &= ~(1u << level);
-            wframe_load<RING>(B, level, s, f);
+            wframe_load<RING, TEX>(B, level, s, f);
             mode = M_NEXT_CHILD;
         }
     }
@@ -584,7 +637,7 @@ struct QueueEmit {
 };
 
 // One lane per closest-hit result of queue `cur`; appends to queue `cur ^ 1` and to the shadow queue.
-template <bool RING, int BLOCK>
+template <bool RING, int BLOCK, bool TEX>
 __global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, DevParams P, WaveBuffers B, int cur, unsigned int n_closest,
                                                  DevCounters * ctr) {
     __shared__ unsigned int s_cnt[BLOCK / 64 + 1];
@@ -633,7 +686,7 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, DevParams P, WaveB
     }
     QueueEmit<BLOCK> emit = { B, cur ^ 1, s_cnt };
     unsigned int shaded = 0;
-    shade_entry<RING>(sc, P, B, tb, live, s, level, pending, ray_o, ray_d, T, hit, emit, shaded);
+    shade_entry<RING, TEX>(sc, P, B, tb, live, s, level, pending, ray_o, ray_d, T, hit, emit, shaded);
 
     // shaded-hit count: one atomic per workgroup
     {

@@ -84,6 +84,11 @@ struct prt_ctx {
     prt_scene_info info;
     float scene_abs_max = 0.0f;
     bool any_translucent = false;
+    bool textured = false;                // any material has a texture map: the TEX kernel variants run
+    DevBuf<DevTexture> textures;
+    DevBuf<unsigned int> texels;
+    DevBuf<float> srgb_lut;
+    DevBuf<float4> tri_uv, tri_tan;
     std::vector<float> material_ns;      // for rebuilding spec_dirs when spec_samples changes
     unsigned int spec_table_samples = 0;
 
@@ -250,7 +255,7 @@ int chain_setup(prt_ctx * ctx, Chain & c, int index, const DevParams & P, bool r
     c.P = P;
     const size_t N = n_samples;
     const unsigned int levels = std::max(1u, P.bounce_depth);
-    const unsigned int fr4 = ring ? 5u : 4u;
+    const unsigned int fr4 = ctx->textured ? 7u : ring ? 5u : 4u;
     const unsigned int n_lights = std::max(1u, ctx->scene.light_count);
     // float4 slab: frames + 2x3 closest queues + hits + 3 shadow arrays (accum aliases the shared sample_rgb)
     const size_t f4_total = (size_t)levels * fr4 * N + 6 * N + N + 3 * N * n_lights;
@@ -330,12 +335,14 @@ int chain_issue_round(prt_ctx * ctx, Chain & c, const WaveTuning & t) {
     if (c.n_closest) {
         if (t.shade_block == 1024) {
             const unsigned int sgrid = (c.n_closest + 1023) / 1024;
-            if (t.ring) hipLaunchKernelGGL((k_shade<true, 1024>), dim3(sgrid), dim3(1024), 0, stream, ctx->scene, c.P, B, c.cur, c.n_closest, ctx->counters.p);
-            else hipLaunchKernelGGL((k_shade<false, 1024>), dim3(sgrid), dim3(1024), 0, stream, ctx->scene, c.P, B, c.cur, c.n_closest, ctx->counters.p);
+            if (ctx->textured) hipLaunchKernelGGL((k_shade<true, 1024, true>), dim3(sgrid), dim3(1024), 0, stream, ctx->scene, c.P, B, c.cur, c.n_closest, ctx->counters.p);
+            else if (t.ring) hipLaunchKernelGGL((k_shade<true, 1024, false>), dim3(sgrid), dim3(1024), 0, stream, ctx->scene, c.P, B, c.cur, c.n_closest, ctx->counters.p);
+            else hipLaunchKernelGGL((k_shade<false, 1024, false>), dim3(sgrid), dim3(1024), 0, stream, ctx->scene, c.P, B, c.cur, c.n_closest, ctx->counters.p);
         } else {
             const unsigned int sgrid = (c.n_closest + 255) / 256;
-            if (t.ring) hipLaunchKernelGGL((k_shade<true, 256>), dim3(sgrid), dim3(256), 0, stream, ctx->scene, c.P, B, c.cur, c.n_closest, ctx->counters.p);
-            else hipLaunchKernelGGL((k_shade<false, 256>), dim3(sgrid), dim3(256), 0, stream, ctx->scene, c.P, B, c.cur, c.n_closest, ctx->counters.p);
+            if (ctx->textured) hipLaunchKernelGGL((k_shade<true, 256, true>), dim3(sgrid), dim3(256), 0, stream, ctx->scene, c.P, B, c.cur, c.n_closest, ctx->counters.p);
+            else if (t.ring) hipLaunchKernelGGL((k_shade<true, 256, false>), dim3(sgrid), dim3(256), 0, stream, ctx->scene, c.P, B, c.cur, c.n_closest, ctx->counters.p);
+            else hipLaunchKernelGGL((k_shade<false, 256, false>), dim3(sgrid), dim3(256), 0, stream, ctx->scene, c.P, B, c.cur, c.n_closest, ctx->counters.p);
         }
         HIP_TRY(ctx, hipGetLastError());
     }
@@ -452,12 +459,12 @@ int render_wavefront(prt_ctx * ctx, const DevCamera & cam, const DevParams & P, 
 
 // The wave-pool pipeline (kernels_pool.h): one launch; per-sample arrays as in the wavefront pipeline (chain 0's
 // workspace, without the global queues), plus cap (+ cap * lights shadow) ray slots per resident wave.
-template <int BLOCK, int WAVES, bool LDSTAB, bool RING>
+template <int BLOCK, int WAVES, bool LDSTAB, bool RING, bool TEX>
 int launch_pool(prt_ctx * ctx, bool count, const DevCamera & cam, DevParams P, unsigned int n_samples, unsigned int stack_entries) {
     const size_t lds = (size_t)stack_entries * BLOCK * sizeof(int);
     int per_cu = 0;
-    hipError_t oe = count ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_pool<BLOCK, WAVES, LDSTAB, RING, true>, BLOCK, lds)
-                          : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_pool<BLOCK, WAVES, LDSTAB, RING, false>, BLOCK, lds);
+    hipError_t oe = count ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_pool<BLOCK, WAVES, LDSTAB, RING, true, TEX>, BLOCK, lds)
+                          : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_pool<BLOCK, WAVES, LDSTAB, RING, false, TEX>, BLOCK, lds);
     if (oe != hipSuccess || per_cu < 1) per_cu = 1;
     per_cu = std::min(per_cu, 8);
     if (const char * e = getenv("PRT_POOL_BLOCKS_PER_CU")) per_cu = std::max(1, std::min(per_cu, atoi(e)));
@@ -477,7 +484,7 @@ int launch_pool(prt_ctx * ctx, bool count, const DevCamera & cam, DevParams P, u
     prt_ctx::ChainWs & w = ctx->chain[0];
     const size_t N = n_samples;
     const unsigned int levels = std::max(1u, P.bounce_depth);
-    const unsigned int fr4 = RING ? 5u : 4u;
+    const unsigned int fr4 = TEX ? 7u : RING ? 5u : 4u;
     HIP_TRY(ctx, w.f4.ensure((size_t)levels * fr4 * N));
     HIP_TRY(ctx, w.rng.ensure(RING ? 2 * N : N));
     HIP_TRY(ctx, ctx->pool_f4.ensure((size_t)waves * (7u * (size_t)cap + 3u * (size_t)scap)));
@@ -512,10 +519,10 @@ int launch_pool(prt_ctx * ctx, bool count, const DevCamera & cam, DevParams P, u
     if (const char * e = getenv("PRT_NODE_MIN")) node_min = std::max(0, std::min(64, atoi(e)));
     const int multi_light = ctx->scene.light_count > 1 ? 1 : 0;
     if (count)
-        hipLaunchKernelGGL((k_pool<BLOCK, WAVES, LDSTAB, RING, true>), dim3(grid), dim3(BLOCK), lds, ctx->stream, ctx->scene, cam, P, B, Q, keep_min, node_min,
+        hipLaunchKernelGGL((k_pool<BLOCK, WAVES, LDSTAB, RING, true, TEX>), dim3(grid), dim3(BLOCK), lds, ctx->stream, ctx->scene, cam, P, B, Q, keep_min, node_min,
                            multi_light, ctx->counters.p);
     else
-        hipLaunchKernelGGL((k_pool<BLOCK, WAVES, LDSTAB, RING, false>), dim3(grid), dim3(BLOCK), lds, ctx->stream, ctx->scene, cam, P, B, Q, keep_min, node_min,
+        hipLaunchKernelGGL((k_pool<BLOCK, WAVES, LDSTAB, RING, false, TEX>), dim3(grid), dim3(BLOCK), lds, ctx->stream, ctx->scene, cam, P, B, Q, keep_min, node_min,
                            multi_light, ctx->counters.p);
     return 0;
 }
@@ -565,7 +572,9 @@ int render_pixels(prt_ctx * ctx, const prt_camera * cam_in, const prt_params * p
     P.pixel_list = px.d_pixel_list;
 
     const bool count_visits = (params->pipeline & PRT_FLAG_COUNT_VISITS) != 0;
-    const bool ring = ctx->any_translucent || max_rng_draws(P.bounce_depth, P.reflection_samples, P.spec_samples) > 15;
+    // the compact 2-register RNG only covers opaque scenes with <= 15 draws per sample; textured scenes always take the
+    // general variant (an alpha map can make any hit translucent)
+    const bool ring = ctx->any_translucent || ctx->textured || max_rng_draws(P.bounce_depth, P.reflection_samples, P.spec_samples) > 15;
     const int levels = (int)P.bounce_depth + 1;
 
     unsigned int pipeline = params->pipeline & PRT_PIPELINE_MASK;
@@ -579,6 +588,10 @@ int render_pixels(prt_ctx * ctx, const prt_camera * cam_in, const prt_params * p
         pipeline = (unsigned long long)px.n_pixels * params->spp <= pool_max ? PRT_PIPELINE_POOL : PRT_PIPELINE_WAVEFRONT;
     }
     if (pipeline != PRT_PIPELINE_MEGAKERNEL && pipeline != PRT_PIPELINE_WAVEFRONT && pipeline != PRT_PIPELINE_PERSISTENT && pipeline != PRT_PIPELINE_POOL) { ctx->error = "prt_render: unknown pipeline"; return -1; }
+    if (ctx->textured && (pipeline == PRT_PIPELINE_MEGAKERNEL || pipeline == PRT_PIPELINE_PERSISTENT)) {
+        ctx->error = "prt_render: textured scenes run on PRT_PIPELINE_WAVEFRONT / PRT_PIPELINE_POOL (or DEFAULT) only";
+        return -1;
+    }
 
     // Passes.  The per-sample workspace (radiance, RNG, pending frames, ray queues) is 100 B .. 1 KB per sample, so a
     // 4K x 64 spp frame (530 M samples) does not fit any GPU in one piece: the call's pixel set is rendered in passes of
@@ -587,7 +600,7 @@ int render_pixels(prt_ctx * ctx, const prt_camera * cam_in, const prt_params * p
     const unsigned long long total_samples = (unsigned long long)px.n_pixels * P.spp;
     unsigned int pass_pixels = px.n_pixels;
     {
-        const unsigned long long lv = std::max(1u, P.bounce_depth), fr4 = ring ? 5 : 4, nl = std::max(1u, ctx->scene.light_count);
+        const unsigned long long lv = std::max(1u, P.bounce_depth), fr4 = ctx->textured ? 7 : ring ? 5 : 4, nl = std::max(1u, ctx->scene.light_count);
         unsigned long long per_sample = 16 + (ring && pipeline != PRT_PIPELINE_PERSISTENT ? 128 : 0);
         if (pipeline == PRT_PIPELINE_WAVEFRONT) per_sample += (lv * fr4 + 7 + 3 * nl) * 16 + (ring ? 32 : 16) + 4 * (1 + nl);
         if (pipeline == PRT_PIPELINE_POOL) per_sample += lv * fr4 * 16 + (ring ? 32 : 16);
@@ -671,8 +684,9 @@ int render_pixels(prt_ctx * ctx, const prt_camera * cam_in, const prt_params * p
         } else if (pipeline == PRT_PIPELINE_POOL) {
             // 512-thread blocks, 4 waves per SIMD (128 VGPRs), direction table in LDS.  Measured alternatives: 5 waves
             // (96 VGPRs, 93 dwords spilled) 24.2 ms and 6 waves (80 VGPRs, 154 spilled) 29.5 ms against 17.3 ms on a C4 frame.
-            rc = ring ? launch_pool<512, 4, true, true>(ctx, count_visits, cam, P, n_samples, stack_entries)
-                      : launch_pool<512, 4, true, false>(ctx, count_visits, cam, P, n_samples, stack_entries);
+            rc = ctx->textured ? launch_pool<512, 4, true, true, true>(ctx, count_visits, cam, P, n_samples, stack_entries)
+               : ring ? launch_pool<512, 4, true, true, false>(ctx, count_visits, cam, P, n_samples, stack_entries)
+                      : launch_pool<512, 4, true, false, false>(ctx, count_visits, cam, P, n_samples, stack_entries);
             launches += 1;
         } else {
             unsigned long long rays = 0;
@@ -790,6 +804,7 @@ void prt_destroy(prt_ctx * ctx) {
     ctx->nodes.release(); ctx->tris.release(); ctx->shade.release(); ctx->diffuse_dirs.release(); ctx->spec_dirs.release();
     ctx->tri_rank.release(); ctx->materials.release(); ctx->lights.release();
     ctx->sample_rgb.release(); ctx->frame_out.release(); ctx->counters.release(); ctx->ring_ws.release(); ctx->pixel_list.release(); ctx->wf_counts.release(); ctx->stack_spill.release(); ctx->pool_f4.release();
+    ctx->textures.release(); ctx->texels.release(); ctx->srgb_lut.release(); ctx->tri_uv.release(); ctx->tri_tan.release();
     for (int c = 0; c < PRT_MAX_CHAINS; ++c) {
         prt_ctx::ChainWs & w = ctx->chain[c];
         w.f4.release(); w.rng.release(); w.counts.release(); w.overflow.release(); w.slow_stack.release();
@@ -836,13 +851,25 @@ int prt_upload_scene(prt_ctx * ctx, const prt_scene_desc * s) {
             return -1;
         }
     }
+    bool textured = false, bumped = false;
     for (uint32_t m = 0; m < s->material_count; ++m) {
         const prt_material & pm = s->materials[m];
-        if (pm.ambient_texture >= 0 || pm.diffuse_texture >= 0 || pm.specular_texture >= 0 || pm.alpha_texture >= 0 || pm.bump_texture >= 0) {
-            ctx->error = "prt_upload_scene: textured materials are not supported yet (SURVEY.md §8f N1)";
-            return -4;
+        const int32_t slots[5] = { pm.ambient_texture, pm.diffuse_texture, pm.specular_texture, pm.alpha_texture, pm.bump_texture };
+        for (int k = 0; k < 5; ++k) {
+            if (slots[k] < 0) continue;
+            textured = true;
+            if (k == 4) bumped = true;
+            if (!s->textures || (uint32_t)slots[k] >= s->texture_count) { ctx->error = "prt_upload_scene: material texture slot out of range"; return -1; }
+            const prt_texture & t = s->textures[slots[k]];
+            // size - 2 is the sampling scale (texture.cpp:63-64): below 2 it wraps around as u32 in the reference
+            if (!t.texels || t.size_x < 2 || t.size_y < 2 || t.channels < 1 || t.channels > 4) {
+                ctx->error = "prt_upload_scene: texture needs texels, 1..4 channels and at least 2 x 2 texels";
+                return -1;
+            }
         }
     }
+    if (textured && s->texture_count >= DEV_TEX_NONE) { ctx->error = "prt_upload_scene: more than 65534 textures"; return -1; }
+    if (bumped && !s->tangents) { ctx->error = "prt_upload_scene: a material has a bump map but the scene has no tangents"; return -1; }
 
     // ---- BVH over un-indexed triangles
     auto t0 = std::chrono::steady_clock::now();
@@ -902,6 +929,8 @@ int prt_upload_scene(prt_ctx * ctx, const prt_scene_desc * s) {
     const uint32_t n_rec = n_tris + 1;                              // + the all-zero dummy triangle empty BVH slots point at
     std::vector<float4> tris((size_t)n_rec * 3, make_float4(0, 0, 0, 0)), shade((size_t)n_rec * 4, make_float4(0, 0, 0, 0));
     std::vector<unsigned int> rank(n_rec, 0);
+    std::vector<float4> tri_uv(textured ? (size_t)n_rec * 2 : 0, make_float4(0, 0, 0, 0));
+    std::vector<float4> tri_tan(bumped ? (size_t)n_rec * 3 : 0, make_float4(0, 0, 0, 0));
     float abs_max = 0.0f;
     for (uint32_t slot = 0; slot < n_tris; ++slot) {
         const uint32_t t = bvh.tri_order[slot];
@@ -923,10 +952,21 @@ int prt_upload_scene(prt_ctx * ctx, const prt_scene_desc * s) {
         shade[(size_t)slot * 4 + 0] = make_float4(n0[0], n0[1], n0[2], n1[0]);
         shade[(size_t)slot * 4 + 1] = make_float4(n1[1], n1[2], n2[0], n2[1]);
         // the geometric normal n = Cross(ab, ac) rides in the shading record too, so a shaded hit costs ONE 64 B
-        // gather instead of two (texcoords will get their own array with the texture path)
+        // gather instead of two; texture coordinates and tangents have their own arrays, only for textured scenes
         shade[(size_t)slot * 4 + 2] = make_float4(n2[2], n.x, n.y, n.z);
         shade[(size_t)slot * 4 + 3] = make_float4(0.0f, 0.0f, 0.0f, mbits);
-        (void)u0; (void)u1; (void)u2;
+        if (textured) {
+            tri_uv[(size_t)slot * 2 + 0] = make_float4(u0[0], u0[1], u1[0], u1[1]);
+            tri_uv[(size_t)slot * 2 + 1] = make_float4(u2[0], u2[1], 0.0f, 0.0f);
+        }
+        if (bumped) {                                             // mesh->tangents[idx_normals[...]], raytracer.cpp:470-473
+            const float * g0 = s->tangents + 3 * (size_t)s->idx_normals[3 * t + 0];
+            const float * g1 = s->tangents + 3 * (size_t)s->idx_normals[3 * t + 1];
+            const float * g2 = s->tangents + 3 * (size_t)s->idx_normals[3 * t + 2];
+            tri_tan[(size_t)slot * 3 + 0] = make_float4(g0[0], g0[1], g0[2], g1[0]);
+            tri_tan[(size_t)slot * 3 + 1] = make_float4(g1[1], g1[2], g2[0], g2[1]);
+            tri_tan[(size_t)slot * 3 + 2] = make_float4(g2[2], 0.0f, 0.0f, 0.0f);
+        }
         rank[slot] = rank_of_input[t];
         for (int k = 0; k < 9; ++k) abs_max = std::max(abs_max, fabsf(verts[(size_t)t * 9 + k]));
     }
@@ -942,8 +982,44 @@ int prt_upload_scene(prt_ctx * ctx, const prt_scene_desc * s) {
         d.specular_intensity = pm.specular_intensity;
         d.index_of_refraction = pm.index_of_refraction;
         d.alpha = pm.alpha;
+        auto slot16 = [](int32_t v) { return v < 0 ? (unsigned int)DEV_TEX_NONE : (unsigned int)v; };
+        d.tex[0] = slot16(pm.ambient_texture) | slot16(pm.diffuse_texture) << 16;
+        d.tex[1] = slot16(pm.specular_texture) | slot16(pm.alpha_texture) << 16;
+        d.tex[2] = slot16(pm.bump_texture) | (unsigned int)DEV_TEX_NONE << 16;
         ctx->material_ns[m] = pm.specular_intensity;
         if (!(pm.alpha >= 1.0f)) ctx->any_translucent = true;      // alpha < 1 (or NaN): continuation rays, unbounded draws
+    }
+    // textures: RGBA8 by GetTexel's channel rules (texture.cpp:27-41) + the 256 values Color_SRGBToLinear can take
+    std::vector<DevTexture> dev_tex;
+    std::vector<unsigned int> texel_pool;
+    std::vector<float> lut;
+    if (textured) {
+        dev_tex.resize(s->texture_count);
+        for (uint32_t ti = 0; ti < s->texture_count; ++ti) {
+            const prt_texture & t = s->textures[ti];
+            DevTexture & d = dev_tex[ti];
+            memset(&d, 0, sizeof(d));
+            if (!t.texels || t.size_x < 2 || t.size_y < 2 || t.channels < 1 || t.channels > 4) continue;     // unreferenced and unusable
+            const size_t n = (size_t)t.size_x * t.size_y;
+            if (texel_pool.size() + n >= (1ull << 32)) { ctx->error = "prt_upload_scene: more than 2^32 texels"; return -1; }
+            d.first_texel = (unsigned int)texel_pool.size();
+            d.size_x = t.size_x;
+            d.size_y = t.size_y;
+            texel_pool.resize(texel_pool.size() + n);
+            unsigned int * out = texel_pool.data() + d.first_texel;
+            for (size_t i = 0; i < n; ++i) {
+                const uint8_t * px = t.texels + i * t.channels;
+                unsigned int r = px[0], g = t.channels >= 2 ? px[1] : 0u, b = t.channels >= 3 ? px[2] : 0u, a = t.channels >= 4 ? px[3] : 255u;
+                if (t.channels == 1) b = g = r;
+                out[i] = r | g << 8 | b << 16 | a << 24;
+            }
+        }
+        lut.resize(256);
+        const float one_over_255 = 1.0f / 255.0f;                  // texture.cpp:15
+        for (int i = 0; i < 256; ++i) {
+            const float srgb = (float)i * one_over_255;
+            lut[i] = srgb <= 0.04045f ? srgb / 12.92f : powf((srgb + 0.055f) / 1.055f, 2.4f);     // color.h:13-21
+        }
     }
     std::vector<DevLight> lights(std::max(1u, s->light_count));
     memset(lights.data(), 0, lights.size() * sizeof(DevLight));
@@ -968,6 +1044,14 @@ int prt_upload_scene(prt_ctx * ctx, const prt_scene_desc * s) {
     HIP_TRY(ctx, ctx->materials.upload(mats));
     HIP_TRY(ctx, ctx->lights.upload(lights));
     HIP_TRY(ctx, ctx->diffuse_dirs.upload(ddirs));
+    ctx->textured = textured;
+    if (textured) {
+        HIP_TRY(ctx, ctx->textures.upload(dev_tex));
+        HIP_TRY(ctx, ctx->texels.upload(texel_pool));
+        HIP_TRY(ctx, ctx->srgb_lut.upload(lut));
+        HIP_TRY(ctx, ctx->tri_uv.upload(tri_uv));
+        if (bumped) HIP_TRY(ctx, ctx->tri_tan.upload(tri_tan));
+    }
 
     DevScene & sc = ctx->scene;
     sc.nodes = ctx->nodes.p;
@@ -981,6 +1065,11 @@ int prt_upload_scene(prt_ctx * ctx, const prt_scene_desc * s) {
     sc.material_count = s->material_count;
     sc.tri_count = n_tris;
     sc.node_count = bvh.node_count;
+    sc.textures = textured ? ctx->textures.p : nullptr;
+    sc.texels = textured ? ctx->texels.p : nullptr;
+    sc.srgb_lut = textured ? ctx->srgb_lut.p : nullptr;
+    sc.tri_uv = textured ? ctx->tri_uv.p : nullptr;
+    sc.tri_tan = bumped ? ctx->tri_tan.p : nullptr;
     ctx->spec_table_samples = 0;
     int rc = build_spec_table(ctx, 1);
     if (rc) return rc;
@@ -994,7 +1083,9 @@ int prt_upload_scene(prt_ctx * ctx, const prt_scene_desc * s) {
     info.tri_record_bytes = 48;
     info.shade_record_bytes = 64;
     info.device_bytes = ctx->nodes.bytes() + ctx->tris.bytes() + ctx->shade.bytes() + ctx->tri_rank.bytes() +
-                        ctx->materials.bytes() + ctx->lights.bytes() + ctx->diffuse_dirs.bytes() + ctx->spec_dirs.bytes();
+                        ctx->materials.bytes() + ctx->lights.bytes() + ctx->diffuse_dirs.bytes() + ctx->spec_dirs.bytes() +
+                        (textured ? ctx->textures.bytes() + ctx->texels.bytes() + ctx->srgb_lut.bytes() + ctx->tri_uv.bytes() : 0) +
+                        (bumped ? ctx->tri_tan.bytes() : 0);
     info.bvh_build_ms = build_ms;
     ctx->has_scene = true;
     return 0;

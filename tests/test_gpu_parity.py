@@ -18,6 +18,7 @@ TOL = 1e-4      # north_star: "per-pixel RGB within 1e-4 of the reference"
 SMALL = ["c1_sphere_plane_256", "c2_cornell_128", "c2_cornell_512_l4", "cornell_point_light_d5",
          "icosphere_l3_two_lights", "terrain64_d3", "terrain192_d2"]
 BIG = ["c3_icosphere_1080p_l24", "c4_terrain1m_1080p_l40", "c5_terrain1m_4k_l120"]
+TEXTURED = ["gallery_160x120", "gallery_two_lights_d4"]       # row N1: ambient / diffuse / specular / alpha / bump maps
 
 
 def _render_fixture(gpu_renderer_factory, name, pipeline=0):
@@ -43,6 +44,51 @@ def test_matches_reference_golden(gpu_renderer_factory, name, pipeline):
     assert ctr.ray_count == int(g["ray_count"]), "ray_count %d != reference %d (max|d|=%g, %d px over tol)" % (
         ctr.ray_count, int(g["ray_count"]), diff.max(), n_bad)
     assert n_bad == 0 and diff.max() <= TOL, "max|dRGB| = %g, %d pixels over %g" % (diff.max(), n_bad, TOL)
+
+
+@pytest.mark.parametrize("pipeline", ["wavefront", "pool"])
+@pytest.mark.parametrize("name", TEXTURED)
+def test_textured_scene_matches_reference_golden(gpu_renderer_factory, name, pipeline):
+    """The texture path against the unmodified reference: bilinear lookups with the (size - 2) scale and flipped v,
+    sRGB decode of all four channels, the specular map REPLACING Ks, alpha maps (holes pass the ray through with
+    its bounce budget, the rest blends), bump-mapped normals that are not renormalised."""
+    g, img, ctr = _render_fixture(gpu_renderer_factory, name, PIPELINES[pipeline])
+    ref = g["rgb"]
+    diff = np.abs(img[:, :, :3] - ref)
+    n_bad = int((diff.max(axis=2) > TOL).sum())
+    assert ctr.ray_count == int(g["ray_count"]), "ray_count %d != reference %d (max|d|=%g, %d px over tol)" % (
+        ctr.ray_count, int(g["ray_count"]), diff.max(), n_bad)
+    assert n_bad == 0 and diff.max() <= TOL, "max|dRGB| = %g, %d pixels over %g" % (diff.max(), n_bad, TOL)
+    assert np.all(img[:, :, 3] == 1.0)
+
+
+def test_textured_scene_shards_passes_and_pipelines_agree(gpu_renderer_factory, monkeypatch):
+    g = load_golden("gallery_160x120")
+    r = gpu_renderer_factory(str(g["scene"]), 0)
+    w, h = int(g["width"]), int(g["height"])
+    cam, p_wave = camera_and_params(g, PIPELINES["wavefront"])
+    cam, p_pool = camera_and_params(g, PIPELINES["pool"])
+    a, ca = r.render(cam, p_wave, w, h)
+    b, cb = r.render(cam, p_pool, w, h)
+    assert ca.ray_count == cb.ray_count == int(g["ray_count"])
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), "single light: both pipelines add in the same order"
+    from par_raytracer_amd import sharding
+    frame = np.zeros((h, w, 4), dtype=np.float32)
+    for k in range(3):
+        frame[sharding.shard_row_list(h, 8, k, 3)] = r.render_shard(cam, p_pool, w, h, 8, k, 3)[0]
+    assert np.array_equal(frame.view(np.uint32), a.reshape(h, w, 4).view(np.uint32))
+    monkeypatch.setenv("PRT_PASS_SAMPLES", "2051")
+    c, cc = r.render(cam, p_wave, w, h)
+    monkeypatch.delenv("PRT_PASS_SAMPLES")
+    assert np.array_equal(a.view(np.uint32), c.view(np.uint32)) and cc.ray_count == ca.ray_count
+
+
+def test_textured_scene_is_refused_by_the_experimental_pipelines(gpu_renderer_factory):
+    g = load_golden("gallery_160x120")
+    r = gpu_renderer_factory(str(g["scene"]), 0)
+    cam, p = camera_and_params(g, PIPELINES["megakernel"])
+    with pytest.raises(RuntimeError, match="textured scenes run on"):
+        r.render(cam, p, 16, 16)
 
 
 @pytest.mark.parametrize("name", ["c2_cornell_128", "terrain64_d3"])
