@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PRT_ABI_VERSION 1
+#define PRT_ABI_VERSION 2
 
 /* ---- scene description: the reference's pointer graph flattened to POD arrays ---------------- */
 
@@ -119,9 +119,17 @@ typedef struct prt_params {
     uint32_t spec_samples;
     uint32_t bounce_depth;
     float background_color[4];
-    uint32_t spp;
+    uint32_t spp;                  /* samples per pixel; in adaptive mode the fixed first part (min_samples, main.cpp:308) */
     uint32_t pipeline;             /* PRT_PIPELINE_* ; 0 = library default */
     uint64_t seed;
+    /* Adaptive sampling (RenderPixel's second loop, main.cpp:245-258), on when max_spp > spp: after `spp` samples with
+     * +-0.5 pixel jitter, samples with +-1 pixel jitter are added until the variance of the samples BEFORE the newest is
+     * <= variance_threshold or max_spp is reached (the reference hard-codes 10, 50 and 0.01).  The reference's quirks are
+     * kept: the newest sample is added to the sum but the sum is divided by the count without it when the rule stops the
+     * loop.  One RNG stream per pixel, seeded with prt_sample_key(seed, pixel, 0), as the loop needs; the fixed mode
+     * (max_spp <= spp) reseeds per sample.  0 / 0.0f = off / the reference's threshold. */
+    uint32_t max_spp;
+    float variance_threshold;
 } prt_params;
 
 /* DEFAULT picks by size: POOL (one launch, wave-private ray pools) up to ~5 M samples per call, WAVEFRONT (one launch

@@ -47,6 +47,11 @@ FIXTURES = {
     # row N1: texture / alpha / bump path (14 texture files in 9 encodings; alpha holes, translucency, bump frames)
     "gallery_160x120": dict(scene="textured_gallery", width=160, height=120, spp=4, lattice=1),
     "gallery_two_lights_d4": dict(scene="textured_gallery", width=96, height=72, spp=2, lattice=1, depth=4, light_mode=1, rs=2, ss=2),
+    # row N4: the reference's adaptive loop (main.cpp:245-258), one RNG stream per pixel; spp = min_samples
+    "cornell_adaptive_4_16": dict(scene="cornell_box", width=96, height=72, spp=4, max_spp=16, lattice=1),
+    "gallery_adaptive_10_50": dict(scene="textured_gallery", width=64, height=48, spp=10, max_spp=50, lattice=1),      # reference defaults
+    "terrain64_adaptive_3_12_d4": dict(scene="terrain_64", width=80, height=60, spp=3, max_spp=12, lattice=1, depth=4, light_mode=1),
+    "c4_terrain1m_adaptive_l60": dict(scene="terrain_1m", width=1920, height=1080, spp=10, max_spp=50, lattice=60),
 }
 
 
@@ -65,12 +70,12 @@ def generate(name: str, cfg: dict, scene_cache: dict) -> None:
                             s.camera_facing, s.fov, bounce_depth=cfg.get("depth", 2),
                             reflection_samples=cfg.get("rs", 1), spec_samples=cfg.get("ss", 1),
                             lattice=cfg["lattice"], light_mode=cfg.get("light_mode", 0), dump_scene=want_dump,
-                            timeout=6 * 3600)
+                            timeout=6 * 3600, adaptive_max=cfg.get("max_spp", 0))
     st = ref["stats"]
     out = dict(
         scene=scene_name, width=cfg["width"], height=cfg["height"], spp=cfg["spp"], lattice=cfg["lattice"],
         bounce_depth=cfg.get("depth", 2), light_mode=cfg.get("light_mode", 0), reflection_samples=cfg.get("rs", 1),
-        spec_samples=cfg.get("ss", 1), seed=seed,
+        spec_samples=cfg.get("ss", 1), seed=seed, max_spp=cfg.get("max_spp", 0),
         camera_position=np.array(s.camera_position, dtype=np.float64), camera_facing=np.array(s.camera_facing, dtype=np.float64),
         fov=float(s.fov),
         rgb=ref["pixels"][:, :, :3].copy(),

@@ -97,7 +97,7 @@ def run_reference(directory: str, obj_name: str, width: int, height: int, spp: i
                   camera_position: Sequence[float], camera_facing: Sequence[float], fov: float = 60.0,
                   bounce_depth: int = 2, reflection_samples: int = 1, spec_samples: int = 1, lattice: int = 1,
                   light_mode: int = 0, render: bool = True, dump_scene: bool = False, kat: bool = False,
-                  timeout: float = 3600.0) -> dict:
+                  timeout: float = 3600.0, adaptive_max: int = 0) -> dict:
     """Run the compiled, unmodified reference through ref_harness.  Returns {'pixels', 'stats', 'scene', 'kat'}."""
     if not have_reference():
         raise RuntimeError("oracle/_ref/ref_harness is not built (needs /root/reference; `make -C oracle ref`)")
@@ -109,6 +109,8 @@ def run_reference(directory: str, obj_name: str, width: int, height: int, spp: i
                "--specular_samples", str(spec_samples),
                "-d", directory.rstrip("/") + "/", "--obj", obj_name, "--spp", str(spp), "--seed", str(seed),
                "--lattice", str(lattice), "--light-mode", str(light_mode), "--stats", os.path.join(tmp, "stats.json")]
+        if adaptive_max:
+            cmd += ["--adaptive", str(adaptive_max)]
         if render:
             cmd += ["--out", os.path.join(tmp, "out.f32")]
         if dump_scene:

@@ -52,6 +52,7 @@ struct Section {
 struct HarnessArgs {
     const char * obj_name = "sponza.obj";
     u32 spp = 1;
+    u32 adaptive_max = 0;            // > spp: the reference's own adaptive loop (main.cpp:245-258), one RNG stream per pixel
     u64 seed = 1234;
     u32 lattice = 1;
     u32 light_mode = 0;
@@ -68,6 +69,7 @@ HarnessArgs ParseHarnessArgs(int argc, char ** argv) {
         bool has_val = i + 1 < argc;
         if (s == "--obj" && has_val) a.obj_name = argv[++i];
         else if (s == "--spp" && has_val) a.spp = (u32)atoi(argv[++i]);
+        else if (s == "--adaptive" && has_val) a.adaptive_max = (u32)atoi(argv[++i]);
         else if (s == "--seed" && has_val) a.seed = strtoull(argv[++i], NULL, 0);
         else if (s == "--lattice" && has_val) a.lattice = (u32)atoi(argv[++i]);
         else if (s == "--light-mode" && has_val) a.light_mode = (u32)atoi(argv[++i]);
@@ -401,6 +403,15 @@ int main(int argc, char ** argv) {
             for (u32 lx = 0; lx < lw; ++lx) {
                 u32 x = lx * args.lattice, y = ly * args.lattice;
                 u32 pixel = y * w + x;
+                if (args.adaptive_max > args.spp) {
+                    // adaptive mode: RenderPixel exactly as main.cpp:224-265 runs it (min_samples fixed samples, then
+                    // up to max_samples with the variance rule), on one RNG stream seeded per PIXEL
+                    shared.min_samples = args.spp;
+                    shared.max_samples = args.adaptive_max;
+                    Random_Seed(&job.rng, prt_sample_key(args.seed, pixel, 0));
+                    pixels[(size_t)ly * lw + lx] = RenderPixel(&job, &debug, x, y);
+                    continue;
+                }
                 Vector4 sum;
                 for (u32 s = 0; s < args.spp; ++s) {
                     Random_Seed(&job.rng, prt_sample_key(args.seed, pixel, s));

@@ -106,7 +106,9 @@ def make_camera(fov: float, width: int, height: int, position: Sequence[float], 
 
 
 def default_params(spp: int, seed: int = 1234, bounce_depth: Optional[int] = None, reflection_samples: Optional[int] = None,
-                   spec_samples: Optional[int] = None, pipeline: int = 0) -> PrtParams:
+                   spec_samples: Optional[int] = None, pipeline: int = 0, max_spp: int = 0,
+                   variance_threshold: float = 0.0) -> PrtParams:
+    """`max_spp` > spp turns on the reference's adaptive loop (main.cpp:245-258): spp fixed samples, then up to max_spp."""
     p = PrtParams()
     capi.host_lib().prt_host_default_params(int(spp), int(seed), C.byref(p))
     if bounce_depth is not None:
@@ -116,6 +118,8 @@ def default_params(spp: int, seed: int = 1234, bounce_depth: Optional[int] = Non
     if spec_samples is not None:
         p.spec_samples = int(spec_samples)
     p.pipeline = int(pipeline)
+    p.max_spp = int(max_spp)
+    p.variance_threshold = float(variance_threshold)
     return p
 
 

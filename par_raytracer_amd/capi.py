@@ -67,7 +67,7 @@ class PrtCamera(C.Structure):
 class PrtParams(C.Structure):
     _fields_ = [("ray_bias", C.c_float), ("reflection_samples", C.c_uint32), ("spec_samples", C.c_uint32),
                 ("bounce_depth", C.c_uint32), ("background_color", c_float4), ("spp", C.c_uint32),
-                ("pipeline", C.c_uint32), ("seed", C.c_uint64)]
+                ("pipeline", C.c_uint32), ("seed", C.c_uint64), ("max_spp", C.c_uint32), ("variance_threshold", C.c_float)]
 
 
 class PrtCounters(C.Structure):

@@ -52,6 +52,7 @@ void InitParams(int argc, char ** argv) {
     // The reference hard-codes these (adaptive 10..50 spp main.cpp:308-309, seed table main.cpp:9-67,
     // "sponza.obj" main.cpp:553).  BASELINE's "N spp" is min_samples = max_samples = N.
     gParams.spp = 8;
+    gParams.max_spp = 0;
     gParams.seed = 1234;
     gParams.obj_filename = strdup("sponza.obj");
     gParams.pipeline = 0;
@@ -59,6 +60,7 @@ void InitParams(int argc, char ** argv) {
     for (int i = 1; i < argc; ++i) {
         const char * arg = argv[i];
         if (FlagIs("--spp", arg)) { gParams.spp = ArgU32(argc, argv, i); ++i; }
+        else if (FlagIs("--max_spp", arg)) { gParams.max_spp = ArgU32(argc, argv, i); ++i; }
         else if (FlagIs("--seed", arg)) { if (i + 1 >= argc) Die(); gParams.seed = strtoull(argv[i + 1], NULL, 0); ++i; }
         else if (FlagIs("--obj", arg)) { if (i + 1 >= argc) Die(); ReplaceString(&gParams.obj_filename, argv[i + 1]); ++i; }
         else if (FlagIs("--pipeline", arg)) { gParams.pipeline = ArgU32(argc, argv, i); ++i; }
@@ -294,5 +296,7 @@ prt_params ToPrtParams(const GlobalParams * p) {
     o.spp = p->spp;
     o.pipeline = p->pipeline;
     o.seed = p->seed;
+    o.max_spp = p->max_spp;
+    o.variance_threshold = 0.0f;                          // the reference's 0.01 (main.cpp:254)
     return o;
 }

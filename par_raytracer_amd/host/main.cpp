@@ -3,7 +3,7 @@
 //   InitParams -> MakeCamera -> ParseOBJ -> CalculateTangents -> BuildHierarchy -> InitScene ->
 //   object list -> Render -> WriteFramebufferImage
 //
-// Same flags as the reference (prefix matching included) plus --spp N, --seed S, --obj FILE, --gpus N,
+// Same flags as the reference (prefix matching included) plus --spp N, --max_spp M (adaptive mode), --seed S, --obj FILE, --gpus N,
 // --pipeline P, which replace what the reference hard-codes (adaptive 10..50 spp, rank-indexed seed
 // table, "sponza.obj", MPI rank count).  MPI is gone: one process drives all GPUs of the node.
 #include <cstdio>

@@ -126,6 +126,7 @@ struct GlobalParams {               // globals.h:9-22 (the reference's anonymous
     u32 image_height;
     // additions (no reference flag exists for these; SURVEY.md §5 "Config / flags")
     u32 spp;
+    u32 max_spp;                    // > spp: the reference's adaptive mode (main.cpp:245-258, it hard-codes 10 / 50)
     u64 seed;
     char * obj_filename;
     u32 pipeline;

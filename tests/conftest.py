@@ -77,7 +77,7 @@ def camera_and_params(g, pipeline: int = 0):
     cam = api.make_camera(float(g["fov"]), int(g["width"]), int(g["height"]), g["camera_position"], g["camera_facing"])
     p = api.default_params(int(g["spp"]), int(g["seed"]), bounce_depth=int(g["bounce_depth"]),
                            reflection_samples=int(g["reflection_samples"]), spec_samples=int(g["spec_samples"]),
-                           pipeline=pipeline)
+                           pipeline=pipeline, max_spp=int(g["max_spp"]) if "max_spp" in g else 0)
     return cam, p
 
 
