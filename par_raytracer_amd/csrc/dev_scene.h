@@ -111,6 +111,9 @@ struct DevParams {
     int * stack_spill;
     unsigned int stack_lds_entries, stack_spill_stride;
     unsigned int local_base;                    // large calls run in passes of bounded workspace (prt_api.hip render_pixels)
+    // adaptive sampling (main.cpp:245-258): on when max_spp > spp; k_pool<ADAPT> only
+    unsigned int max_spp;
+    float variance_threshold;
 };
 
 PRT_HD unsigned int pixel_of_local(const DevParams & P, unsigned int lp) {

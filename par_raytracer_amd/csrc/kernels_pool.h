@@ -35,13 +35,20 @@ struct PoolBuffers {
     unsigned int * head;         // global sample counter
     unsigned int cap, scap;      // slots per wave; multiples of 64
     unsigned int topup_min;      // top up when at least this many slots are free
+    // adaptive mode (k_pool<ADAPT>): the unit in the pool is a PIXEL that runs its samples one after the other
+    unsigned int * fin;          // [waves][cap]         pixels whose current sample has no ray left; finalised after the next trace phase
+    float4 * scratch;            // [max_spp][n_pixels]  every sample's colour (RenderPixel's scratch_buffer, main.cpp:232)
+    float4 * jobsum;             // [n_pixels]           (running colour sum .xyz, samples finished so far as int bits)
+    float4 * final_rgb;          // [n_pixels]           the pixel's colour when it is done
 };
 
 // Emitter of k_pool: appends to the wave's private lists, slots by rank among the appending lanes.
+template <bool ADAPT>
 struct PoolEmit {
     float4 * co, * cd, * ct;     // next closest list
     float4 * so, * sc, * sd;     // next shadow list
-    unsigned int m_c, m_s;       // wave-uniform fill counts
+    unsigned int * fin;          // ADAPT: pixels to finalise after the next trace phase
+    unsigned int m_c, m_s, m_f;  // wave-uniform fill counts
     PRT_D void shadow(bool want, unsigned int s, f3 o, f3 d, f3 contrib, float w, int kind) {
         const unsigned long long mask = __ballot(want);
         const unsigned int prefix = __builtin_amdgcn_mbcnt_hi((unsigned int)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)mask, 0u));
@@ -53,7 +60,13 @@ struct PoolEmit {
         }
         m_s += (unsigned int)__popcll(mask);
     }
-    PRT_D void closest(bool want, unsigned int s, f3 o, f3 d, f3 T, int level, unsigned int pending) {
+    PRT_D void closest(bool want, unsigned int s, f3 o, f3 d, f3 T, int level, unsigned int pending, bool sample_ended) {
+        if (ADAPT) {
+            const unsigned long long ended = __ballot(sample_ended);
+            const unsigned int rank = __builtin_amdgcn_mbcnt_hi((unsigned int)(ended >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)ended, 0u));
+            if (sample_ended) fin[m_f + rank] = s;
+            m_f += (unsigned int)__popcll(ended);
+        }
         const unsigned long long mask = __ballot(want);
         const unsigned int prefix = __builtin_amdgcn_mbcnt_hi((unsigned int)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)mask, 0u));
         if (want) {
@@ -69,7 +82,7 @@ struct PoolEmit {
 PRT_D void pool_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }
 
 // grid = resident blocks; dynamic LDS = stack_entries * BLOCK * 4 (traversal stack columns).
-template <int BLOCK, int WAVES, bool LDSTAB, bool RING, bool COUNT, bool TEX>
+template <int BLOCK, int WAVES, bool LDSTAB, bool RING, bool COUNT, bool TEX, bool ADAPT>
 __global__ __launch_bounds__(BLOCK, WAVES) void k_pool(DevScene sc, DevCamera cam, DevParams P, WaveBuffers B, PoolBuffers Q, int keep_min,
                                                  int node_min, int multi_light, DevCounters * ctr) {
     extern __shared__ int s_stack[];
@@ -114,6 +127,9 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_pool(DevScene sc, DevCamera ca
     float4 * const sq_c = sq_o + scap;
     float4 * const sq_d = sq_c + scap;
 
+    unsigned int * const fin = ADAPT ? Q.fin + (size_t)wave * cap : nullptr;
+    unsigned int n_f = 0;                      // wave-uniform (ADAPT): pixels waiting to be finalised
+
     int cur = 0;
     unsigned int n_c = 0, n_s = 0;             // wave-uniform: rays in the current closest / shadow list
     bool fetch_done = false;                   // wave-uniform: the sample counter ran past n_samples
@@ -128,8 +144,8 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_pool(DevScene sc, DevCamera ca
         float4 * const ct = cd + cap;
 
         // ---- top up: fresh samples into the free closest-hit slots ------------------------------------------
-        if (!fetch_done && n_c + Q.topup_min <= cap) {
-            const unsigned int want = cap - n_c;
+        if (!fetch_done && n_c + n_f + Q.topup_min <= cap) {
+            const unsigned int want = cap - n_c - n_f;
             unsigned int base = 0;
             if (lane == 0) base = atomicAdd(Q.head, want);
             base = (unsigned int)__builtin_amdgcn_readfirstlane((int)base);
@@ -144,7 +160,13 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_pool(DevScene sc, DevCamera ca
                     SampleState S;
                     Frame fr;
                     u64 * ring = RING ? B.ring + sid : nullptr;
-                    sample_begin<RING>(cam, P, pixel_of_local(P, gsid / P.spp), gsid % P.spp, S, fr, ring, B.n_samples);
+                    if (ADAPT) {
+                        // the unit is the pixel: one RNG stream, key of sample 0 (include/prt.h prt_params::max_spp)
+                        sample_begin<RING>(cam, P, pixel_of_local(P, gsid), 0u, S, fr, ring, B.n_samples);
+                        Q.jobsum[sid] = make_float4(0.0f, 0.0f, 0.0f, as_f(0));
+                    } else {
+                        sample_begin<RING>(cam, P, pixel_of_local(P, gsid / P.spp), gsid % P.spp, S, fr, ring, B.n_samples);
+                    }
                     B.rng[sid] = make_ulonglong2(S.rng.chain, S.rng.prev);
                     if (RING) B.rng_aux[sid] = make_ulonglong2(S.rng.seed0, (u64)S.rng.k);
                     B.accum[sid] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -156,7 +178,7 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_pool(DevScene sc, DevCamera ca
             }
         }
         const unsigned int total = n_c + n_s;
-        if (total == 0u) {
+        if (total == 0u && n_f == 0u) {
             if (fetch_done) break;
             continue;
         }
@@ -257,12 +279,75 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_pool(DevScene sc, DevCamera ca
         // ---- shade: every closest hit of the pool, 64 per pass ----------------------------------------------
         {
             const int nxt = cur ^ 1;
-            PoolEmit emit;
+            PoolEmit<ADAPT> emit;
             emit.co = cq_base + (size_t)nxt * 3u * cap;
             emit.cd = emit.co + cap;
             emit.ct = emit.cd + cap;
             emit.so = sq_o; emit.sc = sq_c; emit.sd = sq_d;
-            emit.m_c = 0; emit.m_s = 0;
+            emit.fin = fin;
+            emit.m_c = 0; emit.m_s = 0; emit.m_f = 0;
+            if (ADAPT) {
+                // ---- finalise: pixels whose sample ended one round ago; its last shadow rays have landed by now.
+                // RenderPixel's loops (main.cpp:236-258) one step at a time: store the sample, apply the stopping rule,
+                // start the next sample on the same RNG stream.
+                const size_t n_px = B.n_samples;
+                for (unsigned int b0 = 0; b0 < n_f; b0 += 64u) {
+                    const unsigned int i = b0 + lane;
+                    const bool live = i < n_f;
+                    bool go_on = false;
+                    unsigned int j = 0;
+                    f3 ray_o = mk3(0, 0, 0), ray_d = mk3(0, 0, 1);
+                    if (live) {
+                        j = fin[i];
+                        const float4 a = B.accum[j], st = Q.jobsum[j];
+                        unsigned int samp = (unsigned int)as_i(st.w);              // index of the sample that just ended
+                        const f3 sum_prev = mk3(st.x, st.y, st.z);
+                        const f3 c = mk3(a.x, a.y, a.z);
+                        Q.scratch[(size_t)samp * n_px + j] = make_float4(c.x, c.y, c.z, 0.0f);
+                        const f3 sum = sum_prev + c;                                // color += scratch_buffer[samp]
+                        bool stop = false;
+                        if (samp >= P.spp) {                                        // second loop: CalculateVariance(scratch, samp), main.cpp:253
+                            const f3 mean = sum_prev / (float)samp;                 // the mean's running sum IS the colour sum so far
+                            float variance = 0.0f;
+                            for (unsigned int k = 0; k < samp; ++k) {
+                                const float4 v = Q.scratch[(size_t)k * n_px + j];
+                                const float d = (fabsf(v.x - mean.x) + fabsf(v.y - mean.y)) + fabsf(v.z - mean.z);   // main.cpp:179-186
+                                variance += d * d;
+                            }
+                            variance /= (float)(samp - 1u);
+                            stop = variance <= P.variance_threshold;                // break BEFORE ++samp: the divisor misses this sample
+                        }
+                        if (!stop) {
+                            ++samp;
+                            stop = samp >= P.max_spp;
+                        }
+                        if (stop) {
+                            const f3 out = sum / (float)samp;                       // color /= samp, main.cpp:262
+                            Q.final_rgb[j] = make_float4(out.x, out.y, out.z, 1.0f);
+                        } else {
+                            Q.jobsum[j] = make_float4(sum.x, sum.y, sum.z, as_f((int)samp));
+                            B.accum[j] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                            Rng rng;
+                            const ulonglong2 rs = B.rng[j], ra = B.rng_aux[j];
+                            rng.chain = rs.x; rng.prev = rs.y; rng.seed0 = ra.x; rng.k = (u32)ra.y;
+                            u64 * ring = B.ring + j;
+                            const float off_y = rng_float11<true>(rng, ring, n_px);  // first draw -> .y (main.cpp:238, 247)
+                            const float off_x = rng_float11<true>(rng, ring, n_px);
+                            B.rng[j] = make_ulonglong2(rng.chain, rng.prev);
+                            B.rng_aux[j] = make_ulonglong2(rng.seed0, (u64)rng.k);
+                            const float jitter = samp < P.spp ? 0.5f : 1.0f;        // main.cpp:240 vs :249
+                            const unsigned int pixel = pixel_of_local(P, B.sample_base + j);
+                            const unsigned int x = pixel % P.width, y = pixel / P.width;
+                            ray_o = cam.position;
+                            ray_d = make_camera_dir(cam, (float)x + off_x * jitter, (float)y + off_y * jitter);
+                            go_on = true;
+                        }
+                    }
+                    emit.closest(go_on, j, ray_o, ray_d, mk3(1.0f, 1.0f, 1.0f), 0, 0u, false);
+                }
+                emit.m_f = 0;                                                       // the list is consumed; shading refills it from 0
+                pool_fence();
+            }
             for (unsigned int b0 = 0; b0 < n_c; b0 += 64u) {
                 const unsigned int i = b0 + lane;
                 const bool live = i < n_c;
@@ -288,6 +373,7 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_pool(DevScene sc, DevCamera ca
             }
             n_c = emit.m_c;
             n_s = emit.m_s;
+            n_f = emit.m_f;
             cur = nxt;
         }
         pool_fence();

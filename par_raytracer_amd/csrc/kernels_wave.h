@@ -372,7 +372,8 @@ struct ShadeTables {
 
 // One closest-hit result -> the sample's next rays.  `live` lanes process (s, level, pending, ray, T, hit); every
 // lane of the calling group must call it (the emitter aggregates appends).  emit.shadow(...) is called once per
-// light by every lane, emit.closest(...) once at the end.
+// light by every lane, emit.closest(...) once at the end (its last argument tells the emitter that this lane's
+// sample has no ray left - the adaptive mode of k_pool starts the pixel's next sample from there).
 template <bool RING, bool TEX, class Emit>
 PRT_D void shade_entry(const DevScene & sc, const DevParams & P, const WaveBuffers & B, const ShadeTables & tb, bool live,
                        unsigned int s, int level, unsigned int pending, f3 ray_o, f3 ray_d, f3 T, const HitRec & hit, Emit & emit,
@@ -609,7 +610,7 @@ PRT_D void shade_entry(const DevScene & sc, const DevParams & P, const WaveBuffe
         B.rng[s] = make_ulonglong2(rng.chain, rng.prev);
         if (RING) B.rng_aux[s] = make_ulonglong2(rng.seed0, (u64)rng.k);
     }
-    emit.closest(emit_closest, s, next_o, next_d, next_T, next_level, pending);
+    emit.closest(emit_closest, s, next_o, next_d, next_T, next_level, pending, live && !emit_closest);
 }
 
 // Emitter of k_shade: workgroup-aggregated appends to the global next-round queues.
@@ -626,7 +627,7 @@ struct QueueEmit {
             B.sq_c[slot] = make_float4(contrib.x, contrib.y, contrib.z, w);      // w >= 0: point light distance^2; < 0: -(light + 1)
         }
     }
-    PRT_D void closest(bool want, unsigned int s, f3 o, f3 d, f3 T, int level, unsigned int pending) const {
+    PRT_D void closest(bool want, unsigned int s, f3 o, f3 d, f3 T, int level, unsigned int pending, bool /*sample_ended*/) const {
         const unsigned int slot = block_append<BLOCK / 64>(B.counts + 0, want, s_cnt);
         if (want) {
             B.rq_o[nxt][slot] = make_float4(o.x, o.y, o.z, as_f((int)s));

@@ -113,6 +113,8 @@ struct prt_ctx {
     } chain[PRT_MAX_CHAINS];
     DevBuf<unsigned int> wf_counts;       // persistent / pool pipelines' sample counter
     DevBuf<float4> pool_f4;               // pool pipeline: the waves' private ray lists
+    DevBuf<unsigned int> pool_fin;        // adaptive mode: per-wave lists of pixels to finalise
+    DevBuf<float4> adapt_f4;              // adaptive mode: scratch [max_spp][n] + running sums [n] + final colours [n]
     int cu_count = 0;
     unsigned int stack_bound = 0;
     DevBuf<int> stack_spill;
@@ -459,12 +461,12 @@ int render_wavefront(prt_ctx * ctx, const DevCamera & cam, const DevParams & P, 
 
 // The wave-pool pipeline (kernels_pool.h): one launch; per-sample arrays as in the wavefront pipeline (chain 0's
 // workspace, without the global queues), plus cap (+ cap * lights shadow) ray slots per resident wave.
-template <int BLOCK, int WAVES, bool LDSTAB, bool RING, bool TEX>
+template <int BLOCK, int WAVES, bool LDSTAB, bool RING, bool TEX, bool ADAPT>
 int launch_pool(prt_ctx * ctx, bool count, const DevCamera & cam, DevParams P, unsigned int n_samples, unsigned int stack_entries) {
     const size_t lds = (size_t)stack_entries * BLOCK * sizeof(int);
     int per_cu = 0;
-    hipError_t oe = count ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_pool<BLOCK, WAVES, LDSTAB, RING, true, TEX>, BLOCK, lds)
-                          : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_pool<BLOCK, WAVES, LDSTAB, RING, false, TEX>, BLOCK, lds);
+    hipError_t oe = count ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_pool<BLOCK, WAVES, LDSTAB, RING, true, TEX, ADAPT>, BLOCK, lds)
+                          : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_pool<BLOCK, WAVES, LDSTAB, RING, false, TEX, ADAPT>, BLOCK, lds);
     if (oe != hipSuccess || per_cu < 1) per_cu = 1;
     per_cu = std::min(per_cu, 8);
     if (const char * e = getenv("PRT_POOL_BLOCKS_PER_CU")) per_cu = std::max(1, std::min(per_cu, atoi(e)));
@@ -512,6 +514,16 @@ int launch_pool(prt_ctx * ctx, bool count, const DevCamera & cam, DevParams P, u
     Q.head = ctx->wf_counts.p;
     Q.cap = cap;
     Q.scap = scap;
+    Q.fin = nullptr; Q.scratch = nullptr; Q.jobsum = nullptr; Q.final_rgb = nullptr;
+    if (ADAPT) {
+        // n_samples counts PIXELS here: the unit in the pool is a pixel that runs its samples one after the other
+        HIP_TRY(ctx, ctx->pool_fin.ensure((size_t)waves * cap));
+        HIP_TRY(ctx, ctx->adapt_f4.ensure(((size_t)P.max_spp + 2u) * N));
+        Q.fin = ctx->pool_fin.p;
+        Q.scratch = ctx->adapt_f4.p;
+        Q.jobsum = Q.scratch + (size_t)P.max_spp * N;
+        Q.final_rgb = Q.jobsum + N;
+    }
     Q.topup_min = std::max(64u, cap / 4u);
     if (const char * e = getenv("PRT_POOL_TOPUP")) Q.topup_min = (unsigned int)std::max(1, std::min((int)cap, atoi(e)));
     int keep_min = 40, node_min = 32;
@@ -519,10 +531,10 @@ int launch_pool(prt_ctx * ctx, bool count, const DevCamera & cam, DevParams P, u
     if (const char * e = getenv("PRT_NODE_MIN")) node_min = std::max(0, std::min(64, atoi(e)));
     const int multi_light = ctx->scene.light_count > 1 ? 1 : 0;
     if (count)
-        hipLaunchKernelGGL((k_pool<BLOCK, WAVES, LDSTAB, RING, true, TEX>), dim3(grid), dim3(BLOCK), lds, ctx->stream, ctx->scene, cam, P, B, Q, keep_min, node_min,
+        hipLaunchKernelGGL((k_pool<BLOCK, WAVES, LDSTAB, RING, true, TEX, ADAPT>), dim3(grid), dim3(BLOCK), lds, ctx->stream, ctx->scene, cam, P, B, Q, keep_min, node_min,
                            multi_light, ctx->counters.p);
     else
-        hipLaunchKernelGGL((k_pool<BLOCK, WAVES, LDSTAB, RING, false, TEX>), dim3(grid), dim3(BLOCK), lds, ctx->stream, ctx->scene, cam, P, B, Q, keep_min, node_min,
+        hipLaunchKernelGGL((k_pool<BLOCK, WAVES, LDSTAB, RING, false, TEX, ADAPT>), dim3(grid), dim3(BLOCK), lds, ctx->stream, ctx->scene, cam, P, B, Q, keep_min, node_min,
                            multi_light, ctx->counters.p);
     return 0;
 }
@@ -560,6 +572,9 @@ int render_pixels(prt_ctx * ctx, const prt_camera * cam_in, const prt_params * p
     P.background = mk3(params->background_color[0], params->background_color[1], params->background_color[2]);
     P.spp = params->spp;
     P.seed = params->seed;
+    const bool adaptive = params->max_spp > params->spp;            // RenderPixel's second loop (main.cpp:245-258)
+    P.max_spp = adaptive ? params->max_spp : params->spp;
+    P.variance_threshold = params->variance_threshold > 0.0f ? params->variance_threshold : 0.01f;    // main.cpp:254
     P.width = width;
     P.height = height;
     float extent = ctx->scene_abs_max;
@@ -574,10 +589,17 @@ int render_pixels(prt_ctx * ctx, const prt_camera * cam_in, const prt_params * p
     const bool count_visits = (params->pipeline & PRT_FLAG_COUNT_VISITS) != 0;
     // the compact 2-register RNG only covers opaque scenes with <= 15 draws per sample; textured scenes always take the
     // general variant (an alpha map can make any hit translucent)
-    const bool ring = ctx->any_translucent || ctx->textured || max_rng_draws(P.bounce_depth, P.reflection_samples, P.spec_samples) > 15;
+    const bool ring = adaptive || ctx->any_translucent || ctx->textured || max_rng_draws(P.bounce_depth, P.reflection_samples, P.spec_samples) > 15;
     const int levels = (int)P.bounce_depth + 1;
 
     unsigned int pipeline = params->pipeline & PRT_PIPELINE_MASK;
+    if (adaptive) {
+        // a pixel's samples form a chain on one RNG stream with a data-dependent length: only the pool pipeline, whose
+        // work items carry their own state machine, runs it
+        if (pipeline != PRT_PIPELINE_DEFAULT && pipeline != PRT_PIPELINE_POOL) { ctx->error = "prt_render: adaptive sampling (max_spp > spp) runs on PRT_PIPELINE_POOL (or DEFAULT) only"; return -1; }
+        if (params->max_spp > 4096) { ctx->error = "prt_render: max_spp above 4096 is not supported"; return -1; }
+        pipeline = PRT_PIPELINE_POOL;
+    }
     if (pipeline == PRT_PIPELINE_DEFAULT) {
         // Measured on MI355X (tools/pool_cross.py, tools/pool_scene_cross.py): the wavefront pipeline's steady state is
         // ~15 % faster (its k_trace runs 6 waves per SIMD, k_pool 4), but each of its ~8 rounds costs a launch ramp, a
@@ -597,13 +619,15 @@ int render_pixels(prt_ctx * ctx, const prt_camera * cam_in, const prt_params * p
     // 4K x 64 spp frame (530 M samples) does not fit any GPU in one piece: the call's pixel set is rendered in passes of
     // whole pixels, each at most 64 M samples and at most 64 GB of workspace (PRT_PASS_SAMPLES / PRT_PASS_MB override).
     // One pass for everything up to 4K x 8 spp.
-    const unsigned long long total_samples = (unsigned long long)px.n_pixels * P.spp;
+    const unsigned int unit_spp = adaptive ? 1u : P.spp;            // work items per pixel: samples, or the pixel itself
+    const unsigned long long total_samples = (unsigned long long)px.n_pixels * unit_spp;
     unsigned int pass_pixels = px.n_pixels;
     {
         const unsigned long long lv = std::max(1u, P.bounce_depth), fr4 = ctx->textured ? 7 : ring ? 5 : 4, nl = std::max(1u, ctx->scene.light_count);
         unsigned long long per_sample = 16 + (ring && pipeline != PRT_PIPELINE_PERSISTENT ? 128 : 0);
         if (pipeline == PRT_PIPELINE_WAVEFRONT) per_sample += (lv * fr4 + 7 + 3 * nl) * 16 + (ring ? 32 : 16) + 4 * (1 + nl);
         if (pipeline == PRT_PIPELINE_POOL) per_sample += lv * fr4 * 16 + (ring ? 32 : 16);
+        if (adaptive) per_sample += ((unsigned long long)P.max_spp + 2) * 16;
         if (pipeline == PRT_PIPELINE_MEGAKERNEL && ctx->stack_bound > 24) per_sample += 4ull * ctx->stack_bound;
         unsigned long long max_samples = 64ull << 20, max_mb = 64ull << 10;
         if (const char * e = getenv("PRT_PASS_SAMPLES")) max_samples = std::max(1ull, strtoull(e, nullptr, 10));
@@ -611,12 +635,12 @@ int render_pixels(prt_ctx * ctx, const prt_camera * cam_in, const prt_params * p
         max_samples = std::min(max_samples, std::max(1ull, (max_mb << 20) / per_sample));
         max_samples = std::min(max_samples, 0x7FFFFFFFull);
         if (total_samples > max_samples) {
-            unsigned long long pp = std::max(1ull, max_samples / P.spp);
+            unsigned long long pp = std::max(1ull, max_samples / unit_spp);
             if (pp > 64) pp = pp / 64 * 64;                                 // passes start on a wave boundary
             pass_pixels = (unsigned int)std::min<unsigned long long>(pp, px.n_pixels);
         }
     }
-    const size_t n_samples64 = (size_t)pass_pixels * P.spp;                 // samples of the largest pass
+    const size_t n_samples64 = (size_t)pass_pixels * unit_spp;              // work items of the largest pass
     if (n_samples64 > 0x7FFFFFFFull) { ctx->error = "prt_render: spp too large for one pixel per pass"; return -1; }
     HIP_TRY(ctx, ctx->sample_rgb.ensure(n_samples64));
     HIP_TRY(ctx, ctx->counters.ensure(1));
@@ -658,7 +682,7 @@ int render_pixels(prt_ctx * ctx, const prt_camera * cam_in, const prt_params * p
     const bool single_launch = pipeline != PRT_PIPELINE_WAVEFRONT;
     for (unsigned int p0 = 0; p0 < px.n_pixels; p0 += pass_pixels) {
         const unsigned int n_px = std::min(pass_pixels, px.n_pixels - p0);
-        const unsigned int n_samples = n_px * P.spp;
+        const unsigned int n_samples = n_px * unit_spp;
         const bool last_pass = p0 + n_px == px.n_pixels;
         P.local_base = p0;
         if (single_launch) HIP_TRY(ctx, hipEventRecord(ctx->ev[2], stream));
@@ -684,9 +708,13 @@ int render_pixels(prt_ctx * ctx, const prt_camera * cam_in, const prt_params * p
         } else if (pipeline == PRT_PIPELINE_POOL) {
             // 512-thread blocks, 4 waves per SIMD (128 VGPRs), direction table in LDS.  Measured alternatives: 5 waves
             // (96 VGPRs, 93 dwords spilled) 24.2 ms and 6 waves (80 VGPRs, 154 spilled) 29.5 ms against 17.3 ms on a C4 frame.
-            rc = ctx->textured ? launch_pool<512, 4, true, true, true>(ctx, count_visits, cam, P, n_samples, stack_entries)
-               : ring ? launch_pool<512, 4, true, true, false>(ctx, count_visits, cam, P, n_samples, stack_entries)
-                      : launch_pool<512, 4, true, false, false>(ctx, count_visits, cam, P, n_samples, stack_entries);
+            if (adaptive)
+                rc = ctx->textured ? launch_pool<512, 4, true, true, true, true>(ctx, count_visits, cam, P, n_samples, stack_entries)
+                                   : launch_pool<512, 4, true, true, false, true>(ctx, count_visits, cam, P, n_samples, stack_entries);
+            else
+                rc = ctx->textured ? launch_pool<512, 4, true, true, true, false>(ctx, count_visits, cam, P, n_samples, stack_entries)
+                   : ring ? launch_pool<512, 4, true, true, false, false>(ctx, count_visits, cam, P, n_samples, stack_entries)
+                          : launch_pool<512, 4, true, false, false, false>(ctx, count_visits, cam, P, n_samples, stack_entries);
             launches += 1;
         } else {
             unsigned long long rays = 0;
@@ -700,7 +728,11 @@ int render_pixels(prt_ctx * ctx, const prt_camera * cam_in, const prt_params * p
         if (rc) return rc;
         HIP_TRY(ctx, hipGetLastError());
         if (single_launch) HIP_TRY(ctx, hipEventRecord(ctx->ev[3], stream));
-        hipLaunchKernelGGL(k_resolve, dim3((n_px + 255) / 256), dim3(256), 0, stream, ctx->sample_rgb.p, d_out + p0, n_px, P.spp);
+        if (adaptive)       // k_pool<ADAPT> has already divided by each pixel's own sample count
+            hipLaunchKernelGGL(k_resolve, dim3((n_px + 255) / 256), dim3(256), 0, stream,
+                               ctx->adapt_f4.p + ((size_t)P.max_spp + 1u) * n_samples, d_out + p0, n_px, 1u);
+        else
+            hipLaunchKernelGGL(k_resolve, dim3((n_px + 255) / 256), dim3(256), 0, stream, ctx->sample_rgb.p, d_out + p0, n_px, P.spp);
         HIP_TRY(ctx, hipGetLastError());
         if (single_launch && (counters || !last_pass)) {
             // the next pass reuses ev[2] / ev[3] (and the workspace is stream ordered anyway): take this pass's time now
@@ -803,7 +835,7 @@ void prt_destroy(prt_ctx * ctx) {
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     ctx->nodes.release(); ctx->tris.release(); ctx->shade.release(); ctx->diffuse_dirs.release(); ctx->spec_dirs.release();
     ctx->tri_rank.release(); ctx->materials.release(); ctx->lights.release();
-    ctx->sample_rgb.release(); ctx->frame_out.release(); ctx->counters.release(); ctx->ring_ws.release(); ctx->pixel_list.release(); ctx->wf_counts.release(); ctx->stack_spill.release(); ctx->pool_f4.release();
+    ctx->sample_rgb.release(); ctx->frame_out.release(); ctx->counters.release(); ctx->ring_ws.release(); ctx->pixel_list.release(); ctx->wf_counts.release(); ctx->stack_spill.release(); ctx->pool_f4.release(); ctx->pool_fin.release(); ctx->adapt_f4.release();
     ctx->textures.release(); ctx->texels.release(); ctx->srgb_lut.release(); ctx->tri_uv.release(); ctx->tri_tan.release();
     for (int c = 0; c < PRT_MAX_CHAINS; ++c) {
         prt_ctx::ChainWs & w = ctx->chain[c];

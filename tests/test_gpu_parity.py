@@ -19,6 +19,7 @@ SMALL = ["c1_sphere_plane_256", "c2_cornell_128", "c2_cornell_512_l4", "cornell_
          "icosphere_l3_two_lights", "terrain64_d3", "terrain192_d2"]
 BIG = ["c3_icosphere_1080p_l24", "c4_terrain1m_1080p_l40", "c5_terrain1m_4k_l120"]
 TEXTURED = ["gallery_160x120", "gallery_two_lights_d4"]       # row N1: ambient / diffuse / specular / alpha / bump maps
+ADAPTIVE = ["cornell_adaptive_4_16", "gallery_adaptive_10_50", "terrain64_adaptive_3_12_d4", "c4_terrain1m_adaptive_l60"]   # row N4
 
 
 def _render_fixture(gpu_renderer_factory, name, pipeline=0):
@@ -60,6 +61,49 @@ def test_textured_scene_matches_reference_golden(gpu_renderer_factory, name, pip
         ctr.ray_count, int(g["ray_count"]), diff.max(), n_bad)
     assert n_bad == 0 and diff.max() <= TOL, "max|dRGB| = %g, %d pixels over %g" % (diff.max(), n_bad, TOL)
     assert np.all(img[:, :, 3] == 1.0)
+
+
+@pytest.mark.parametrize("name", ADAPTIVE)
+def test_adaptive_sampling_matches_reference_golden(gpu_renderer_factory, name):
+    """RenderPixel's adaptive loop (main.cpp:245-258) as the unmodified reference runs it, one RNG stream per pixel:
+    equal ray counts mean every pixel took the same number of samples as on the CPU (the stopping rule compares a
+    float variance with 0.01, so this also pins the per-sample colours to well inside the tolerance)."""
+    g, img, ctr = _render_fixture(gpu_renderer_factory, name)
+    assert ctr.pipeline == PIPELINES["pool"]
+    ref = g["rgb"]
+    diff = np.abs(img[:, :, :3] - ref)
+    n_bad = int((diff.max(axis=2) > TOL).sum())
+    assert ctr.ray_count == int(g["ray_count"]), "ray_count %d != reference %d (max|d|=%g, %d px over tol)" % (
+        ctr.ray_count, int(g["ray_count"]), diff.max(), n_bad)
+    assert n_bad == 0 and diff.max() <= TOL, "max|dRGB| = %g, %d pixels over %g" % (diff.max(), n_bad, TOL)
+    assert np.all(img[:, :, 3] == 1.0)
+
+
+def test_adaptive_sampling_shards_passes_and_refusals(gpu_renderer_factory, monkeypatch):
+    g = load_golden("terrain64_adaptive_3_12_d4")
+    r = gpu_renderer_factory(str(g["scene"]), int(g["light_mode"]))
+    w, h = int(g["width"]), int(g["height"])
+    cam, p = camera_and_params(g)
+    full, c = r.render(cam, p, w, h)
+    assert c.ray_count == int(g["ray_count"])
+    from par_raytracer_amd import sharding
+    frame = np.zeros((h, w, 4), dtype=np.float32)
+    rays = 0
+    for k in range(3):
+        part, ck = r.render_shard(cam, p, w, h, 8, k, 3)
+        frame[sharding.shard_row_list(h, 8, k, 3)] = part
+        rays += ck.ray_count
+    assert rays == c.ray_count
+    # two lights: the two shadow contributions of a hit are added with atomics, in either order
+    assert np.abs(frame - full.reshape(h, w, 4)).max() <= 1e-5
+    monkeypatch.setenv("PRT_PASS_SAMPLES", "700")
+    again, c2 = r.render(cam, p, w, h)
+    monkeypatch.delenv("PRT_PASS_SAMPLES")
+    assert c2.ray_count == c.ray_count and c2.trace_kernel_launches > 1
+    assert np.abs(again - full).max() <= 1e-5
+    cam, p_wave = camera_and_params(g, PIPELINES["wavefront"])
+    with pytest.raises(RuntimeError, match="adaptive sampling"):
+        r.render(cam, p_wave, 16, 16)
 
 
 def test_textured_scene_shards_passes_and_pipelines_agree(gpu_renderer_factory, monkeypatch):
