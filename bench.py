@@ -18,8 +18,8 @@ Extra objects on the JSON line:
   roofline      dominant kernel (k_trace, the persistent traversal kernel; one launch per bounce round):
                 SURVEY.md §8d algorithmic bytes of its launches in a frame (rays x 52 B + BVH nodes fetched x 64 B
                 + triangle tests x 48 B) / their summed duration, measured with HIP events on the kernel's own
-                stream inside the timed region.  `traffic` = HBM bytes of the same launches from rocprofv3 PMC
-                passes of this command (profiles/traffic_C4.json), or null.
+                stream inside the timed region.  `traffic` = HBM bytes per launch from rocprofv3 PMC passes of this
+                command (profiles/traffic_C4.json, FETCH_SIZE x 2 + WRITE_SIZE as the gfx950 guide prescribes), or null.
   cpu_baseline  the CPU oracle ("port", oracle/prt_oracle.cpp, proven bit-identical to the compiled
                 reference) timed on this host's cores on a sparse pixel lattice of the SAME frame; rank 0,
                 N = 1 only.  The same lattice is the parity check of the GPU frame (max |dRGB|, ray counts).
@@ -220,9 +220,14 @@ def main():
                 traffic = json.load(f).get("hbm_bytes_per_frame_k_trace")
         except Exception:
             traffic = None
-    roofline = {"bound": "hbm", "kernel": kernel_name, "launches_per_frame": int(cc.trace_kernel_launches),
+    launches = max(1, int(cc.trace_kernel_launches))
+    # `achieved` = algorithmic bytes per launch / mean launch duration; `traffic` = measured HBM bytes per launch.  Both are
+    # also given per frame (launches_per_frame launches of the kernel make one frame).
+    roofline = {"bound": "hbm", "kernel": kernel_name, "launches_per_frame": launches,
                 "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": int(traffic / launches) if traffic else None,
+                "traffic_per_frame": traffic, "algorithmic_bytes_per_launch": int(alg_bytes / launches),
+                "launch_ms_mean": round(kernel_ms / launches, 4),
                 "algorithmic_bytes_per_frame": int(alg_bytes), "kernel_ms_per_frame": round(kernel_ms, 4),
                 "per_frame": {"rays": int(cc.ray_count), "node_visits": int(cc.node_visits), "tri_tests": int(cc.tri_tests),
                                "shaded_hits": int(cc.shaded_hits), "pixels": int(n_px_local)},
