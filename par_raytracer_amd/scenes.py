@@ -451,6 +451,22 @@ def displaced_icosphere(level: int = 6, n_groups: int = 64, radius: float = 2.0,
                     camera_position=(0.5, 3.6, 8.0), camera_facing=(-0.05, -0.12, -1.0), fov=60.0)
 
 
+def many_materials(level: int = 3, n_groups: int = 40) -> ObjScene:
+    """The displaced icosphere with one material per face cluster (41 MTL materials + the scene default = 42): more
+    than the 32 the shading kernels stage in LDS, so the global-table path runs.  Every fifth cluster is translucent."""
+    s = displaced_icosphere(level, n_groups)
+    rng = np.random.default_rng(77)
+    mats = [m for m in s.materials if m.name == "ground"]
+    for g in range(n_groups):
+        kd = tuple(float(v) for v in rng.uniform(0.25, 0.95, size=3))
+        mats.append(MtlMaterial("m%02d" % g, Ns=float(rng.uniform(4.0, 80.0)), Ni=float(rng.uniform(1.1, 2.2)),
+                                d=0.6 if g % 5 == 2 else 1.0, Ka=kd, Kd=kd, Ks=tuple(float(v) for v in rng.uniform(0.0, 0.9, size=3))))
+        s.groups[g].material = "m%02d" % g
+    s.materials = mats
+    s.name = "many_materials_L%d" % level
+    return s
+
+
 # ----------------------------------------------------------------------------------------
 # C4 / C5: height-field terrain with canyon walls
 # ----------------------------------------------------------------------------------------
@@ -657,6 +673,7 @@ SCENES = {
     "terrain_1m": lambda: terrain(708, 32),
     "terrain_64": lambda: terrain(64, 4, size=64.0),          # 8,192 tris in 16 groups, CPU-test sized
     "terrain_192": lambda: terrain(192, 8, size=192.0),       # 73,728 tris in 64 groups
+    "many_materials": lambda: many_materials(),               # 1,282 tris, 42 materials (LDS table fallback), translucent clusters
     "textured_gallery": lambda: textured_gallery(),           # 192 tris, 7 materials, 14 texture files (row N1)
 }
 

@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-4      # north_star: "per-pixel RGB within 1e-4 of the reference"
 
 SMALL = ["c1_sphere_plane_256", "c2_cornell_128", "c2_cornell_512_l4", "cornell_point_light_d5",
-         "icosphere_l3_two_lights", "terrain64_d3", "terrain192_d2"]
+         "icosphere_l3_two_lights", "terrain64_d3", "terrain192_d2", "many_materials_two_lights"]
 BIG = ["c3_icosphere_1080p_l24", "c4_terrain1m_1080p_l40", "c5_terrain1m_4k_l120"]
 TEXTURED = ["gallery_160x120", "gallery_two_lights_d4"]       # row N1: ambient / diffuse / specular / alpha / bump maps
 ADAPTIVE = ["cornell_adaptive_4_16", "gallery_adaptive_10_50", "terrain64_adaptive_3_12_d4", "c4_terrain1m_adaptive_l60"]   # row N4
@@ -221,6 +221,51 @@ def test_multi_pass_rendering_is_invisible(gpu_renderer_factory, pipeline, monke
     assert c_got.shaded_hits == c_ref.shaded_hits
     if pipeline != "wavefront":
         assert c_got.trace_kernel_launches > c_ref.trace_kernel_launches == 1
+
+
+@pytest.mark.parametrize("pipeline", sorted(PIPELINES))
+def test_many_lights_and_materials_against_the_oracle(pipeline):
+    """More lights (7) and materials (42) than the shading kernels stage in LDS (4 / 32), directional and point lights
+    mixed: the global-table paths, one shadow queue slot per light, atomics for the shadow contributions.  The
+    reference's InitScene only ever enables two lights, so this compares with the CPU oracle, which is pinned to the
+    reference bit for bit on the one- and two-light fixtures of the same scene."""
+    import ctypes as C
+    import oracle_py as orc
+    from conftest import host_scene
+    from par_raytracer_amd import api, capi
+    g = load_golden("many_materials_two_lights")
+    hs = host_scene("many_materials", 1)
+    base = hs.desc.contents
+    n = 7
+    lights = (capi.PrtLight * n)()
+    rng = np.random.default_rng(3)
+    for i in range(n):
+        l = lights[i]
+        l.type = i % 2                                        # directional, point, directional, ...
+        col = rng.uniform(0.3, 1.0, size=3) * (1.5 if i % 2 == 0 else 6.0)
+        l.color = (C.c_float * 4)(float(col[0]), float(col[1]), float(col[2]), 1.0)
+        f = rng.normal(size=3); f[1] = -abs(f[1]) - 0.5; f /= np.linalg.norm(f)
+        l.facing = (C.c_float * 3)(*[float(np.float32(v)) for v in f])
+        l.position = (C.c_float * 3)(float(rng.uniform(-4, 4)), float(rng.uniform(3, 7)), float(rng.uniform(-2, 6)))
+        l.falloff = float(rng.uniform(2.0, 5.0))
+    desc = capi.PrtSceneDesc()
+    C.memmove(C.byref(desc), C.byref(base), C.sizeof(desc))
+    desc.lights = C.cast(lights, C.POINTER(capi.PrtLight))
+    desc.light_count = n
+    w, h = 64, 48
+    cam, p = camera_and_params(g, PIPELINES[pipeline])
+    cam = api.make_camera(float(g["fov"]), w, h, g["camera_position"], g["camera_facing"])
+    ref, c_ref = orc.render(C.pointer(desc), cam, p, w, h, 1, 8)
+    r = api.Renderer(0)
+    try:
+        r.upload(C.pointer(desc))
+        img, ctr = r.render(cam, p, w, h)
+    finally:
+        r.close()
+    assert ctr.ray_count == c_ref.ray_count
+    diff = np.abs(img.reshape(h, w, 4)[:, :, :3] - ref[:, :, :3])
+    assert diff.max() <= TOL, "max|dRGB| = %g" % diff.max()
+    assert c_ref.ray_count > 10 * w * h, "seven shadow rays per hit"
 
 
 def test_default_pipeline_picks_by_size_and_both_agree(gpu_renderer_factory, monkeypatch):
