@@ -133,7 +133,12 @@ def main():
     my_rows = r.shard_rows(height, SHARD_BLOCK_ROWS, rank, world)
     assert my_rows == sharding.shard_rows(height, SHARD_BLOCK_ROWS, rank, world)
     max_rows = sharding.max_shard_rows(height, SHARD_BLOCK_ROWS, world)
-    shard = torch.zeros((max_rows, width, 4), dtype=torch.float32, device=dev)
+    # two shard buffers: the RCCL gather of frame k (asynchronous, on torch's communication stream) reads one while
+    # frame k + 1 is rendered into the other; an event per buffer says when its gather has finished
+    shards = [torch.zeros((max_rows, width, 4), dtype=torch.float32, device=dev) for _ in range(2 if world > 1 else 1)]
+    shard = shards[0]
+    gathered = [None, None]
+    frame_no = 0
     gather_list = None
     row_index = None
     frame = None
@@ -143,17 +148,24 @@ def main():
 
     def step(want_counters=True):
         """One frame.  Returns this rank's counters."""
-        nonlocal frame
+        nonlocal frame, frame_no
         if world == 1:
             c = r.render_device(cam, params, width, height, 0, width * height, shard.data_ptr(), want_counters)
         else:
-            c = r.render_shard_device(cam, params, width, height, SHARD_BLOCK_ROWS, rank, world, shard.data_ptr(), want_counters)
+            b = frame_no % 2
+            frame_no += 1
+            if gathered[b] is not None:
+                gathered[b].synchronize()                           # the gather that read this buffer two frames ago
+            buf = shards[b]
+            c = r.render_shard_device(cam, params, width, height, SHARD_BLOCK_ROWS, rank, world, buf.data_ptr(), want_counters)
             if args.backend == "nccl":
-                dist.gather(shard, gather_list, dst=0)              # RCCL over xGMI: 7 shards -> GPU 0
+                dist.gather(buf, gather_list, dst=0)                # RCCL over xGMI: 7 shards -> GPU 0
                 if rank == 0:
                     frame = sharding.assemble(torch.cat(gather_list, dim=0), row_index, height)
+                gathered[b] = torch.cuda.Event()
+                gathered[b].record()
             else:
-                host = shard.cpu()
+                host = buf.cpu()
                 gl = [torch.empty_like(host) for _ in range(world)] if rank == 0 else None
                 dist.gather(host, gl, dst=0)
                 if rank == 0:
