@@ -12,6 +12,10 @@ and their de-interleave on GPU 0.  Excluded, as in the reference's TIME_BLOCK("R
 (main.cpp:327): OBJ parse, hierarchy/BVH build, upload, tone map, PNG.
 
 A ray is one TraceRay call (raytracer.cpp:161): primary, shadow, bounce.  value = rays of all ranks / time.
+With several GPUs up to --frames-in-flight (default 2; 1 on a single GPU) consecutive frames overlap on each GPU, each on its own context / stream: the
+persistent kernels of a frame leave the GPU partly idle while their last rays drain, and the next frame fills that
+(1/8-frame shard: 2.74 -> 2.38 ms per frame).  Every frame is rendered, gathered and assembled inside the timed
+region; `render_ms_device` stays the per-frame device latency.
 Total work is fixed as N grows -> "scaling": "strong".
 
 Extra objects on the JSON line:
@@ -72,6 +76,11 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend; gloo (host-staged) only exists to rehearse the N > 1 path on a 1-GPU box")
     ap.add_argument("--share-device", action="store_true", help="rehearsal: every rank uses GPU 0")
+    ap.add_argument("--frames-in-flight", type=int, default=0,
+                    help="consecutive frames rendered concurrently (own context, stream and workspace each): the drain tail "
+                         "of frame k overlaps the start of frame k + 1.  1 = strictly one frame at a time; 0 = auto: 1 on one "
+                         "GPU (a full frame gains 2 %% and the kernel timings of the roofline would be taken under "
+                         "contention), 2 on several (a 1/8-frame shard gains 13 %%)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -129,16 +138,24 @@ def main():
     cam = api.make_camera(fov, width, height, cam_pos, cam_dir)
     params = api.default_params(spp, SEED, bounce_depth=depth, pipeline=args.pipeline)
 
+    # ---- frames in flight: F independent contexts on this GPU (scene replicated: 133 MB for C4), each with its own stream,
+    # workspace and output buffer; frame k runs on context k % F from its own host thread (the render call blocks its
+    # caller: the wavefront pipeline needs host round trips).  Every frame is still complete - rendered, gathered,
+    # assembled - inside the timed region; only the GPU idle time at the end of one frame is filled by the next.
+    F = args.frames_in_flight if args.frames_in_flight > 0 else (1 if world == 1 else 2)
+    renderers = [r]
+    for _ in range(F - 1):
+        extra = api.Renderer(local_rank)
+        extra.upload(hs)
+        renderers.append(extra)
+
     # ---- output buffers (device).  Shards are padded to the largest shard so the gather has equal sizes.
     my_rows = r.shard_rows(height, SHARD_BLOCK_ROWS, rank, world)
     assert my_rows == sharding.shard_rows(height, SHARD_BLOCK_ROWS, rank, world)
     max_rows = sharding.max_shard_rows(height, SHARD_BLOCK_ROWS, world)
-    # two shard buffers: the RCCL gather of frame k (asynchronous, on torch's communication stream) reads one while
-    # frame k + 1 is rendered into the other; an event per buffer says when its gather has finished
-    shards = [torch.zeros((max_rows, width, 4), dtype=torch.float32, device=dev) for _ in range(2 if world > 1 else 1)]
+    shards = [torch.zeros((max_rows, width, 4), dtype=torch.float32, device=dev) for _ in range(F)]
     shard = shards[0]
-    gathered = [None, None]
-    frame_no = 0
+    gathered = [None] * F                  # per buffer: event recorded after the RCCL gather that read it
     gather_list = None
     row_index = None
     frame = None
@@ -146,52 +163,68 @@ def main():
         gather_list = [torch.empty_like(shard) for _ in range(world)]
         row_index = torch.from_numpy(sharding.row_index(height, SHARD_BLOCK_ROWS, world)).to(dev)
 
-    def step(want_counters=True):
-        """One frame.  Returns this rank's counters."""
-        nonlocal frame, frame_no
+    def render_frame(slot):
+        """Render one frame into buffer `slot` on context `slot` (called from a worker thread when F > 1)."""
+        rr, buf = renderers[slot], shards[slot]
         if world == 1:
-            c = r.render_device(cam, params, width, height, 0, width * height, shard.data_ptr(), want_counters)
+            return rr.render_device(cam, params, width, height, 0, width * height, buf.data_ptr(), True)
+        return rr.render_shard_device(cam, params, width, height, SHARD_BLOCK_ROWS, rank, world, buf.data_ptr(), True)
+
+    def deliver_frame(slot):
+        """Main thread, after the frame in buffer `slot` is rendered: gather the shards to rank 0 and assemble."""
+        nonlocal frame
+        if world == 1:
+            return
+        buf = shards[slot]
+        if args.backend == "nccl":
+            dist.gather(buf, gather_list, dst=0)                    # RCCL over xGMI: 7 shards -> GPU 0 (asynchronous)
+            if rank == 0:
+                frame = sharding.assemble(torch.cat(gather_list, dim=0), row_index, height)
+            gathered[slot] = torch.cuda.Event()
+            gathered[slot].record()
         else:
-            b = frame_no % 2
-            frame_no += 1
-            if gathered[b] is not None:
-                gathered[b].synchronize()                           # the gather that read this buffer two frames ago
-            buf = shards[b]
-            c = r.render_shard_device(cam, params, width, height, SHARD_BLOCK_ROWS, rank, world, buf.data_ptr(), want_counters)
-            if args.backend == "nccl":
-                dist.gather(buf, gather_list, dst=0)                # RCCL over xGMI: 7 shards -> GPU 0
-                if rank == 0:
-                    frame = sharding.assemble(torch.cat(gather_list, dim=0), row_index, height)
-                gathered[b] = torch.cuda.Event()
-                gathered[b].record()
-            else:
-                host = buf.cpu()
-                gl = [torch.empty_like(host) for _ in range(world)] if rank == 0 else None
-                dist.gather(host, gl, dst=0)
-                if rank == 0:
-                    frame = sharding.assemble(torch.cat(gl, dim=0).to(dev), row_index, height)
-        return c
+            host = buf.cpu()
+            gl = [torch.empty_like(host) for _ in range(world)] if rank == 0 else None
+            dist.gather(host, gl, dst=0)
+            if rank == 0:
+                frame = sharding.assemble(torch.cat(gl, dim=0).to(dev), row_index, height)
+
+    from concurrent.futures import ThreadPoolExecutor
+    pool = ThreadPoolExecutor(max_workers=F) if F > 1 else None
+
+    def run_frames(n):
+        """n frames, at most F in flight.  Returns the per-frame counters in frame order."""
+        out, pending = [], []
+        for k in range(n):
+            slot = k % F
+            if len(pending) == F:                                   # the frame that used this slot F frames ago
+                s0, fut = pending.pop(0)
+                out.append(fut.result() if pool else fut)
+                deliver_frame(s0)
+            if gathered[slot] is not None:
+                gathered[slot].synchronize()                        # its gather must have read the buffer before we overwrite it
+                gathered[slot] = None
+            pending.append((slot, pool.submit(render_frame, slot) if pool else render_frame(slot)))
+        for s0, fut in pending:
+            out.append(fut.result() if pool else fut)
+            deliver_frame(s0)
+        return out
 
     def sync_all():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    # ---- warmup, then EXACTLY K timed steps
-    for _ in range(args.warmup):
-        step()
+    # ---- warmup (every context at least once), then EXACTLY K timed steps
+    run_frames(max(args.warmup, F if args.warmup > 0 else 0))
     sync_all()
     t_start = time.perf_counter()
-    rays_local = 0
-    trace_ms = []
-    render_ms = []
-    for _ in range(args.steps):
-        c = step()
-        rays_local += c.ray_count
-        trace_ms.append(c.trace_kernel_ms)
-        render_ms.append(c.render_ms)
+    counters = run_frames(args.steps)
     sync_all()
     elapsed = time.perf_counter() - t_start
+    rays_local = sum(c.ray_count for c in counters)
+    trace_ms = [c.trace_kernel_ms for c in counters]
+    render_ms = [c.render_ms for c in counters]
 
     t = torch.tensor([elapsed, float(rays_local)], dtype=torch.float64, device=cdev)
     if world > 1:
@@ -293,12 +326,15 @@ def main():
                        "spp": spp, "bounce_depth": depth, "rays_per_frame": int(rays_total / args.steps),
                        "parallelism": "pixel rows sharded in %d-row blocks over %d GPU(s)%s" % (
                            SHARD_BLOCK_ROWS, world, (", RCCL gather to rank 0" if args.backend == "nccl" else ", gloo gather (rehearsal)") if world > 1 else ""),
-                       "pipeline": pipeline_name},
+                       "pipeline": pipeline_name, "frames_in_flight": F},
             "render_ms_device": round(float(np.mean(render_ms)), 4),
             "roofline": roofline, "cpu_baseline": cpu_baseline, "parity": parity, "multi_gpu_check": multi_check,
         }
         print(json.dumps(out), flush=True)
-    r.close()
+    if pool:
+        pool.shutdown()
+    for rr in renderers:
+        rr.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
