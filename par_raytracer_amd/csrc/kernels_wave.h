@@ -438,7 +438,8 @@ PRT_D void shade_entry(const DevScene & sc, const DevParams & P, const WaveBuffe
                     alpha_tested = true;
                 }
             }
-            if (alpha_tested && alpha <= 0.05f) {                                   // raytracer.cpp:443-453
+            // (the non-RING variants only run scenes whose materials all have alpha >= 1: the translucency paths fold away)
+            if (RING && alpha_tested && alpha <= 0.05f) {                           // raytracer.cpp:443-453
                 next_o = pos + ray_d * P.ray_bias * 2.0f;
                 next_d = ray_d;
                 next_T = T;
@@ -484,7 +485,7 @@ PRT_D void shade_entry(const DevScene & sc, const DevParams & P, const WaveBuffe
                 f.w_diffuse = 1.0f - w_reflect;
                 f.stage = WF_STAGE_REFL;
                 f.idx = 0;
-                T_own = alpha < 1.0f ? T * alpha : T;                               // raytracer.cpp:551
+                T_own = RING && alpha < 1.0f ? T * alpha : T;                       // raytracer.cpp:551
                 add = add + T_own * (ka * 0.1f);                                    // raytracer.cpp:543
                 want_shadow = true;
                 mode = M_NEXT_CHILD;
@@ -527,7 +528,7 @@ PRT_D void shade_entry(const DevScene & sc, const DevParams & P, const WaveBuffe
         if (mode == M_NEXT_CHILD) {                       // frame f at `level` spawns its next child, if any
             const int iters = depth - level;
             const DevMaterial fm = tb.materials[f.mat];
-            const f3 own = f.alpha < 1.0f ? f.T_in * f.alpha : f.T_in;
+            const f3 own = RING && f.alpha < 1.0f ? f.T_in * f.alpha : f.T_in;
             // which child comes next (cheap), then ONE copy of the expensive direction code for both lobes
             int kind = -1;                                                          // 0 diffuse, 1 specular, 2 alpha continuation
             if (f.stage == WF_STAGE_REFL) {                                         // raytracer.cpp:516-526
@@ -540,7 +541,7 @@ PRT_D void shade_entry(const DevScene & sc, const DevParams & P, const WaveBuffe
             }
             if (kind < 0 && f.stage == WF_STAGE_ALPHA) {                            // raytracer.cpp:547-552
                 f.stage = WF_STAGE_DONE;
-                if (f.alpha < 1.0f) kind = 2;
+                if (RING && f.alpha < 1.0f) kind = 2;
             }
             const bool spawned = kind >= 0;
             if (kind == 2) {
@@ -568,7 +569,7 @@ PRT_D void shade_entry(const DevScene & sc, const DevParams & P, const WaveBuffe
                 // (64 B written, 64 B read back later) nor revisited
                 const bool more_refl = kind == 0 && (unsigned int)f.idx < P.reflection_samples;
                 const bool more_spec = kind == 0 ? P.spec_samples > 0u : (unsigned int)f.idx < P.spec_samples;
-                if (!more_refl && !more_spec && !(f.alpha < 1.0f)) f.stage = WF_STAGE_DONE;
+                if (!more_refl && !more_spec && !(RING && f.alpha < 1.0f)) f.stage = WF_STAGE_DONE;
             }
             if (!spawned) { f_held = false; mode = M_RETURN_UP; continue; }
             f_held = true;                                // f (at `level`) stays in registers until the child's fate is known

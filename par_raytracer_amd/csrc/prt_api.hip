@@ -711,7 +711,14 @@ int render_pixels(prt_ctx * ctx, const prt_camera * cam_in, const prt_params * p
             if (adaptive)
                 rc = ctx->textured ? launch_pool<512, 4, true, true, true, true>(ctx, count_visits, cam, P, n_samples, stack_entries)
                                    : launch_pool<512, 4, true, true, false, true>(ctx, count_visits, cam, P, n_samples, stack_entries);
-            else
+            else if (getenv("PRT_POOL_VARIANT") && !ctx->textured && !ring) {
+                const int v = atoi(getenv("PRT_POOL_VARIANT"));
+                rc = v == 1 ? launch_pool<512, 4, false, false, false, false>(ctx, count_visits, cam, P, n_samples, stack_entries)
+                   : v == 2 ? launch_pool<320, 5, false, false, false, false>(ctx, count_visits, cam, P, n_samples, stack_entries)
+                   : v == 3 ? launch_pool<256, 4, false, false, false, false>(ctx, count_visits, cam, P, n_samples, stack_entries)
+                   : v == 4 ? launch_pool<320, 5, true, false, false, false>(ctx, count_visits, cam, P, n_samples, stack_entries)
+                            : launch_pool<512, 4, true, false, false, false>(ctx, count_visits, cam, P, n_samples, stack_entries);
+            } else
                 rc = ctx->textured ? launch_pool<512, 4, true, true, true, false>(ctx, count_visits, cam, P, n_samples, stack_entries)
                    : ring ? launch_pool<512, 4, true, true, false, false>(ctx, count_visits, cam, P, n_samples, stack_entries)
                           : launch_pool<512, 4, true, false, false, false>(ctx, count_visits, cam, P, n_samples, stack_entries);
