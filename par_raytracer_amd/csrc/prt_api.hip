@@ -706,22 +706,18 @@ int render_pixels(prt_ctx * ctx, const prt_camera * cam_in, const prt_params * p
             else rc = launch_persistent<17, true>(ctx, count_visits, lds, cam, P, n_samples, keep_min, node_min, blocks_cap);
             launches += 1;
         } else if (pipeline == PRT_PIPELINE_POOL) {
-            // 512-thread blocks, 4 waves per SIMD (128 VGPRs), direction table in LDS.  Measured alternatives: 5 waves
-            // (96 VGPRs, 93 dwords spilled) 24.2 ms and 6 waves (80 VGPRs, 154 spilled) 29.5 ms against 17.3 ms on a C4 frame.
+            // 256-thread blocks, 4 waves per SIMD (128 VGPRs), 4 blocks per CU; the Hammersley direction table stays in
+            // global memory (staging it in LDS measured 17.04 vs 17.15 ms: nothing).  Small blocks retire - and let the
+            // blocks of the next frame's kernel in - at a finer grain: with two frames in flight a 1/8-frame shard takes
+            // 2.24 ms per frame instead of 2.59 with 512-thread blocks.  Measured alternatives at other occupancies: 5 waves
+            // per SIMD (96 VGPRs, 93 dwords spilled) 29-31 ms, 6 waves (80 VGPRs, 154 spilled) 29.5 ms on a C4 frame.
             if (adaptive)
-                rc = ctx->textured ? launch_pool<512, 4, true, true, true, true>(ctx, count_visits, cam, P, n_samples, stack_entries)
-                                   : launch_pool<512, 4, true, true, false, true>(ctx, count_visits, cam, P, n_samples, stack_entries);
-            else if (getenv("PRT_POOL_VARIANT") && !ctx->textured && !ring) {
-                const int v = atoi(getenv("PRT_POOL_VARIANT"));
-                rc = v == 1 ? launch_pool<512, 4, false, false, false, false>(ctx, count_visits, cam, P, n_samples, stack_entries)
-                   : v == 2 ? launch_pool<320, 5, false, false, false, false>(ctx, count_visits, cam, P, n_samples, stack_entries)
-                   : v == 3 ? launch_pool<256, 4, false, false, false, false>(ctx, count_visits, cam, P, n_samples, stack_entries)
-                   : v == 4 ? launch_pool<320, 5, true, false, false, false>(ctx, count_visits, cam, P, n_samples, stack_entries)
-                            : launch_pool<512, 4, true, false, false, false>(ctx, count_visits, cam, P, n_samples, stack_entries);
-            } else
-                rc = ctx->textured ? launch_pool<512, 4, true, true, true, false>(ctx, count_visits, cam, P, n_samples, stack_entries)
-                   : ring ? launch_pool<512, 4, true, true, false, false>(ctx, count_visits, cam, P, n_samples, stack_entries)
-                          : launch_pool<512, 4, true, false, false, false>(ctx, count_visits, cam, P, n_samples, stack_entries);
+                rc = ctx->textured ? launch_pool<256, 4, false, true, true, true>(ctx, count_visits, cam, P, n_samples, stack_entries)
+                                   : launch_pool<256, 4, false, true, false, true>(ctx, count_visits, cam, P, n_samples, stack_entries);
+            else
+                rc = ctx->textured ? launch_pool<256, 4, false, true, true, false>(ctx, count_visits, cam, P, n_samples, stack_entries)
+                   : ring ? launch_pool<256, 4, false, true, false, false>(ctx, count_visits, cam, P, n_samples, stack_entries)
+                          : launch_pool<256, 4, false, false, false, false>(ctx, count_visits, cam, P, n_samples, stack_entries);
             launches += 1;
         } else {
             unsigned long long rays = 0;

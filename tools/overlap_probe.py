@@ -15,7 +15,7 @@ for _ in range(F_MAX):
 bufs = [torch.zeros((h, w, 4), dtype=torch.float32, device="cuda") for _ in range(F_MAX)]
 for nr in (1, 2, 4, 8):
     for F in (1, 2, 3):
-        frames = 12
+        frames = 24
         for k in range(F): rs[k].render_shard_device(cam, p, w, h, 8, 0, nr, bufs[k].data_ptr(), False)
         def work(k):
             for _ in range(frames // F):
