@@ -85,6 +85,10 @@ struct prt_ctx {
     float scene_abs_max = 0.0f;
     bool any_translucent = false;
     bool textured = false;                // any material has a texture map: the TEX kernel variants run
+    // PRT_PIPELINE_DEFAULT: which pipeline won the try-out for a (scene, pixel set, sampling) configuration
+    struct TuneEntry { uint64_t key[4]; unsigned int pipeline; };
+    std::vector<TuneEntry> tuned;
+    uint64_t scene_epoch = 0;
     DevBuf<DevTexture> textures;
     DevBuf<unsigned int> texels;
     DevBuf<float> srgb_lut;
@@ -602,12 +606,46 @@ int render_pixels(prt_ctx * ctx, const prt_camera * cam_in, const prt_params * p
     }
     if (pipeline == PRT_PIPELINE_DEFAULT) {
         // Measured on MI355X (tools/pool_cross.py, tools/pool_scene_cross.py): the wavefront pipeline's steady state is
-        // ~15 % faster (its k_trace runs 6 waves per SIMD, k_pool 4), but each of its ~8 rounds costs a launch ramp, a
-        // drain tail and a host round trip, ~1 ms per frame in total.  Below ~5 M samples (a quarter of 1080p x 8 spp,
-        // i.e. every shard of a 4..8 GPU run) the single-launch pool pipeline wins, by up to 2x on small frames.
-        unsigned long long pool_max = 5000000ull;
-        if (const char * e = getenv("PRT_POOL_MAX_SAMPLES")) pool_max = strtoull(e, nullptr, 10);
-        pipeline = (unsigned long long)px.n_pixels * params->spp <= pool_max ? PRT_PIPELINE_POOL : PRT_PIPELINE_WAVEFRONT;
+        // ~12 % faster (its k_trace runs 6 waves per SIMD, k_pool 4), but each of its ~8 rounds costs a launch ramp, a
+        // drain tail and a host round trip, ~1 ms per frame in total.  So the single-launch pool pipeline wins when a
+        // frame takes less than ~6 ms on the wavefront pipeline - every C4 shard of a 4..8 GPU run, but also a full 1080p
+        // frame of a scene whose rays are short (C3: 4.75 vs 5.85 ms).  Sample count alone cannot tell those apart, so in
+        // the range where either can win the first call of a configuration renders the frame with both (twice each: the
+        // first run of a pipeline allocates its workspace) and keeps the faster; the images are the same.  Outside
+        // that range - and always when PRT_POOL_MAX_SAMPLES is set - the size decides.
+        const unsigned long long ns = (unsigned long long)px.n_pixels * params->spp;
+        const char * forced = getenv("PRT_POOL_MAX_SAMPLES");
+        if (forced || ns <= (1ull << 20) || ns > (64ull << 20)) {
+            const unsigned long long pool_max = forced ? strtoull(forced, nullptr, 10) : 5000000ull;
+            pipeline = ns <= pool_max ? PRT_PIPELINE_POOL : PRT_PIPELINE_WAVEFRONT;
+        } else {
+            prt_ctx::TuneEntry e;
+            e.key[0] = ctx->scene_epoch;
+            e.key[1] = (uint64_t)px.n_pixels | (uint64_t)params->spp << 32;
+            e.key[2] = (uint64_t)width | (uint64_t)height << 32;
+            e.key[3] = (uint64_t)params->bounce_depth | (uint64_t)params->reflection_samples << 8 | (uint64_t)params->spec_samples << 20 |
+                       (uint64_t)px.nranks << 32 | (uint64_t)px.block_rows << 44 | (uint64_t)(px.d_pixel_list ? 1 : 0) << 56;
+            for (const prt_ctx::TuneEntry & t : ctx->tuned)
+                if (!memcmp(t.key, e.key, sizeof(e.key))) pipeline = t.pipeline;
+            if (pipeline == PRT_PIPELINE_DEFAULT) {
+                const unsigned int cand[2] = { PRT_PIPELINE_POOL, PRT_PIPELINE_WAVEFRONT };
+                double ms[2] = { 0.0, 0.0 };
+                prt_counters c;
+                for (int run = 0; run < 4; ++run) {                        // pool, wavefront (cold), pool, wavefront (timed)
+                    prt_params pp = *params;
+                    pp.pipeline = (params->pipeline & ~(uint32_t)PRT_PIPELINE_MASK) | cand[run & 1];
+                    int rc = render_pixels(ctx, cam_in, &pp, width, height, px, d_out, &c);
+                    if (rc) return rc;
+                    ms[run & 1] = c.render_ms;
+                }
+                e.pipeline = ms[0] <= ms[1] ? PRT_PIPELINE_POOL : PRT_PIPELINE_WAVEFRONT;
+                if (ctx->tuned.size() >= 64) ctx->tuned.erase(ctx->tuned.begin());
+                ctx->tuned.push_back(e);
+                if (getenv("PRT_DEBUG_UTIL")) fprintf(stderr, "[prt] default pipeline try-out: pool %.3f ms, wavefront %.3f ms\n", ms[0], ms[1]);
+                if (counters) *counters = c;                               // the frame in d_out is the last (wavefront) run
+                return 0;
+            }
+        }
     }
     if (pipeline != PRT_PIPELINE_MEGAKERNEL && pipeline != PRT_PIPELINE_WAVEFRONT && pipeline != PRT_PIPELINE_PERSISTENT && pipeline != PRT_PIPELINE_POOL) { ctx->error = "prt_render: unknown pipeline"; return -1; }
     if (ctx->textured && (pipeline == PRT_PIPELINE_MEGAKERNEL || pipeline == PRT_PIPELINE_PERSISTENT)) {
@@ -1123,6 +1161,8 @@ int prt_upload_scene(prt_ctx * ctx, const prt_scene_desc * s) {
                         (bumped ? ctx->tri_tan.bytes() : 0);
     info.bvh_build_ms = build_ms;
     ctx->has_scene = true;
+    ctx->scene_epoch++;
+    ctx->tuned.clear();
     return 0;
 }
 

@@ -223,6 +223,26 @@ def test_multi_pass_rendering_is_invisible(gpu_renderer_factory, pipeline, monke
         assert c_got.trace_kernel_launches > c_ref.trace_kernel_launches == 1
 
 
+def test_default_pipeline_try_out_is_invisible(gpu_renderer_factory):
+    """Between 1 M and 64 M samples the first PRT_PIPELINE_DEFAULT call of a configuration renders the frame with both
+    production pipelines and keeps the faster one: the image is the same whichever wins, later calls stick to it."""
+    g = load_golden("terrain192_d2")
+    r = gpu_renderer_factory(str(g["scene"]), 0)
+    w, h = 640, 480                                               # x 4 spp = 1.23 M samples
+    from par_raytracer_amd import api
+    cam = api.make_camera(float(g["fov"]), w, h, g["camera_position"], g["camera_facing"])
+    p0 = api.default_params(4, 99)
+    first, c1 = r.render(cam, p0, w, h)
+    second, c2 = r.render(cam, p0, w, h)
+    assert c1.pipeline in (PIPELINES["pool"], PIPELINES["wavefront"]) and c2.pipeline in (PIPELINES["pool"], PIPELINES["wavefront"])
+    third, c3 = r.render(cam, p0, w, h)
+    assert c3.pipeline == c2.pipeline, "the choice is kept"
+    for name in ("pool", "wavefront"):
+        img, c = r.render(cam, api.default_params(4, 99, pipeline=PIPELINES[name]), w, h)
+        assert c.ray_count == c1.ray_count == c2.ray_count
+        assert np.array_equal(img.view(np.uint32), first.view(np.uint32)) and np.array_equal(img.view(np.uint32), second.view(np.uint32))
+
+
 @pytest.mark.parametrize("pipeline", sorted(PIPELINES))
 def test_many_lights_and_materials_against_the_oracle(pipeline):
     """More lights (7) and materials (42) than the shading kernels stage in LDS (4 / 32), directional and point lights
