@@ -558,6 +558,7 @@ int render_pixels(prt_ctx * ctx, const prt_camera * cam_in, const prt_params * p
         HIP_TRY(ctx, hipStreamSynchronize(stream));
         int rc = build_spec_table(ctx, params->spec_samples);
         if (rc) return rc;
+        HIP_TRY(ctx, hipDeviceSynchronize());      // the table went through the null stream
     }
 
     DevCamera cam;
@@ -1160,6 +1161,7 @@ int prt_upload_scene(prt_ctx * ctx, const prt_scene_desc * s) {
                         (textured ? ctx->textures.bytes() + ctx->texels.bytes() + ctx->srgb_lut.bytes() + ctx->tri_uv.bytes() : 0) +
                         (bumped ? ctx->tri_tan.bytes() : 0);
     info.bvh_build_ms = build_ms;
+    HIP_TRY(ctx, hipDeviceSynchronize());      // uploads went through the null stream; renders use the context's non-blocking streams
     ctx->has_scene = true;
     ctx->scene_epoch++;
     ctx->tuned.clear();
@@ -1235,7 +1237,8 @@ int prt_render_pixel_list(prt_ctx * ctx, const prt_camera * cam, const prt_param
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, ctx->pixel_list.ensure(n_pixels));
     HIP_TRY(ctx, ctx->frame_out.ensure(n_pixels));
-    if (n_pixels) HIP_TRY(ctx, hipMemcpy(ctx->pixel_list.p, pixel_ids, (size_t)n_pixels * 4, hipMemcpyHostToDevice));
+    if (n_pixels) HIP_TRY(ctx, hipMemcpyAsync(ctx->pixel_list.p, pixel_ids, (size_t)n_pixels * 4, hipMemcpyHostToDevice, ctx->stream));
+    if (n_pixels) HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));     // pixel_ids is the caller's memory
     PixelSet px = { n_pixels, 0, 1, 0, 1, ctx->pixel_list.p };
     int rc = render_pixels(ctx, cam, params, width, height, px, ctx->frame_out.p, counters);
     if (rc) return rc;
@@ -1254,8 +1257,10 @@ int prt_debug_device_kat(prt_ctx * ctx, int kind, const void * in, size_t in_byt
     HIP_TRY(ctx, hipMalloc(&d_in, in_bytes));
     HIP_TRY(ctx, hipMalloc(&d_out, out_bytes));
     HIP_TRY(ctx, ctx->ring_ws.ensure((size_t)16 * n));
-    HIP_TRY(ctx, hipMemcpy(d_in, in, in_bytes, hipMemcpyHostToDevice));
-    HIP_TRY(ctx, hipMemset(d_out, 0, out_bytes));
+    // everything on the context's stream: it is a non-blocking stream, so work on the null stream (a plain hipMemset)
+    // is NOT ordered against the kernel below
+    HIP_TRY(ctx, hipMemcpyAsync(d_in, in, in_bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(d_out, 0, out_bytes, ctx->stream));
     DevCamera cam;
     memset(&cam, 0, sizeof(cam));
     if (cam_in) {

@@ -223,6 +223,47 @@ def test_multi_pass_rendering_is_invisible(gpu_renderer_factory, pipeline, monke
         assert c_got.trace_kernel_launches > c_ref.trace_kernel_launches == 1
 
 
+def _random_configs():
+    rng = np.random.default_rng(20241003)
+    scenes_ = ["cornell_box", "sphere_plane", "icosphere_l3", "terrain_64", "many_materials", "textured_gallery"]
+    out = []
+    for i in range(18):
+        sc = scenes_[i % len(scenes_)]
+        cfg = dict(scene=sc, light_mode=int(rng.integers(0, 3)), depth=int(rng.integers(0, 7)), rs=int(rng.integers(0, 4)),
+                   ss=int(rng.integers(0, 4)), spp=int(rng.integers(1, 6)), seed=int(rng.integers(0, 2 ** 62)),
+                   w=int(rng.integers(17, 70)), h=int(rng.integers(11, 50)), adaptive=int(rng.integers(0, 3) == 0))
+        out.append(cfg)
+    return out
+
+
+@pytest.mark.parametrize("cfg", _random_configs(), ids=lambda c: "%s-d%d-r%d-s%d-l%d-%s" % (c["scene"], c["depth"], c["rs"], c["ss"], c["light_mode"], "adapt" if c["adaptive"] else "fixed"))
+def test_random_configurations_against_the_oracle(cfg):
+    """Parameter corners the fixtures do not visit (depth 0..6, 0..3 diffuse / specular bounce samples, odd image sizes,
+    point lights, adaptive mode with arbitrary bounds): every production pipeline that accepts the configuration must give
+    the oracle's ray count and colours."""
+    import oracle_py as orc
+    from conftest import host_scene, scene_dir
+    from par_raytracer_amd import api
+    s, _ = scene_dir(cfg["scene"])
+    hs = host_scene(cfg["scene"], cfg["light_mode"])
+    cam = api.make_camera(s.fov, cfg["w"], cfg["h"], s.camera_position, s.camera_facing)
+    max_spp = cfg["spp"] + 5 if cfg["adaptive"] else 0
+    def params(pipeline):
+        return api.default_params(cfg["spp"], cfg["seed"], bounce_depth=cfg["depth"], reflection_samples=cfg["rs"],
+                                  spec_samples=cfg["ss"], pipeline=pipeline, max_spp=max_spp)
+    ref, c_ref = orc.render(hs.desc, cam, params(0), cfg["w"], cfg["h"], 1, 8)
+    r = api.Renderer(0)
+    try:
+        r.upload(hs)
+        for name in (["pool"] if cfg["adaptive"] else ["pool", "wavefront"]):
+            img, c = r.render(cam, params(PIPELINES[name]), cfg["w"], cfg["h"])
+            assert c.ray_count == c_ref.ray_count, "%s: ray count %d != oracle %d" % (name, c.ray_count, c_ref.ray_count)
+            d = np.abs(img.reshape(cfg["h"], cfg["w"], 4)[:, :, :3] - ref[:, :, :3])
+            assert d.max() <= TOL, "%s: max|dRGB| = %g" % (name, d.max())
+    finally:
+        r.close()
+
+
 def test_default_pipeline_try_out_is_invisible(gpu_renderer_factory):
     """Between 1 M and 64 M samples the first PRT_PIPELINE_DEFAULT call of a configuration renders the frame with both
     production pipelines and keeps the faster one: the image is the same whichever wins, later calls stick to it."""
