@@ -16,7 +16,8 @@ for path in sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "*.npz"))):
         r = api.Renderer(0); r.upload(api.HostScene(d, "scene.obj", key[1], s.camera_position)); cache[key] = r
     r = cache[key]
     line = "%-28s" % name
-    for pl in (2, 4):
+    adaptive = "max_spp" in g and int(g["max_spp"]) > int(g["spp"])
+    for pl in ((4,) if adaptive else (2, 4)):
         cam, p = camera_and_params(g, pl)
         img, c = r.render_lattice(cam, p, int(g["width"]), int(g["height"]), int(g["lattice"]))
         d = np.abs(img[:, :, :3] - g["rgb"])
