@@ -368,7 +368,8 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_pool(DevScene sc, DevCamera ca
                     hit.t = h.x; hit.v = h.y; hit.w = h.z; hit.tri = as_i(h.w);
                 }
                 unsigned int shaded = 0;
-                shade_entry<RING, TEX>(sc, P, B, tb, live, s, level, pending, ray_o, ray_d, T, hit, emit, shaded);
+                // the frame under construction lives in this lane's (idle) traversal stack column
+                shade_entry_lds<RING, TEX, BLOCK>(sc, P, B, tb, live, s, level, pending, ray_o, ray_d, T, hit, emit, shaded, stack.col);
                 shaded_w += (unsigned int)__popcll(__ballot(shaded != 0));
             }
             n_c = emit.m_c;

@@ -326,8 +326,50 @@ struct WFrame {
     int mat, stage, idx;
 };
 
-template <bool RING, bool TEX>
-PRT_D void wframe_save(const WaveBuffers & B, int level, unsigned int s, const WFrame & f) {
+// The same frame held in LDS: field k of lane l at col[k * STRIDE] (col = the lane's own traversal stack column, which
+// is idle while the wave shades).  Proxies make `f.hit_n`, `f.idx++`, `f.stage = x` read and write LDS in place, so
+// the state machine of shade_entry keeps no frame in registers across its loop (97 -> 81 VGPRs).
+template <int STRIDE>
+struct LdsF {
+    int * p;
+    PRT_D operator float() const { return as_f(*p); }
+    PRT_D LdsF & operator=(float v) { *p = as_i(v); return *this; }
+    PRT_D LdsF & operator=(const LdsF & o) { *p = *o.p; return *this; }
+};
+template <int STRIDE>
+struct LdsI {
+    int * p;
+    PRT_D operator int() const { return *p; }
+    PRT_D LdsI & operator=(int v) { *p = v; return *this; }
+    PRT_D LdsI & operator=(const LdsI & o) { *p = *o.p; return *this; }
+    PRT_D int operator++(int) { const int v = *p; *p = v + 1; return v; }
+};
+template <int STRIDE>
+struct LdsF3 {
+    int * p;
+    PRT_D operator f3() const { return mk3(as_f(p[0]), as_f(p[STRIDE]), as_f(p[2 * STRIDE])); }
+    PRT_D LdsF3 & operator=(f3 v) { p[0] = as_i(v.x); p[STRIDE] = as_i(v.y); p[2 * STRIDE] = as_i(v.z); return *this; }
+    PRT_D LdsF3 & operator=(const LdsF3 & o) { return *this = (f3)o; }
+};
+template <int STRIDE>
+struct WFrameLds {
+    LdsF3<STRIDE> hit_p, hit_n, ray_d, T_in, hit_pos, kd, ks;
+    LdsF<STRIDE> alpha, w_diffuse;
+    LdsI<STRIDE> mat, stage, idx;
+    PRT_D explicit WFrameLds(int * col) {
+        hit_p.p = col; hit_n.p = col + 3 * STRIDE; ray_d.p = col + 6 * STRIDE; T_in.p = col + 9 * STRIDE;
+        hit_pos.p = col + 12 * STRIDE; kd.p = col + 15 * STRIDE; ks.p = col + 18 * STRIDE;
+        alpha.p = col + 21 * STRIDE; w_diffuse.p = col + 22 * STRIDE;
+        mat.p = col + 23 * STRIDE; stage.p = col + 24 * STRIDE; idx.p = col + 25 * STRIDE;
+    }
+};
+enum { WFRAME_LDS_DWORDS = 26 };
+
+template <bool RING, bool TEX, class FrameT>
+PRT_D void wframe_save(const WaveBuffers & B, int level, unsigned int s, const FrameT & fr) {
+    WFrame f;
+    f.hit_p = fr.hit_p; f.hit_n = fr.hit_n; f.ray_d = fr.ray_d; f.T_in = fr.T_in; f.hit_pos = fr.hit_pos; f.kd = fr.kd; f.ks = fr.ks;
+    f.alpha = fr.alpha; f.w_diffuse = fr.w_diffuse; f.mat = fr.mat; f.stage = fr.stage; f.idx = fr.idx;
     constexpr int FR4 = TEX ? 7 : RING ? 5 : 4;
     float4 * p = B.frames + ((size_t)level * FR4) * B.n_samples + s;
     p[0] = make_float4(f.hit_p.x, f.hit_p.y, f.hit_p.z, as_f(f.mat));
@@ -341,8 +383,9 @@ PRT_D void wframe_save(const WaveBuffers & B, int level, unsigned int s, const W
     }
 }
 
-template <bool RING, bool TEX>
-PRT_D void wframe_load(const WaveBuffers & B, int level, unsigned int s, WFrame & f) {
+template <bool RING, bool TEX, class FrameT>
+PRT_D void wframe_load(const WaveBuffers & B, int level, unsigned int s, FrameT & fr) {
+    WFrame f;
     constexpr int FR4 = TEX ? 7 : RING ? 5 : 4;
     const float4 * p = B.frames + ((size_t)level * FR4) * B.n_samples + s;
     const float4 a = p[0], b = p[(size_t)B.n_samples], c = p[(size_t)B.n_samples * 2], d = p[(size_t)B.n_samples * 3];
@@ -360,7 +403,12 @@ PRT_D void wframe_load(const WaveBuffers & B, int level, unsigned int s, WFrame 
         const float4 g = p[(size_t)B.n_samples * 5], h = p[(size_t)B.n_samples * 6];
         f.kd = mk3(g.x, g.y, g.z);
         f.ks = mk3(h.x, h.y, h.z);
+    } else {
+        f.kd = f.ks = mk3(0, 0, 0);
     }
+    fr.hit_p = f.hit_p; fr.hit_n = f.hit_n; fr.ray_d = f.ray_d; fr.T_in = f.T_in; fr.hit_pos = f.hit_pos;
+    if (TEX) { fr.kd = f.kd; fr.ks = f.ks; }
+    fr.alpha = f.alpha; fr.w_diffuse = f.w_diffuse; fr.mat = f.mat; fr.stage = f.stage; fr.idx = f.idx;
 }
 
 // What k_shade reads besides the queues: small read-only tables (global, or staged in LDS by the caller).
@@ -374,10 +422,10 @@ struct ShadeTables {
 // lane of the calling group must call it (the emitter aggregates appends).  emit.shadow(...) is called once per
 // light by every lane, emit.closest(...) once at the end (its last argument tells the emitter that this lane's
 // sample has no ray left - the adaptive mode of k_pool starts the pixel's next sample from there).
-template <bool RING, bool TEX, class Emit>
-PRT_D void shade_entry(const DevScene & sc, const DevParams & P, const WaveBuffers & B, const ShadeTables & tb, bool live,
-                       unsigned int s, int level, unsigned int pending, f3 ray_o, f3 ray_d, f3 T, const HitRec & hit, Emit & emit,
-                       unsigned int & shaded) {
+template <bool RING, bool TEX, class Emit, class FrameT>
+PRT_D void shade_entry_on(const DevScene & sc, const DevParams & P, const WaveBuffers & B, const ShadeTables & tb, bool live,
+                          unsigned int s, int level, unsigned int pending, f3 ray_o, f3 ray_d, f3 T, const HitRec & hit, Emit & emit,
+                          unsigned int & shaded, FrameT & f) {
     const int depth = (int)P.bounce_depth;
     Rng rng;
     rng.chain = rng.prev = rng.seed0 = 0; rng.k = 0;
@@ -397,7 +445,6 @@ PRT_D void shade_entry(const DevScene & sc, const DevParams & P, const WaveBuffe
     // ---- step 1: the hit (or miss) of the ray that just came back ----------------------------------------
     enum { M_NEXT_CHILD, M_ENTER, M_RETURN_UP, M_DONE };
     int mode = M_DONE;
-    WFrame f;
     f.hit_p = f.hit_n = f.ray_d = f.T_in = f.hit_pos = f.kd = f.ks = mk3(0, 0, 0);
     f.alpha = 1.0f; f.w_diffuse = 0.0f; f.mat = 0; f.stage = WF_STAGE_DONE; f.idx = 0;
     bool want_shadow = false;
@@ -469,9 +516,10 @@ PRT_D void shade_entry(const DevScene & sc, const DevParams & P, const WaveBuffe
                     const f3 smp = tex_sample_rgb(sc, mat.tex[2] & 0xFFFFu, tu, tv);
                     const f3 sn = smp * 2.0f - mk3(1.0f, 1.0f, 1.0f);
                     // world_from_tangent_space * sn, columns (tangent, bitangent, normal), mathlib.h:697-709; not renormalised
-                    f.hit_n = mk3((tangent.x * sn.x + bitangent.x * sn.y) + f.hit_n.x * sn.z,
-                                  (tangent.y * sn.x + bitangent.y * sn.y) + f.hit_n.y * sn.z,
-                                  (tangent.z * sn.x + bitangent.z * sn.y) + f.hit_n.z * sn.z);
+                    const f3 nn = f.hit_n;
+                    f.hit_n = mk3((tangent.x * sn.x + bitangent.x * sn.y) + nn.x * sn.z,
+                                  (tangent.y * sn.x + bitangent.y * sn.y) + nn.y * sn.z,
+                                  (tangent.z * sn.x + bitangent.z * sn.y) + nn.z * sn.z);
                 }
                 f.hit_pos = pos;
                 f.hit_p = pos + gn * P.ray_bias;                                    // raytracer.cpp:425
@@ -612,6 +660,24 @@ PRT_D void shade_entry(const DevScene & sc, const DevParams & P, const WaveBuffe
         if (RING) B.rng_aux[s] = make_ulonglong2(rng.seed0, (u64)rng.k);
     }
     emit.closest(emit_closest, s, next_o, next_d, next_T, next_level, pending, live && !emit_closest);
+}
+
+// The frame in registers (k_shade) ...
+template <bool RING, bool TEX, class Emit>
+PRT_D void shade_entry(const DevScene & sc, const DevParams & P, const WaveBuffers & B, const ShadeTables & tb, bool live,
+                       unsigned int s, int level, unsigned int pending, f3 ray_o, f3 ray_d, f3 T, const HitRec & hit, Emit & emit,
+                       unsigned int & shaded) {
+    WFrame f;
+    shade_entry_on<RING, TEX>(sc, P, B, tb, live, s, level, pending, ray_o, ray_d, T, hit, emit, shaded, f);
+}
+
+// ... or in the lane's LDS column `col` (stride STRIDE dwords between fields; WFRAME_LDS_DWORDS fields).
+template <bool RING, bool TEX, int STRIDE, class Emit>
+PRT_D void shade_entry_lds(const DevScene & sc, const DevParams & P, const WaveBuffers & B, const ShadeTables & tb, bool live,
+                           unsigned int s, int level, unsigned int pending, f3 ray_o, f3 ray_d, f3 T, const HitRec & hit, Emit & emit,
+                           unsigned int & shaded, int * col) {
+    WFrameLds<STRIDE> f(col);
+    shade_entry_on<RING, TEX>(sc, P, B, tb, live, s, level, pending, ray_o, ray_d, T, hit, emit, shaded, f);
 }
 
 // Emitter of k_shade: workgroup-aggregated appends to the global next-round queues.

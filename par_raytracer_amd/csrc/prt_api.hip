@@ -467,7 +467,8 @@ int render_wavefront(prt_ctx * ctx, const DevCamera & cam, const DevParams & P, 
 // workspace, without the global queues), plus cap (+ cap * lights shadow) ray slots per resident wave.
 template <int BLOCK, int WAVES, bool LDSTAB, bool RING, bool TEX, bool ADAPT>
 int launch_pool(prt_ctx * ctx, bool count, const DevCamera & cam, DevParams P, unsigned int n_samples, unsigned int stack_entries) {
-    const size_t lds = (size_t)stack_entries * BLOCK * sizeof(int);
+    // the stack columns double as the shading phase's frame storage (WFRAME_LDS_DWORDS per lane)
+    const size_t lds = (size_t)std::max(stack_entries, (unsigned int)WFRAME_LDS_DWORDS) * BLOCK * sizeof(int);
     int per_cu = 0;
     hipError_t oe = count ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_pool<BLOCK, WAVES, LDSTAB, RING, true, TEX, ADAPT>, BLOCK, lds)
                           : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_pool<BLOCK, WAVES, LDSTAB, RING, false, TEX, ADAPT>, BLOCK, lds);
