@@ -81,55 +81,84 @@ struct PoolEmit {
 
 PRT_D void pool_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }
 
-// grid = resident blocks; dynamic LDS = stack_entries * BLOCK * 4 (traversal stack columns).
+// Everything the kernel is told, in device memory.  Passed by value these ~130 dwords are loaded into SGPRs at kernel
+// entry and stay live through every loop; the kernel then spills ~170 SGPRs into VGPR lanes and reloads them with
+// v_readlane inside the traversal loop (45 of its 250 VALU instructions, measured).  Instead each phase of the main loop
+// reads what it needs through a pointer the compiler cannot see through (pool_args), as scalar loads from the
+// constant address space, and the values die with the phase.
+struct PoolArgs {
+    DevScene sc;
+    DevCamera cam;
+    DevParams P;
+    WaveBuffers B;
+    PoolBuffers Q;
+    int keep_min, node_min, multi_light, pad;
+};
+typedef const PoolArgs __attribute__((address_space(4))) * PoolArgsPtr;
+
+// Pointers read from memory have no known address space: tell the compiler they are global, or every access through them
+// becomes a FLAT instruction with a 64-bit VGPR address.
+template <class T>
+PRT_D T * as_global(T * p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_assume(!__builtin_amdgcn_is_shared((const void *)p));
+    __builtin_assume(!__builtin_amdgcn_is_private((const void *)p));
+#endif
+    return p;
+}
+
+PRT_D PoolArgs pool_args(const PoolArgs * args) {
+    asm volatile("" : "+s"(args));                 // a fresh value as far as the optimiser knows: no load is hoisted above this point
+    PoolArgs A;
+    __builtin_memcpy(&A, (PoolArgsPtr)args, sizeof(PoolArgs));      // constant address space: uniform scalar loads
+    A.sc.nodes = as_global(A.sc.nodes); A.sc.tris = as_global(A.sc.tris); A.sc.shade = as_global(A.sc.shade);
+    A.sc.tri_rank = as_global(A.sc.tri_rank); A.sc.materials = as_global(A.sc.materials); A.sc.lights = as_global(A.sc.lights);
+    A.sc.diffuse_dirs = as_global(A.sc.diffuse_dirs); A.sc.spec_dirs = as_global(A.sc.spec_dirs);
+    A.sc.textures = as_global(A.sc.textures); A.sc.texels = as_global(A.sc.texels); A.sc.srgb_lut = as_global(A.sc.srgb_lut);
+    A.sc.tri_uv = as_global(A.sc.tri_uv); A.sc.tri_tan = as_global(A.sc.tri_tan);
+    A.P.pixel_list = as_global(A.P.pixel_list); A.P.stack_spill = as_global(A.P.stack_spill);
+    A.B.accum = as_global(A.B.accum); A.B.rng = as_global(A.B.rng); A.B.rng_aux = as_global(A.B.rng_aux); A.B.ring = as_global(A.B.ring);
+    A.B.frames = as_global(A.B.frames);
+    A.Q.cq = as_global(A.Q.cq); A.Q.hits = as_global(A.Q.hits); A.Q.sq = as_global(A.Q.sq); A.Q.head = as_global(A.Q.head);
+    A.Q.fin = as_global(A.Q.fin); A.Q.scratch = as_global(A.Q.scratch); A.Q.jobsum = as_global(A.Q.jobsum); A.Q.final_rgb = as_global(A.Q.final_rgb);
+    return A;
+}
+
+// grid = resident blocks; dynamic LDS = max(stack_entries, WFRAME_LDS_DWORDS) * BLOCK * 4 (traversal stack columns).
 template <int BLOCK, int WAVES, bool LDSTAB, bool RING, bool COUNT, bool TEX, bool ADAPT>
-__global__ __launch_bounds__(BLOCK, WAVES) void k_pool(DevScene sc, DevCamera cam, DevParams P, WaveBuffers B, PoolBuffers Q, int keep_min,
-                                                 int node_min, int multi_light, DevCounters * ctr) {
+__global__ __launch_bounds__(BLOCK, WAVES) void k_pool(const PoolArgs * args, DevCounters * ctr) {
     extern __shared__ int s_stack[];
     constexpr int LDS_MATS = 32, LDS_LIGHTS = 4;
     __shared__ float4 s_diffuse[LDSTAB ? 1024 : 1];
     __shared__ DevMaterial s_mats[LDS_MATS];
     __shared__ DevLight s_lights[LDS_LIGHTS];
     __shared__ unsigned long long s_red[2];
-    const bool lds_mats = sc.material_count <= (unsigned int)LDS_MATS;
-    const bool lds_lights = sc.light_count <= (unsigned int)LDS_LIGHTS;
-    if (LDSTAB) for (unsigned int k = threadIdx.x; k < 1024u; k += BLOCK) s_diffuse[k] = sc.diffuse_dirs[k];
-    if (lds_mats) {
-        const float4 * src = reinterpret_cast<const float4 *>(sc.materials);
-        float4 * dst = reinterpret_cast<float4 *>(s_mats);
-        for (unsigned int k = threadIdx.x; k < sc.material_count * 4u; k += BLOCK) dst[k] = src[k];
-    }
-    if (lds_lights) {
-        const float4 * src = reinterpret_cast<const float4 *>(sc.lights);
-        float4 * dst = reinterpret_cast<float4 *>(s_lights);
-        for (unsigned int k = threadIdx.x; k < sc.light_count * 3u; k += BLOCK) dst[k] = src[k];
+    {
+        const PoolArgs A0 = pool_args(args);
+        const DevScene & sc = A0.sc;
+        if (LDSTAB) for (unsigned int k = threadIdx.x; k < 1024u; k += BLOCK) s_diffuse[k] = sc.diffuse_dirs[k];
+        if (sc.material_count <= (unsigned int)LDS_MATS) {
+            const float4 * src = reinterpret_cast<const float4 *>(sc.materials);
+            float4 * dst = reinterpret_cast<float4 *>(s_mats);
+            for (unsigned int k = threadIdx.x; k < sc.material_count * 4u; k += BLOCK) dst[k] = src[k];
+        }
+        if (sc.light_count <= (unsigned int)LDS_LIGHTS) {
+            const float4 * src = reinterpret_cast<const float4 *>(sc.lights);
+            float4 * dst = reinterpret_cast<float4 *>(s_lights);
+            for (unsigned int k = threadIdx.x; k < sc.light_count * 3u; k += BLOCK) dst[k] = src[k];
+        }
     }
     if (threadIdx.x < 2) s_red[threadIdx.x] = 0ull;
     __syncthreads();
-    ShadeTables tb;
-    tb.diffuse = LDSTAB ? s_diffuse : sc.diffuse_dirs;
-    tb.materials = lds_mats ? s_mats : sc.materials;
-    tb.lights = lds_lights ? s_lights : sc.lights;
 
-    LdsStack<BLOCK> stack;
-    stack.col = s_stack + threadIdx.x;
-    stack.cap = P.stack_lds_entries;
     const unsigned int slot_id = blockIdx.x * BLOCK + threadIdx.x;
-    GlobalStack slow;
-    slow.col = P.stack_spill + slot_id;
-    slow.stride = P.stack_spill_stride;
     const unsigned int lane = lane_id();
     const unsigned int wave = (unsigned int)__builtin_amdgcn_readfirstlane((int)(slot_id >> 6));      // scalar: the list pointers stay in SGPRs
-    const unsigned int cap = Q.cap, scap = Q.scap;
-    float4 * const cq_base = Q.cq + (size_t)wave * 6u * cap;
-    float4 * const hits = Q.hits + (size_t)wave * cap;
-    float4 * const sq_o = Q.sq + (size_t)wave * 3u * scap;
-    float4 * const sq_c = sq_o + scap;
-    float4 * const sq_d = sq_c + scap;
+    LdsStack<BLOCK> stack;
+    stack.col = s_stack + threadIdx.x;
+    stack.cap = ((PoolArgsPtr)args)->P.stack_lds_entries;
 
-    unsigned int * const fin = ADAPT ? Q.fin + (size_t)wave * cap : nullptr;
     unsigned int n_f = 0;                      // wave-uniform (ADAPT): pixels waiting to be finalised
-
     int cur = 0;
     unsigned int n_c = 0, n_s = 0;             // wave-uniform: rays in the current closest / shadow list
     bool fetch_done = false;                   // wave-uniform: the sample counter ran past n_samples
@@ -138,13 +167,28 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_pool(DevScene sc, DevCamera ca
     TraceStats st;
     st.nodes = st.tris = st.wnodes = st.wleaves = st.wtris = st.wrefills = st.max_sp = st.culled = 0;
 
-    for (;;) {
-        float4 * const co = cq_base + (size_t)cur * 3u * cap;
-        float4 * const cd = co + cap;
-        float4 * const ct = cd + cap;
+// this wave's lists, from the arguments as re-read in the current phase
+#define PRT_POOL_LISTS(A)                                                                              \
+    const unsigned int cap = (A).Q.cap, scap = (A).Q.scap;                                            \
+    float4 * const cq_base = (A).Q.cq + (size_t)wave * 6u * cap;                                      \
+    float4 * const hits = (A).Q.hits + (size_t)wave * cap;                                            \
+    float4 * const sq_o = (A).Q.sq + (size_t)wave * 3u * scap;                                        \
+    float4 * const sq_c = sq_o + scap;                                                                \
+    float4 * const sq_d = sq_c + scap;                                                                \
+    float4 * const co = cq_base + (size_t)cur * 3u * cap;                                             \
+    float4 * const cd = co + cap;                                                                     \
+    float4 * const ct = cd + cap;                                                                     \
+    (void)hits; (void)sq_o; (void)sq_c; (void)sq_d; (void)ct
 
+    for (;;) {
         // ---- top up: fresh samples into the free closest-hit slots ------------------------------------------
-        if (!fetch_done && n_c + n_f + Q.topup_min <= cap) {
+        if (!fetch_done) {
+          const PoolArgs A = pool_args(args);
+          const DevParams & P = A.P;
+          const WaveBuffers & B = A.B;
+          const PoolBuffers & Q = A.Q;
+          PRT_POOL_LISTS(A);
+          if (n_c + n_f + Q.topup_min <= cap) {
             const unsigned int want = cap - n_c - n_f;
             unsigned int base = 0;
             if (lane == 0) base = atomicAdd(Q.head, want);
@@ -154,6 +198,7 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_pool(DevScene sc, DevCamera ca
             } else {
                 unsigned int cnt = B.n_samples - base;
                 if (cnt <= want) fetch_done = true; else cnt = want;
+                const DevCamera cam = A.cam;
                 for (unsigned int k = lane; k < cnt; k += 64u) {
                     const unsigned int sid = base + k;
                     const unsigned int gsid = B.sample_base + sid;
@@ -176,6 +221,7 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_pool(DevScene sc, DevCamera ca
                 }
                 n_c += cnt;
             }
+          }
         }
         const unsigned int total = n_c + n_s;
         if (total == 0u && n_f == 0u) {
@@ -187,6 +233,16 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_pool(DevScene sc, DevCamera ca
 
         // ---- trace: every ray of the pool ------------------------------------------------------------------
         {
+            const PoolArgs A = pool_args(args);
+            const DevScene & sc = A.sc;
+            const DevParams & P = A.P;
+            const WaveBuffers & B = A.B;
+            const int keep_min = A.keep_min, node_min = A.node_min, multi_light = A.multi_light;
+            PRT_POOL_LISTS(A);
+            const DevLight * lights = sc.light_count <= (unsigned int)LDS_LIGHTS ? s_lights : sc.lights;
+            GlobalStack slow;
+            slow.col = P.stack_spill + slot_id;
+            slow.stride = P.stack_spill_stride;
             TravRay r;
             r.node = TRAV_SENTINEL; r.sp = 0; r.kind = 0; r.overflow = false;
             int ray = -1;
@@ -214,7 +270,7 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_pool(DevScene sc, DevCamera ca
                             ro = sq_o[j];
                             payload = sq_c[j];
                             if (payload.w < 0.0f) {          // directional light: the direction is a per-light constant
-                                const DevLight & L = tb.lights[(unsigned int)(-payload.w) - 1u];
+                                const DevLight & L = lights[(unsigned int)(-payload.w) - 1u];
                                 const f3 lv = mk3(L.facing[0], L.facing[1], L.facing[2]) * -1.0f;   // raytracer.cpp:240
                                 rd = make_float4(lv.x, lv.y, lv.z, 0.0f);
                                 kind = WF_KIND_SHADOW_ANY;
@@ -278,6 +334,17 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_pool(DevScene sc, DevCamera ca
 
         // ---- shade: every closest hit of the pool, 64 per pass ----------------------------------------------
         {
+            const PoolArgs A = pool_args(args);
+            const DevScene & sc = A.sc;
+            const DevParams & P = A.P;
+            const WaveBuffers & B = A.B;
+            const PoolBuffers & Q = A.Q;
+            PRT_POOL_LISTS(A);
+            unsigned int * const fin = ADAPT ? Q.fin + (size_t)wave * cap : nullptr;
+            ShadeTables tb;
+            tb.diffuse = LDSTAB ? s_diffuse : sc.diffuse_dirs;
+            tb.materials = sc.material_count <= (unsigned int)LDS_MATS ? s_mats : sc.materials;
+            tb.lights = sc.light_count <= (unsigned int)LDS_LIGHTS ? s_lights : sc.lights;
             const int nxt = cur ^ 1;
             PoolEmit<ADAPT> emit;
             emit.co = cq_base + (size_t)nxt * 3u * cap;
@@ -338,6 +405,7 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_pool(DevScene sc, DevCamera ca
                             const float jitter = samp < P.spp ? 0.5f : 1.0f;        // main.cpp:240 vs :249
                             const unsigned int pixel = pixel_of_local(P, B.sample_base + j);
                             const unsigned int x = pixel % P.width, y = pixel / P.width;
+                            const DevCamera cam = A.cam;
                             ray_o = cam.position;
                             ray_d = make_camera_dir(cam, (float)x + off_x * jitter, (float)y + off_y * jitter);
                             go_on = true;
@@ -401,5 +469,7 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_pool(DevScene sc, DevCamera ca
         atomicAdd(&ctr->culled, (unsigned long long)st.culled);
     }
 }
+
+#undef PRT_POOL_LISTS
 
 }  // namespace prt

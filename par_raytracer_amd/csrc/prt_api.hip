@@ -118,6 +118,7 @@ struct prt_ctx {
     DevBuf<unsigned int> wf_counts;       // persistent / pool pipelines' sample counter
     DevBuf<float4> pool_f4;               // pool pipeline: the waves' private ray lists
     DevBuf<unsigned int> pool_fin;        // adaptive mode: per-wave lists of pixels to finalise
+    DevBuf<PoolArgs> pool_args;           // k_pool's arguments (read per phase from memory, kernels_pool.h)
     DevBuf<float4> adapt_f4;              // adaptive mode: scratch [max_spp][n] + running sums [n] + final colours [n]
     int cu_count = 0;
     unsigned int stack_bound = 0;
@@ -535,12 +536,22 @@ int launch_pool(prt_ctx * ctx, bool count, const DevCamera & cam, DevParams P, u
     if (const char * e = getenv("PRT_KEEP_MIN")) keep_min = std::max(1, std::min(64, atoi(e)));
     if (const char * e = getenv("PRT_NODE_MIN")) node_min = std::max(0, std::min(64, atoi(e)));
     const int multi_light = ctx->scene.light_count > 1 ? 1 : 0;
+    PoolArgs A;
+    memset(&A, 0, sizeof(A));
+    A.sc = ctx->scene;
+    A.cam = cam;
+    A.P = P;
+    A.B = B;
+    A.Q = Q;
+    A.keep_min = keep_min;
+    A.node_min = node_min;
+    A.multi_light = multi_light;
+    HIP_TRY(ctx, ctx->pool_args.ensure(1));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->pool_args.p, &A, sizeof(A), hipMemcpyHostToDevice, ctx->stream));   // pageable source: staged before return
     if (count)
-        hipLaunchKernelGGL((k_pool<BLOCK, WAVES, LDSTAB, RING, true, TEX, ADAPT>), dim3(grid), dim3(BLOCK), lds, ctx->stream, ctx->scene, cam, P, B, Q, keep_min, node_min,
-                           multi_light, ctx->counters.p);
+        hipLaunchKernelGGL((k_pool<BLOCK, WAVES, LDSTAB, RING, true, TEX, ADAPT>), dim3(grid), dim3(BLOCK), lds, ctx->stream, ctx->pool_args.p, ctx->counters.p);
     else
-        hipLaunchKernelGGL((k_pool<BLOCK, WAVES, LDSTAB, RING, false, TEX, ADAPT>), dim3(grid), dim3(BLOCK), lds, ctx->stream, ctx->scene, cam, P, B, Q, keep_min, node_min,
-                           multi_light, ctx->counters.p);
+        hipLaunchKernelGGL((k_pool<BLOCK, WAVES, LDSTAB, RING, false, TEX, ADAPT>), dim3(grid), dim3(BLOCK), lds, ctx->stream, ctx->pool_args.p, ctx->counters.p);
     return 0;
 }
 
@@ -878,7 +889,7 @@ void prt_destroy(prt_ctx * ctx) {
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     ctx->nodes.release(); ctx->tris.release(); ctx->shade.release(); ctx->diffuse_dirs.release(); ctx->spec_dirs.release();
     ctx->tri_rank.release(); ctx->materials.release(); ctx->lights.release();
-    ctx->sample_rgb.release(); ctx->frame_out.release(); ctx->counters.release(); ctx->ring_ws.release(); ctx->pixel_list.release(); ctx->wf_counts.release(); ctx->stack_spill.release(); ctx->pool_f4.release(); ctx->pool_fin.release(); ctx->adapt_f4.release();
+    ctx->sample_rgb.release(); ctx->frame_out.release(); ctx->counters.release(); ctx->ring_ws.release(); ctx->pixel_list.release(); ctx->wf_counts.release(); ctx->stack_spill.release(); ctx->pool_f4.release(); ctx->pool_fin.release(); ctx->pool_args.release(); ctx->adapt_f4.release();
     ctx->textures.release(); ctx->texels.release(); ctx->srgb_lut.release(); ctx->tri_uv.release(); ctx->tri_tan.release();
     for (int c = 0; c < PRT_MAX_CHAINS; ++c) {
         prt_ctx::ChainWs & w = ctx->chain[c];
