@@ -666,6 +666,11 @@ int render_pixels(prt_ctx * ctx, const prt_camera * cam_in, const prt_params * p
         return -1;
     }
 
+    // The pool kernel always runs its general-RNG variant: with the draw ring in memory it fits 96 VGPRs with 29 dwords
+    // spilled and runs 5 waves per SIMD, where the 2-register RNG variant spills 105 (measured: 14.7 vs 15.3 ms per C4 frame
+    // at 4 waves per SIMD; same random numbers either way).
+    const bool ring_eff = ring || pipeline == PRT_PIPELINE_POOL;
+
     // Passes.  The per-sample workspace (radiance, RNG, pending frames, ray queues) is 100 B .. 1 KB per sample, so a
     // 4K x 64 spp frame (530 M samples) does not fit any GPU in one piece: the call's pixel set is rendered in passes of
     // whole pixels, each at most 64 M samples and at most 64 GB of workspace (PRT_PASS_SAMPLES / PRT_PASS_MB override).
@@ -674,10 +679,10 @@ int render_pixels(prt_ctx * ctx, const prt_camera * cam_in, const prt_params * p
     const unsigned long long total_samples = (unsigned long long)px.n_pixels * unit_spp;
     unsigned int pass_pixels = px.n_pixels;
     {
-        const unsigned long long lv = std::max(1u, P.bounce_depth), fr4 = ctx->textured ? 7 : ring ? 5 : 4, nl = std::max(1u, ctx->scene.light_count);
-        unsigned long long per_sample = 16 + (ring && pipeline != PRT_PIPELINE_PERSISTENT ? 128 : 0);
+        const unsigned long long lv = std::max(1u, P.bounce_depth), fr4 = ctx->textured ? 7 : ring_eff ? 5 : 4, nl = std::max(1u, ctx->scene.light_count);
+        unsigned long long per_sample = 16 + (ring_eff && pipeline != PRT_PIPELINE_PERSISTENT ? 128 : 0);
         if (pipeline == PRT_PIPELINE_WAVEFRONT) per_sample += (lv * fr4 + 7 + 3 * nl) * 16 + (ring ? 32 : 16) + 4 * (1 + nl);
-        if (pipeline == PRT_PIPELINE_POOL) per_sample += lv * fr4 * 16 + (ring ? 32 : 16);
+        if (pipeline == PRT_PIPELINE_POOL) per_sample += lv * fr4 * 16 + 32;
         if (adaptive) per_sample += ((unsigned long long)P.max_spp + 2) * 16;
         if (pipeline == PRT_PIPELINE_MEGAKERNEL && ctx->stack_bound > 24) per_sample += 4ull * ctx->stack_bound;
         unsigned long long max_samples = 64ull << 20, max_mb = 64ull << 10;
@@ -695,7 +700,7 @@ int render_pixels(prt_ctx * ctx, const prt_camera * cam_in, const prt_params * p
     if (n_samples64 > 0x7FFFFFFFull) { ctx->error = "prt_render: spp too large for one pixel per pass"; return -1; }
     HIP_TRY(ctx, ctx->sample_rgb.ensure(n_samples64));
     HIP_TRY(ctx, ctx->counters.ensure(1));
-    if (ring && pipeline != PRT_PIPELINE_PERSISTENT) HIP_TRY(ctx, ctx->ring_ws.ensure(n_samples64 * 16));
+    if (ring_eff && pipeline != PRT_PIPELINE_PERSISTENT) HIP_TRY(ctx, ctx->ring_ws.ensure(n_samples64 * 16));
 
     // Traversal stack: LDS column of up to STACK_LDS_CAP entries per lane (occupancy); rays that would need more
     // - 3 pushes per 4-wide level are possible, nothing real comes close - are re-traced on a full-height global
@@ -762,13 +767,17 @@ int render_pixels(prt_ctx * ctx, const prt_camera * cam_in, const prt_params * p
             // blocks of the next frame's kernel in - at a finer grain: with two frames in flight a 1/8-frame shard takes
             // 2.24 ms per frame instead of 2.59 with 512-thread blocks.  Measured alternatives at other occupancies: 5 waves
             // per SIMD (96 VGPRs, 93 dwords spilled) 29-31 ms, 6 waves (80 VGPRs, 154 spilled) 29.5 ms on a C4 frame.
+            // 256-thread blocks, the Hammersley direction table in global memory (staging it in LDS measured 17.04 vs 17.15 ms:
+            // nothing).  Small blocks retire - and let the blocks of the next frame's kernel in - at a finer grain: with two
+            // frames in flight a 1/8-frame shard takes 2.24 ms per frame instead of 2.59 with 512-thread blocks.
+            // Untextured fixed-spp renders: 5 waves per SIMD (96 VGPRs, 29 dwords spilled).  Textured (64 spilled at 96) and
+            // adaptive (41; no gain measured) renders: 4 waves per SIMD.  6 waves (80 VGPRs) spill 90-230 dwords: 29 ms.
             if (adaptive)
                 rc = ctx->textured ? launch_pool<256, 4, false, true, true, true>(ctx, count_visits, cam, P, n_samples, stack_entries)
                                    : launch_pool<256, 4, false, true, false, true>(ctx, count_visits, cam, P, n_samples, stack_entries);
             else
                 rc = ctx->textured ? launch_pool<256, 4, false, true, true, false>(ctx, count_visits, cam, P, n_samples, stack_entries)
-                   : ring ? launch_pool<256, 4, false, true, false, false>(ctx, count_visits, cam, P, n_samples, stack_entries)
-                          : launch_pool<256, 4, false, false, false, false>(ctx, count_visits, cam, P, n_samples, stack_entries);
+                                   : launch_pool<256, 5, false, true, false, false>(ctx, count_visits, cam, P, n_samples, stack_entries);
             launches += 1;
         } else {
             unsigned long long rays = 0;
