@@ -124,6 +124,12 @@ PRT_D PoolArgs pool_args(const PoolArgs * args) {
     return A;
 }
 
+// Puts the arguments where k_pool reads them.  A kernel rather than a hipMemcpyAsync: kernel arguments are captured at
+// launch, whatever the runtime does with asynchronous copies from pageable memory.
+__global__ void k_pool_store_args(PoolArgs a, PoolArgs * dst) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) *dst = a;
+}
+
 // grid = resident blocks; dynamic LDS = max(stack_entries, WFRAME_LDS_DWORDS) * BLOCK * 4 (traversal stack columns).
 template <int BLOCK, int WAVES, bool LDSTAB, bool RING, bool COUNT, bool TEX, bool ADAPT>
 __global__ __launch_bounds__(BLOCK, WAVES) void k_pool(const PoolArgs * args, DevCounters * ctr) {

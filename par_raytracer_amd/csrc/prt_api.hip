@@ -547,7 +547,7 @@ int launch_pool(prt_ctx * ctx, bool count, const DevCamera & cam, DevParams P, u
     A.node_min = node_min;
     A.multi_light = multi_light;
     HIP_TRY(ctx, ctx->pool_args.ensure(1));
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->pool_args.p, &A, sizeof(A), hipMemcpyHostToDevice, ctx->stream));   // pageable source: staged before return
+    hipLaunchKernelGGL(k_pool_store_args, dim3(1), dim3(64), 0, ctx->stream, A, ctx->pool_args.p);
     if (count)
         hipLaunchKernelGGL((k_pool<BLOCK, WAVES, LDSTAB, RING, true, TEX, ADAPT>), dim3(grid), dim3(BLOCK), lds, ctx->stream, ctx->pool_args.p, ctx->counters.p);
     else
