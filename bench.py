@@ -106,6 +106,8 @@ def main():
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if args.backend == "nccl":
+            # the gather shares the GPU with persistent render kernels that fill every wave slot: let its kernels go first
+            os.environ.setdefault("TORCH_NCCL_HIGH_PRIORITY", "1")
             dist.init_process_group("nccl", device_id=dev)          # RCCL over xGMI
         else:
             dist.init_process_group("gloo")
@@ -153,9 +155,12 @@ def main():
     my_rows = r.shard_rows(height, SHARD_BLOCK_ROWS, rank, world)
     assert my_rows == sharding.shard_rows(height, SHARD_BLOCK_ROWS, rank, world)
     max_rows = sharding.max_shard_rows(height, SHARD_BLOCK_ROWS, world)
-    shards = [torch.zeros((max_rows, width, 4), dtype=torch.float32, device=dev) for _ in range(F)]
+    # more output buffers than contexts: a buffer is only reused NB frames later, so a gather that the GPU schedules late
+    # (the persistent render kernels leave it few free wave slots) does not stall the frames behind it
+    NB = F + 2 if world > 1 else F
+    shards = [torch.zeros((max_rows, width, 4), dtype=torch.float32, device=dev) for _ in range(NB)]
     shard = shards[0]
-    gathered = [None] * F                  # per buffer: event recorded after the RCCL gather that read it
+    gathered = [None] * NB                 # per buffer: event recorded after the RCCL gather that read it
     gather_list = None
     row_index = None
     frame = None
@@ -163,9 +168,9 @@ def main():
         gather_list = [torch.empty_like(shard) for _ in range(world)]
         row_index = torch.from_numpy(sharding.row_index(height, SHARD_BLOCK_ROWS, world)).to(dev)
 
-    def render_frame(slot):
-        """Render one frame into buffer `slot` on context `slot` (called from a worker thread when F > 1)."""
-        rr, buf = renderers[slot], shards[slot]
+    def render_frame(slot, bslot=None):
+        """Render one frame into buffer `bslot` on context `slot` (called from a worker thread when F > 1)."""
+        rr, buf = renderers[slot], shards[slot if bslot is None else bslot]
         if world == 1:
             return rr.render_device(cam, params, width, height, 0, width * height, buf.data_ptr(), True)
         return rr.render_shard_device(cam, params, width, height, SHARD_BLOCK_ROWS, rank, world, buf.data_ptr(), True)
@@ -196,18 +201,18 @@ def main():
         """n frames, at most F in flight.  Returns the per-frame counters in frame order."""
         out, pending = [], []
         for k in range(n):
-            slot = k % F
-            if len(pending) == F:                                   # the frame that used this slot F frames ago
-                s0, fut = pending.pop(0)
+            slot, bslot = k % F, k % NB
+            if len(pending) == F:                                   # the frame that used this context F frames ago
+                b0, fut = pending.pop(0)
                 out.append(fut.result() if pool else fut)
-                deliver_frame(s0)
-            if gathered[slot] is not None:
-                gathered[slot].synchronize()                        # its gather must have read the buffer before we overwrite it
-                gathered[slot] = None
-            pending.append((slot, pool.submit(render_frame, slot) if pool else render_frame(slot)))
-        for s0, fut in pending:
+                deliver_frame(b0)
+            if gathered[bslot] is not None:
+                gathered[bslot].synchronize()                       # its gather must have read the buffer before we overwrite it
+                gathered[bslot] = None
+            pending.append((bslot, pool.submit(render_frame, slot, bslot) if pool else render_frame(slot, bslot)))
+        for b0, fut in pending:
             out.append(fut.result() if pool else fut)
-            deliver_frame(s0)
+            deliver_frame(b0)
         return out
 
     def sync_all():
