@@ -37,4 +37,3 @@ if "blocks" in which: sweep("blocks", {"PRT_POOL_BLOCKS_PER_CU": [1, 2]})
 if "topup" in which: sweep("topup", {"PRT_POOL_CAP": [256, 512], "PRT_POOL_TOPUP": [64, 128, 256]})
 if "default" in which: sweep("default", {"PRT_POOL_NOP": [0]})
 if "stagger" in which: sweep("stagger", {"PRT_POOL_STAGGER": [0, 1], "PRT_POOL_CAP": [256, 512], "PRT_POOL_TOPUP": [64, None]})
-if "variant" in which: sweep("variant", {"PRT_POOL_VARIANT": [0, 1, 2, 3, 4]})
