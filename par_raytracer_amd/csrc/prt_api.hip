@@ -1273,10 +1273,15 @@ int prt_debug_device_kat(prt_ctx * ctx, int kind, const void * in, size_t in_byt
     if (!ctx->has_scene) { ctx->error = "prt_debug_device_kat: upload a scene first"; return -2; }
     if (!in || !out || !n) { ctx->error = "prt_debug_device_kat: null buffers"; return -1; }
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    void * d_in = nullptr;
-    void * d_out = nullptr;
-    HIP_TRY(ctx, hipMalloc(&d_in, in_bytes));
-    HIP_TRY(ctx, hipMalloc(&d_out, out_bytes));
+    // scratch buffers owned by DevBuf objects: released on every return path
+    struct Scratch {
+        DevBuf<unsigned char> in, out;
+        ~Scratch() { in.release(); out.release(); }
+    } scratch;
+    HIP_TRY(ctx, scratch.in.ensure(in_bytes));
+    HIP_TRY(ctx, scratch.out.ensure(out_bytes));
+    void * d_in = scratch.in.p;
+    void * d_out = scratch.out.p;
     HIP_TRY(ctx, ctx->ring_ws.ensure((size_t)16 * n));
     // everything on the context's stream: it is a non-blocking stream, so work on the null stream (a plain hipMemset)
     // is NOT ordered against the kernel below
@@ -1296,8 +1301,6 @@ int prt_debug_device_kat(prt_ctx * ctx, int kind, const void * in, size_t in_byt
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     HIP_TRY(ctx, hipMemcpy(out, d_out, out_bytes, hipMemcpyDeviceToHost));
-    (void)hipFree(d_in);
-    (void)hipFree(d_out);
     return 0;
 }
 
