@@ -215,6 +215,9 @@ int prt_get_scene_info(const prt_ctx * ctx, prt_scene_info * info);
  * CPU test-suite calls it): every triangle inside every ancestor's de-quantised box, every triangle in
  * exactly one leaf, links in range.  out[6] = { violations, nodes, depth, stack bound, leaves, triangle refs }. */
 int prt_debug_check_bvh(const prt_scene_desc * scene, uint64_t * out);
+/* The same check on the tree of the GPU LBVH builder (environment PRT_BVH_BUILDER=lbvh at upload: radix tree built on the
+ * device, bvh_lbvh.h; an alternative for scenes that change every frame - ~10x faster to build, slower to traverse). */
+int prt_debug_check_bvh_lbvh(prt_ctx * ctx, const prt_scene_desc * scene, uint64_t * out);
 
 /* Device known-answer hook (GPU test-suite): runs one device function of the hot path on `n` caller-supplied
  * records (host pointers) and returns its outputs, so tests can compare them bit for bit with the reference's.

@@ -93,7 +93,7 @@ FLAG_COUNT_VISITS = 0x100
 
 # Every symbol include/prt.h declares; tests/test_capi_symbols.py checks the library exports them all.
 PRT_SYMBOLS = ["prt_create", "prt_destroy", "prt_last_error", "prt_abi_version", "prt_upload_scene", "prt_render",
-               "prt_render_device", "prt_shard_rows", "prt_render_shard_device", "prt_render_shard", "prt_render_pixel_list", "prt_get_scene_info", "prt_debug_check_bvh", "prt_debug_device_kat"]
+               "prt_render_device", "prt_shard_rows", "prt_render_shard_device", "prt_render_shard", "prt_render_pixel_list", "prt_get_scene_info", "prt_debug_check_bvh", "prt_debug_check_bvh_lbvh", "prt_debug_device_kat"]
 PRT_HOST_SYMBOLS = ["prt_host_load_obj", "prt_host_free_scene", "prt_host_scene_desc", "prt_host_scene_hierarchy_seconds",
                     "prt_host_scene_parse_seconds", "prt_host_last_error", "prt_host_make_camera",
                     "prt_host_default_params", "prt_host_render", "prt_host_write_image", "prt_host_tonemap",
@@ -141,6 +141,7 @@ def hip_lib() -> C.CDLL:
                                               C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(PrtCounters)]
         lib.prt_get_scene_info.argtypes = [C.c_void_p, C.POINTER(PrtSceneInfo)]
         lib.prt_debug_check_bvh.argtypes = [C.POINTER(PrtSceneDesc), C.POINTER(C.c_uint64)]
+        lib.prt_debug_check_bvh_lbvh.argtypes = [C.c_void_p, C.POINTER(PrtSceneDesc), C.POINTER(C.c_uint64)]
         lib.prt_debug_device_kat.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_uint32,
                                              C.POINTER(PrtCamera)]
         _hip = lib

@@ -273,42 +273,10 @@ inline uint32_t float_bits(float f) {
 
 }  // namespace
 
-void build_bvh4q(const float * verts, uint32_t n_tris, uint32_t leaf_max, uint32_t threads, Bvh4Result * out, float trav_cost) {
-    *out = Bvh4Result();
-    if (leaf_max < 1) leaf_max = 1;
-    if (leaf_max > 4) leaf_max = 4;
-    Builder b;
-    b.leaf_max = leaf_max;
-    b.trav_cost = trav_cost;
-    b.prims.resize(n_tris);
-    Box scene;
-    scene.reset();
-    for (uint32_t i = 0; i < n_tris; ++i) {
-        Prim & p = b.prims[i];
-        p.box.reset();
-        p.box.grow(verts + 9 * (size_t)i);
-        p.box.grow(verts + 9 * (size_t)i + 3);
-        p.box.grow(verts + 9 * (size_t)i + 6);
-        for (int a = 0; a < 3; ++a) p.c[a] = 0.5f * p.box.lo[a] + 0.5f * p.box.hi[a];
-        p.id = i;
-        scene.grow(p.box);
-    }
-    for (int a = 0; a < 3; ++a) { out->scene_lo[a] = n_tris ? scene.lo[a] : 0.0f; out->scene_hi[a] = n_tris ? scene.hi[a] : 0.0f; }
-    b.pool.resize(n_tris ? 2 * (size_t)n_tris : 1);
-    b.next_node = 1;
-    b.max_depth = 0;
-    b.threads_free = (int)(threads > 1 ? threads - 1 : 0);
-    if (n_tris) {
-        b.build(0, 0, n_tris, 0);
-    } else {
-        TmpNode & n = b.pool[0];
-        n.box.reset();
-        for (int a = 0; a < 3; ++a) n.box.lo[a] = n.box.hi[a] = 0.0f;
-        n.left = n.right = -1;
-        n.first = 0;
-        n.count = 1;          // the all-zero dummy triangle the uploader always allocates
-        n.depth = 0;
-    }
+namespace {
+
+// Shared back end: TmpNode tree (b.pool, root 0; leaves carry [first, first + count) of b.prims) -> 4-wide quantised nodes.
+void finish_bvh4q(Builder & b, uint32_t n_tris, Bvh4Result * out) {
     out->tri_order.resize(n_tris);
     for (uint32_t i = 0; i < n_tris; ++i) out->tri_order[i] = b.prims[i].id;
 
@@ -421,6 +389,111 @@ void build_bvh4q(const float * verts, uint32_t n_tris, uint32_t leaf_max, uint32
     out->node_count = n_nodes;
     out->max_depth = max_depth;
     out->stack_bound = 3 * max_depth + 2;
+}
+
+}  // namespace
+
+void build_bvh4q(const float * verts, uint32_t n_tris, uint32_t leaf_max, uint32_t threads, Bvh4Result * out, float trav_cost) {
+    *out = Bvh4Result();
+    if (leaf_max < 1) leaf_max = 1;
+    if (leaf_max > 4) leaf_max = 4;
+    Builder b;
+    b.leaf_max = leaf_max;
+    b.trav_cost = trav_cost;
+    b.prims.resize(n_tris);
+    Box scene;
+    scene.reset();
+    for (uint32_t i = 0; i < n_tris; ++i) {
+        Prim & p = b.prims[i];
+        p.box.reset();
+        p.box.grow(verts + 9 * (size_t)i);
+        p.box.grow(verts + 9 * (size_t)i + 3);
+        p.box.grow(verts + 9 * (size_t)i + 6);
+        for (int a = 0; a < 3; ++a) p.c[a] = 0.5f * p.box.lo[a] + 0.5f * p.box.hi[a];
+        p.id = i;
+        scene.grow(p.box);
+    }
+    for (int a = 0; a < 3; ++a) { out->scene_lo[a] = n_tris ? scene.lo[a] : 0.0f; out->scene_hi[a] = n_tris ? scene.hi[a] : 0.0f; }
+    b.pool.resize(n_tris ? 2 * (size_t)n_tris : 1);
+    b.next_node = 1;
+    b.max_depth = 0;
+    b.threads_free = (int)(threads > 1 ? threads - 1 : 0);
+    if (n_tris) {
+        b.build(0, 0, n_tris, 0);
+    } else {
+        TmpNode & n = b.pool[0];
+        n.box.reset();
+        for (int a = 0; a < 3; ++a) n.box.lo[a] = n.box.hi[a] = 0.0f;
+        n.left = n.right = -1;
+        n.first = 0;
+        n.count = 1;          // the all-zero dummy triangle the uploader always allocates
+        n.depth = 0;
+    }
+    finish_bvh4q(b, n_tris, out);
+}
+
+// Back end for a tree built elsewhere (the GPU LBVH builder, bvh_lbvh.hip): a binary radix tree over the triangles in
+// sorted order.  Internal node i has children left[i] / right[i] (>= 0: internal node, < 0: ~sorted position of a
+// single triangle), covers sorted positions [first[i], last[i]] and has box node_box[6 i .. 6 i + 5] (lo xyz, hi xyz);
+// leaf_box holds the triangles' own boxes in sorted order.  Subtrees of at most leaf_max triangles become leaves.
+void build_bvh4q_from_radix_tree(uint32_t n_tris, uint32_t leaf_max, const int32_t * left, const int32_t * right,
+                                 const uint32_t * first, const uint32_t * last, const float * node_box, const float * leaf_box,
+                                 const uint32_t * sorted_ids, Bvh4Result * out) {
+    *out = Bvh4Result();
+    if (leaf_max < 1) leaf_max = 1;
+    if (leaf_max > 4) leaf_max = 4;
+    Builder b;
+    b.leaf_max = leaf_max;
+    b.prims.resize(n_tris);
+    Box scene;
+    scene.reset();
+    for (uint32_t i = 0; i < n_tris; ++i) {
+        Prim & p = b.prims[i];
+        for (int a = 0; a < 3; ++a) { p.box.lo[a] = leaf_box[6 * (size_t)i + a]; p.box.hi[a] = leaf_box[6 * (size_t)i + 3 + a]; p.c[a] = 0.0f; }
+        p.id = sorted_ids[i];
+        scene.grow(p.box);
+    }
+    for (int a = 0; a < 3; ++a) { out->scene_lo[a] = n_tris ? scene.lo[a] : 0.0f; out->scene_hi[a] = n_tris ? scene.hi[a] : 0.0f; }
+    b.pool.resize(n_tris ? 2 * (size_t)n_tris : 1);
+    b.next_node = 1;
+    b.max_depth = 0;
+    b.threads_free = 0;
+    auto make_leaf = [&](TmpNode & n, const Box & box, uint32_t f, uint32_t c, uint32_t depth) {
+        n.box = box; n.left = n.right = -1; n.first = f; n.count = c; n.depth = depth;
+    };
+    if (n_tris == 0) {
+        Box zero = { { 0, 0, 0 }, { 0, 0, 0 } };
+        make_leaf(b.pool[0], zero, 0, 1, 0);            // the all-zero dummy triangle the uploader always allocates
+    } else if (n_tris <= leaf_max || n_tris == 1) {
+        make_leaf(b.pool[0], scene, 0, n_tris, 0);
+    } else {
+        struct Todo { uint32_t tmp; int32_t src; uint32_t depth; };
+        std::vector<Todo> todo;
+        todo.push_back(Todo{ 0u, 0, 0u });
+        while (!todo.empty()) {
+            const Todo t = todo.back();
+            todo.pop_back();
+            TmpNode & n = b.pool[t.tmp];
+            if (t.src < 0) {                                      // a single triangle
+                const uint32_t pos = (uint32_t)~t.src;
+                make_leaf(n, b.prims[pos].box, pos, 1, t.depth);
+                continue;
+            }
+            Box box;
+            for (int a = 0; a < 3; ++a) { box.lo[a] = node_box[6 * (size_t)t.src + a]; box.hi[a] = node_box[6 * (size_t)t.src + 3 + a]; }
+            const uint32_t cnt = last[t.src] - first[t.src] + 1u;
+            if (cnt <= leaf_max) { make_leaf(n, box, first[t.src], cnt, t.depth); continue; }
+            n.box = box;
+            n.depth = t.depth;
+            n.first = n.count = 0;
+            const uint32_t l = b.alloc(), r = b.alloc();
+            n.left = (int32_t)l;
+            n.right = (int32_t)r;
+            todo.push_back(Todo{ l, left[t.src], t.depth + 1 });
+            todo.push_back(Todo{ r, right[t.src], t.depth + 1 });
+        }
+    }
+    finish_bvh4q(b, n_tris, out);
 }
 
 }  // namespace prt

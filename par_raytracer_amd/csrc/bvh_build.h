@@ -35,4 +35,9 @@ struct Bvh4Result {
 };
 void build_bvh4q(const float * verts, uint32_t n_tris, uint32_t leaf_max, uint32_t threads, Bvh4Result * out, float trav_cost = 1.0f);
 
+// The same 4-wide quantised result from a binary radix tree built elsewhere (GPU LBVH, bvh_lbvh.h); see bvh_build.cpp.
+void build_bvh4q_from_radix_tree(uint32_t n_tris, uint32_t leaf_max, const int32_t * left, const int32_t * right,
+                                 const uint32_t * first, const uint32_t * last, const float * node_box, const float * leaf_box,
+                                 const uint32_t * sorted_ids, Bvh4Result * out);
+
 }  // namespace prt

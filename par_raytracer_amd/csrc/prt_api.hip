@@ -22,6 +22,7 @@
 #include "kernels_wave.h"
 #include "kernels_persist.h"
 #include "kernels_pool.h"
+#include "bvh_lbvh.h"
 #include "kernels_debug.h"
 
 using namespace prt;
@@ -555,6 +556,24 @@ int launch_pool(prt_ctx * ctx, bool count, const DevCamera & cam, DevParams P, u
     return 0;
 }
 
+// GPU radix-tree build + host collapse / quantise.  verts: 9 floats per triangle.
+int build_bvh_lbvh(prt_ctx * ctx, const float * verts, uint32_t n_tris, uint32_t leaf_max, Bvh4Result * bvh) {
+    float lo[3] = { 0, 0, 0 }, hi[3] = { 0, 0, 0 };
+    for (uint32_t i = 0; i < n_tris * 3u; ++i)
+        for (int a = 0; a < 3; ++a) {
+            const float v = verts[(size_t)i * 3 + a];
+            if (i == 0 || v < lo[a]) lo[a] = v;
+            if (i == 0 || v > hi[a]) hi[a] = v;
+        }
+    LbvhTree tree;
+    double device_ms = 0.0;
+    HIP_TRY(ctx, build_lbvh_tree(verts, n_tris, lo, hi, ctx->stream, &tree, &device_ms));
+    build_bvh4q_from_radix_tree(n_tris, leaf_max, tree.left.data(), tree.right.data(), tree.first.data(), tree.last.data(),
+                                tree.node_box.data(), tree.leaf_box.data(), tree.sorted_ids.data(), bvh);
+    if (getenv("PRT_DEBUG_UTIL")) fprintf(stderr, "[prt] LBVH: %u triangles, radix tree on the device in %.2f ms\n", n_tris, device_ms);
+    return 0;
+}
+
 // Renders the pixel set into d_out (device, float4 per pixel, packed in local pixel order).  Synchronous.
 int render_pixels(prt_ctx * ctx, const prt_camera * cam_in, const prt_params * params, uint32_t width, uint32_t height,
                   const PixelSet & px, float4 * d_out, prt_counters * counters) {
@@ -979,7 +998,14 @@ int prt_upload_scene(prt_ctx * ctx, const prt_scene_desc * s) {
     if (const char * e = getenv("PRT_LEAF_MAX")) leaf_max = (unsigned int)std::max(1, std::min(4, atoi(e)));   // experiment knob
     float trav_cost = 1.0f;
     if (const char * e = getenv("PRT_SAH_TRAV_COST")) trav_cost = (float)atof(e);                             // experiment knob
-    build_bvh4q(verts.data(), n_tris, leaf_max, std::min(hw, 16u), &bvh, trav_cost);
+    const char * builder = getenv("PRT_BVH_BUILDER");
+    if (builder && !strcmp(builder, "lbvh")) {
+        // fast build for scenes that change every frame: radix tree on the GPU (bvh_lbvh.h), same 4-wide quantised back end
+        int rc = build_bvh_lbvh(ctx, verts.data(), n_tris, leaf_max, &bvh);
+        if (rc) return rc;
+    } else {
+        build_bvh4q(verts.data(), n_tris, leaf_max, std::min(hw, 16u), &bvh, trav_cost);
+    }
     double build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
 
     // ---- reference visit rank: leaves of the sphere tree in the order TraceRay pops them (c1 first)
@@ -1309,14 +1335,7 @@ int prt_debug_device_kat(prt_ctx * ctx, int kind, const void * in, size_t in_byt
 // inside the de-quantised box of every ancestor, that every triangle is referenced by exactly one leaf and
 // that links are in range.  out[0] = violations, out[1] = nodes, out[2] = depth, out[3] = stack bound,
 // out[4] = leaves, out[5] = triangles referenced.
-int prt_debug_check_bvh(const prt_scene_desc * s, uint64_t * out) {
-    if (!s || !out || s->index_count % 3) return -1;
-    const uint32_t n_tris = s->index_count / 3;
-    std::vector<float> verts((size_t)n_tris * 9);
-    for (uint32_t t = 0; t < n_tris; ++t)
-        for (int c = 0; c < 3; ++c) memcpy(&verts[(size_t)t * 9 + 3 * c], s->positions + 3 * (size_t)s->idx_positions[3 * t + c], 12);
-    Bvh4Result bvh;
-    build_bvh4q(verts.data(), n_tris, BVH_LEAF_MAX, 4, &bvh);
+static int check_bvh4q(const std::vector<float> & verts, uint32_t n_tris, const Bvh4Result & bvh, uint64_t * out) {
     uint64_t violations = 0, leaves = 0, refs = 0;
     std::vector<uint8_t> seen(std::max(1u, n_tris), 0);
     struct Item { uint32_t node; float lo[3], hi[3]; };
@@ -1380,6 +1399,31 @@ int prt_debug_check_bvh(const prt_scene_desc * s, uint64_t * out) {
     for (uint32_t t = 0; t < n_tris; ++t) if (!seen[t]) violations++;
     out[0] = violations; out[1] = bvh.node_count; out[2] = bvh.max_depth; out[3] = bvh.stack_bound; out[4] = leaves; out[5] = refs;
     return 0;
+}
+
+int prt_debug_check_bvh(const prt_scene_desc * s, uint64_t * out) {
+    if (!s || !out || s->index_count % 3) return -1;
+    const uint32_t n_tris = s->index_count / 3;
+    std::vector<float> verts((size_t)n_tris * 9);
+    for (uint32_t t = 0; t < n_tris; ++t)
+        for (int c = 0; c < 3; ++c) memcpy(&verts[(size_t)t * 9 + 3 * c], s->positions + 3 * (size_t)s->idx_positions[3 * t + c], 12);
+    Bvh4Result bvh;
+    build_bvh4q(verts.data(), n_tris, BVH_LEAF_MAX, 4, &bvh);
+    return check_bvh4q(verts, n_tris, bvh, out);
+}
+
+// The same check on the tree of the GPU LBVH builder (needs a context: the radix tree is built on its device).
+int prt_debug_check_bvh_lbvh(prt_ctx * ctx, const prt_scene_desc * s, uint64_t * out) {
+    if (!ctx || !s || !out || s->index_count % 3) return -1;
+    const uint32_t n_tris = s->index_count / 3;
+    std::vector<float> verts((size_t)n_tris * 9);
+    for (uint32_t t = 0; t < n_tris; ++t)
+        for (int c = 0; c < 3; ++c) memcpy(&verts[(size_t)t * 9 + 3 * c], s->positions + 3 * (size_t)s->idx_positions[3 * t + c], 12);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    Bvh4Result bvh;
+    int rc = build_bvh_lbvh(ctx, verts.data(), n_tris, BVH_LEAF_MAX, &bvh);
+    if (rc) return rc;
+    return check_bvh4q(verts, n_tris, bvh, out);
 }
 
 }  // extern "C"

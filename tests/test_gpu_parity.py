@@ -223,6 +223,45 @@ def test_multi_pass_rendering_is_invisible(gpu_renderer_factory, pipeline, monke
         assert c_got.trace_kernel_launches > c_ref.trace_kernel_launches == 1
 
 
+@pytest.mark.parametrize("name", ["cornell_box", "sphere_plane", "icosphere_l3", "terrain_64", "terrain_192", "textured_gallery"])
+def test_gpu_lbvh_tree_is_conservative_and_complete(name):
+    """Row N3: the radix tree built on the device (Morton sort + Karras hierarchy + bottom-up fit), pushed through the same
+    4-wide / quantise back end: every triangle inside every ancestor's box and in exactly one leaf."""
+    import ctypes as C
+    from conftest import host_scene
+    from par_raytracer_amd import api, capi
+    hs = host_scene(name)
+    r = api.Renderer(0)
+    try:
+        out = (C.c_uint64 * 6)()
+        assert capi.hip_lib().prt_debug_check_bvh_lbvh(r._ctx, hs.desc, out) == 0, capi.hip_lib().prt_last_error(r._ctx)
+        violations, nodes, depth, bound, leaves, refs = list(out)
+        assert violations == 0
+        assert refs == hs.n_tris and leaves >= hs.n_tris / 4
+    finally:
+        r.close()
+
+
+@pytest.mark.parametrize("name", ["terrain64_d3", "gallery_160x120", "many_materials_two_lights", "c2_cornell_128"])
+def test_gpu_lbvh_renders_the_same_image(name, monkeypatch):
+    """Any conservative tree gives the same closest hits: with PRT_BVH_BUILDER=lbvh the fixtures still match the reference."""
+    from conftest import host_scene
+    from par_raytracer_amd import api
+    g = load_golden(name)
+    hs = host_scene(str(g["scene"]), int(g["light_mode"]))
+    monkeypatch.setenv("PRT_BVH_BUILDER", "lbvh")
+    r = api.Renderer(0)
+    try:
+        r.upload(hs)
+        monkeypatch.delenv("PRT_BVH_BUILDER")
+        cam, p = camera_and_params(g)
+        img, ctr = r.render_lattice(cam, p, int(g["width"]), int(g["height"]), int(g["lattice"]))
+    finally:
+        r.close()
+    assert ctr.ray_count == int(g["ray_count"])
+    assert np.abs(img[:, :, :3] - g["rgb"]).max() <= TOL
+
+
 def _random_configs():
     rng = np.random.default_rng(20241003)
     scenes_ = ["cornell_box", "sphere_plane", "icosphere_l3", "terrain_64", "many_materials", "textured_gallery"]
