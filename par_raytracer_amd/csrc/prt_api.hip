@@ -365,6 +365,7 @@ int chain_finish_round(prt_ctx * ctx, Chain & c) {
     float ms = 0.0f;
     HIP_TRY(ctx, hipEventElapsedTime(&ms, c.ws->ev_t0, c.ws->ev_t1));
     c.trace_ms += ms;
+    if (getenv("PRT_DEBUG_ROUNDS")) fprintf(stderr, "[prt] round %u: %u closest + %u shadow rays, k_trace %.3f ms\n", c.round, c.n_closest, c.n_shadow, ms);
     const unsigned int n_lights = std::max(1u, ctx->scene.light_count);
     const unsigned int next_closest = c.n_closest ? c.ws->host_counts[0] : 0;
     const unsigned int next_shadow = c.n_closest ? c.ws->host_counts[1] : 0;
