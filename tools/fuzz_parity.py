@@ -1,5 +1,5 @@
 """Random configurations (scene, lights, depth, bounce samples, spp, image size, seed, adaptive bounds, pipeline) against the
-CPU oracle: equal ray counts, RGB within 1e-4.  usage: fuzz_parity.py [n_configs] [rng_seed]"""
+CPU oracle: equal ray counts, RGB within 1e-4.  usage: fuzz_parity.py [n_configs] [rng_seed] [deep]"""
 import sys, os, tempfile, time
 ROOT = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -23,8 +23,10 @@ for i in range(n):
         r = api.Renderer(0); r.upload(hosts[(sc, lm)]); rends[(sc, lm)] = r
     hs, r = hosts[(sc, lm)], rends[(sc, lm)]
     w, h = int(rng.integers(9, 90)), int(rng.integers(7, 70))
-    depth, rs, ss, spp = int(rng.integers(0, 8)), int(rng.integers(0, 4)), int(rng.integers(0, 4)), int(rng.integers(1, 7))
+    deep = len(sys.argv) > 3 and sys.argv[3] == "deep"            # bounce depth up to the ABI's maximum of 16
+    depth, rs, ss, spp = int(rng.integers(0, 17 if deep else 8)), int(rng.integers(0, 4)), int(rng.integers(0, 4)), int(rng.integers(1, 7))
     if rs + ss >= 4 and depth > 5: depth = 5                      # keep the oracle's tree finite in wall-clock terms
+    if depth > 7 and rs + ss > 2: rs, ss = 1, 1
     seed = int(rng.integers(0, 2 ** 63))
     adaptive = rng.integers(0, 4) == 0
     max_spp = spp + int(rng.integers(1, 9)) if adaptive else 0
