@@ -132,9 +132,9 @@ typedef struct prt_params {
     float variance_threshold;
 } prt_params;
 
-/* DEFAULT: POOL (one launch, wave-private ray pools) up to 1 M samples per call, WAVEFRONT (one launch per bounce
- * round, global ray queues) above 64 M; in between the first call of a (scene, pixel set, sampling) configuration
- * renders the frame with both and the context keeps the faster one.  Adaptive sampling always runs on POOL.  All
+/* DEFAULT: POOL (one launch, wave-private ray pools) up to 1 M samples per call; above, the first call of a (scene,
+ * pixel set, sampling) configuration renders the frame (its first 32 M samples if it is larger than 64 M) with POOL and
+ * with WAVEFRONT (one launch per bounce round, global ray queues) and the context keeps the faster one.  Adaptive sampling always runs on POOL.  All
  * pipelines produce the same image (tests/test_gpu_parity.py); prt_counters.pipeline reports which ran. */
 enum { PRT_PIPELINE_DEFAULT = 0, PRT_PIPELINE_MEGAKERNEL = 1, PRT_PIPELINE_WAVEFRONT = 2, PRT_PIPELINE_PERSISTENT = 3,
        PRT_PIPELINE_POOL = 4, PRT_PIPELINE_MASK = 0xFF };

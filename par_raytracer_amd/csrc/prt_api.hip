@@ -645,10 +645,10 @@ int render_pixels(prt_ctx * ctx, const prt_camera * cam_in, const prt_params * p
         // frame of a scene whose rays are short (C3: 4.75 vs 5.85 ms).  Sample count alone cannot tell those apart, so in
         // the range where either can win the first call of a configuration renders the frame with both (twice each: the
         // first run of a pipeline allocates its workspace) and keeps the faster; the images are the same.  Outside
-        // that range - and always when PRT_POOL_MAX_SAMPLES is set - the size decides.
+        // that range - and always when PRT_POOL_MAX_SAMPLES is set - the size decides.  (Below 1 M samples: pool.)
         const unsigned long long ns = (unsigned long long)px.n_pixels * params->spp;
         const char * forced = getenv("PRT_POOL_MAX_SAMPLES");
-        if (forced || ns <= (1ull << 20) || ns > (64ull << 20)) {
+        if (forced || ns <= (1ull << 20)) {
             const unsigned long long pool_max = forced ? strtoull(forced, nullptr, 10) : 5000000ull;
             pipeline = ns <= pool_max ? PRT_PIPELINE_POOL : PRT_PIPELINE_WAVEFRONT;
         } else {
@@ -661,13 +661,18 @@ int render_pixels(prt_ctx * ctx, const prt_camera * cam_in, const prt_params * p
             for (const prt_ctx::TuneEntry & t : ctx->tuned)
                 if (!memcmp(t.key, e.key, sizeof(e.key))) pipeline = t.pipeline;
             if (pipeline == PRT_PIPELINE_DEFAULT) {
+                // calls that will run in several passes (more than 64 M samples) try the two pipelines on their first
+                // 32 M samples only (C5, 4K x 64 spp at depth 8: pool 1005 ms, wavefront 1181 ms per frame)
+                PixelSet trial = px;
+                const bool whole = ns <= (64ull << 20);
+                if (!whole) trial.n_pixels = (uint32_t)std::max<unsigned long long>(64, ((32ull << 20) / params->spp) / 64 * 64);
                 const unsigned int cand[2] = { PRT_PIPELINE_POOL, PRT_PIPELINE_WAVEFRONT };
                 double ms[2] = { 0.0, 0.0 };
                 prt_counters c;
                 for (int run = 0; run < 4; ++run) {                        // pool, wavefront (cold), pool, wavefront (timed)
                     prt_params pp = *params;
                     pp.pipeline = (params->pipeline & ~(uint32_t)PRT_PIPELINE_MASK) | cand[run & 1];
-                    int rc = render_pixels(ctx, cam_in, &pp, width, height, px, d_out, &c);
+                    int rc = render_pixels(ctx, cam_in, &pp, width, height, trial, d_out, &c);
                     if (rc) return rc;
                     ms[run & 1] = c.render_ms;
                 }
@@ -675,8 +680,11 @@ int render_pixels(prt_ctx * ctx, const prt_camera * cam_in, const prt_params * p
                 if (ctx->tuned.size() >= 64) ctx->tuned.erase(ctx->tuned.begin());
                 ctx->tuned.push_back(e);
                 if (getenv("PRT_DEBUG_UTIL")) fprintf(stderr, "[prt] default pipeline try-out: pool %.3f ms, wavefront %.3f ms\n", ms[0], ms[1]);
-                if (counters) *counters = c;                               // the frame in d_out is the last (wavefront) run
-                return 0;
+                if (whole) {
+                    if (counters) *counters = c;                           // the frame in d_out is the last (wavefront) run
+                    return 0;
+                }
+                pipeline = e.pipeline;
             }
         }
     }
