@@ -268,10 +268,10 @@ def main():
     achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.workload)
-    if os.path.exists(tpath) and world == 1 and not fused:
+    if os.path.exists(tpath) and world == 1 and used in (2, 4):
         try:
             with open(tpath) as f:
-                traffic = json.load(f).get("hbm_bytes_per_frame_k_trace")
+                traffic = json.load(f).get("hbm_bytes_per_frame_" + kernel_name)
         except Exception:
             traffic = None
     launches = max(1, int(cc.trace_kernel_launches))

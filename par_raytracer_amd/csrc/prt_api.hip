@@ -676,7 +676,8 @@ int render_pixels(prt_ctx * ctx, const prt_camera * cam_in, const prt_params * p
                     if (rc) return rc;
                     ms[run & 1] = c.render_ms;
                 }
-                e.pipeline = ms[0] <= ms[1] ? PRT_PIPELINE_POOL : PRT_PIPELINE_WAVEFRONT;
+                // run-to-run noise is 2-3 %: the pool pipeline has to win by more than that to displace the other
+                e.pipeline = ms[0] <= 0.97 * ms[1] ? PRT_PIPELINE_POOL : PRT_PIPELINE_WAVEFRONT;
                 if (ctx->tuned.size() >= 64) ctx->tuned.erase(ctx->tuned.begin());
                 ctx->tuned.push_back(e);
                 if (getenv("PRT_DEBUG_UTIL")) fprintf(stderr, "[prt] default pipeline try-out: pool %.3f ms, wavefront %.3f ms\n", ms[0], ms[1]);

@@ -36,5 +36,8 @@ for k in sorted(fetch):
 kt = out["kernels"].get("k_trace<256, false>")
 if kt:
     out["hbm_bytes_per_frame_k_trace"] = kt["hbm_bytes_per_frame_corrected"]
+for k, v in out["kernels"].items():
+    if k.startswith("k_pool<") and ", false, false, false>" in k and "true, false, false, false>" not in k.replace("k_pool<256, 5, false, true,", ""):
+        out["hbm_bytes_per_frame_k_pool"] = v["hbm_bytes_per_frame_corrected"]
 json.dump(out, open(out_path, "w"), indent=1)
 print(json.dumps({k: (v["hbm_bytes_per_frame_raw"], v["hbm_bytes_per_frame_corrected"]) for k, v in out["kernels"].items()}, indent=1))
