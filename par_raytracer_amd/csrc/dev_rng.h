@@ -43,7 +43,9 @@ PRT_HD void rng_seed(Rng & r, u64 seed) {     // random.h:9-27
     r.k = 0;
 }
 
-// ring: this sample's 16 u64 slots, element i at ring[i * ring_stride] (NULL when !RING).
+// ring: this sample's 16 u64 slots, element i at ring[i * ring_stride].  NULL when !RING - and also (as a compile-time
+// constant, k_pool<RINGMEM = false>) when the host knows that no sample of the render can make more than 15 draws: the
+// ring is then never read, and leaving out its writes saves 8 scattered bytes per draw.
 template <bool RING>
 PRT_HD u64 rng_next(Rng & r, u64 * ring, size_t ring_stride) {   // random.h:29-42
     u64 s0 = r.prev;
@@ -60,7 +62,7 @@ PRT_HD u64 rng_next(Rng & r, u64 * ring, size_t ring_stride) {   // random.h:29-
     s1 ^= s1 >> 11;
     s0 &= s0 >> 30;                                              // AND (sic)
     u64 out = s0 ^ s1;
-    if (RING) ring[(size_t)((r.k + 1) & 15) * ring_stride] = out;
+    if (RING && ring) ring[(size_t)((r.k + 1) & 15) * ring_stride] = out;
     r.prev = out;
     r.k++;
     return out * 1181783497276652981ULL;

@@ -131,7 +131,7 @@ __global__ void k_pool_store_args(PoolArgs a, PoolArgs * dst) {
 }
 
 // grid = resident blocks; dynamic LDS = max(stack_entries, WFRAME_LDS_DWORDS) * BLOCK * 4 (traversal stack columns).
-template <int BLOCK, int WAVES, bool LDSTAB, bool RING, bool COUNT, bool TEX, bool ADAPT>
+template <int BLOCK, int WAVES, bool LDSTAB, bool RING, bool COUNT, bool TEX, bool ADAPT, bool RINGMEM>
 __global__ __launch_bounds__(BLOCK, WAVES) void k_pool(const PoolArgs * args, DevCounters * ctr) {
     extern __shared__ int s_stack[];
     constexpr int LDS_MATS = 32, LDS_LIGHTS = 4;
@@ -210,7 +210,7 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_pool(const PoolArgs * args, De
                     const unsigned int gsid = B.sample_base + sid;
                     SampleState S;
                     Frame fr;
-                    u64 * ring = RING ? B.ring + sid : nullptr;
+                    u64 * ring = RING && RINGMEM ? B.ring + sid : nullptr;
                     if (ADAPT) {
                         // the unit is the pixel: one RNG stream, key of sample 0 (include/prt.h prt_params::max_spp)
                         sample_begin<RING>(cam, P, pixel_of_local(P, gsid), 0u, S, fr, ring, B.n_samples);
@@ -443,7 +443,7 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_pool(const PoolArgs * args, De
                 }
                 unsigned int shaded = 0;
                 // the frame under construction lives in this lane's (idle) traversal stack column
-                shade_entry_lds<RING, TEX, BLOCK>(sc, P, B, tb, live, s, level, pending, ray_o, ray_d, T, hit, emit, shaded, stack.col);
+                shade_entry_lds<RING, TEX, BLOCK, RINGMEM>(sc, P, B, tb, live, s, level, pending, ray_o, ray_d, T, hit, emit, shaded, stack.col);
                 shaded_w += (unsigned int)__popcll(__ballot(shaded != 0));
             }
             n_c = emit.m_c;

@@ -422,7 +422,7 @@ struct ShadeTables {
 // lane of the calling group must call it (the emitter aggregates appends).  emit.shadow(...) is called once per
 // light by every lane, emit.closest(...) once at the end (its last argument tells the emitter that this lane's
 // sample has no ray left - the adaptive mode of k_pool starts the pixel's next sample from there).
-template <bool RING, bool TEX, class Emit, class FrameT>
+template <bool RING, bool TEX, bool RINGMEM, class Emit, class FrameT>
 PRT_D void shade_entry_on(const DevScene & sc, const DevParams & P, const WaveBuffers & B, const ShadeTables & tb, bool live,
                           unsigned int s, int level, unsigned int pending, f3 ray_o, f3 ray_d, f3 T, const HitRec & hit, Emit & emit,
                           unsigned int & shaded, FrameT & f) {
@@ -434,7 +434,9 @@ PRT_D void shade_entry_on(const DevScene & sc, const DevParams & P, const WaveBu
         rng.chain = rs.x; rng.prev = rs.y;
         if (RING) { const ulonglong2 ra = B.rng_aux[s]; rng.seed0 = ra.x; rng.k = (u32)ra.y; }
     }
-    u64 * ring = RING ? B.ring + s : nullptr;
+    // RINGMEM = false: the general-RNG code without its draw ring in memory, for renders whose samples provably make at
+    // most 15 draws (dev_rng.h) - a compile-time NULL, so the ring code folds away
+    u64 * ring = RING && RINGMEM ? B.ring + s : nullptr;
     const size_t ring_stride = B.n_samples;
 
     f3 add = mk3(0.0f, 0.0f, 0.0f);          // radiance this invocation adds to the sample
@@ -668,16 +670,16 @@ PRT_D void shade_entry(const DevScene & sc, const DevParams & P, const WaveBuffe
                        unsigned int s, int level, unsigned int pending, f3 ray_o, f3 ray_d, f3 T, const HitRec & hit, Emit & emit,
                        unsigned int & shaded) {
     WFrame f;
-    shade_entry_on<RING, TEX>(sc, P, B, tb, live, s, level, pending, ray_o, ray_d, T, hit, emit, shaded, f);
+    shade_entry_on<RING, TEX, true>(sc, P, B, tb, live, s, level, pending, ray_o, ray_d, T, hit, emit, shaded, f);
 }
 
 // ... or in the lane's LDS column `col` (stride STRIDE dwords between fields; WFRAME_LDS_DWORDS fields).
-template <bool RING, bool TEX, int STRIDE, class Emit>
+template <bool RING, bool TEX, int STRIDE, bool RINGMEM, class Emit>
 PRT_D void shade_entry_lds(const DevScene & sc, const DevParams & P, const WaveBuffers & B, const ShadeTables & tb, bool live,
                            unsigned int s, int level, unsigned int pending, f3 ray_o, f3 ray_d, f3 T, const HitRec & hit, Emit & emit,
                            unsigned int & shaded, int * col) {
     WFrameLds<STRIDE> f(col);
-    shade_entry_on<RING, TEX>(sc, P, B, tb, live, s, level, pending, ray_o, ray_d, T, hit, emit, shaded, f);
+    shade_entry_on<RING, TEX, RINGMEM>(sc, P, B, tb, live, s, level, pending, ray_o, ray_d, T, hit, emit, shaded, f);
 }
 
 // Emitter of k_shade: workgroup-aggregated appends to the global next-round queues.

@@ -468,13 +468,15 @@ int render_wavefront(prt_ctx * ctx, const DevCamera & cam, const DevParams & P, 
 
 // The wave-pool pipeline (kernels_pool.h): one launch; per-sample arrays as in the wavefront pipeline (chain 0's
 // workspace, without the global queues), plus cap (+ cap * lights shadow) ray slots per resident wave.
-template <int BLOCK, int WAVES, bool LDSTAB, bool RING, bool TEX, bool ADAPT>
+// RINGMEM = false: no sample can make more than 15 RNG draws (and the scene is opaque, untextured, fixed spp): the
+// general-RNG variant runs without its draw ring in memory (dev_rng.h).
+template <int BLOCK, int WAVES, bool LDSTAB, bool RING, bool TEX, bool ADAPT, bool RINGMEM = true>
 int launch_pool(prt_ctx * ctx, bool count, const DevCamera & cam, DevParams P, unsigned int n_samples, unsigned int stack_entries) {
     // the stack columns double as the shading phase's frame storage (WFRAME_LDS_DWORDS per lane)
     const size_t lds = (size_t)std::max(stack_entries, (unsigned int)WFRAME_LDS_DWORDS) * BLOCK * sizeof(int);
     int per_cu = 0;
-    hipError_t oe = count ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_pool<BLOCK, WAVES, LDSTAB, RING, true, TEX, ADAPT>, BLOCK, lds)
-                          : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_pool<BLOCK, WAVES, LDSTAB, RING, false, TEX, ADAPT>, BLOCK, lds);
+    hipError_t oe = count ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_pool<BLOCK, WAVES, LDSTAB, RING, true, TEX, ADAPT, RINGMEM>, BLOCK, lds)
+                          : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_pool<BLOCK, WAVES, LDSTAB, RING, false, TEX, ADAPT, RINGMEM>, BLOCK, lds);
     if (oe != hipSuccess || per_cu < 1) per_cu = 1;
     per_cu = std::min(per_cu, 8);
     if (const char * e = getenv("PRT_POOL_BLOCKS_PER_CU")) per_cu = std::max(1, std::min(per_cu, atoi(e)));
@@ -513,7 +515,7 @@ int launch_pool(prt_ctx * ctx, bool count, const DevCamera & cam, DevParams P, u
     B.accum = ctx->sample_rgb.p;
     B.rng = w.rng.p;
     B.rng_aux = RING ? w.rng.p + N : nullptr;
-    B.ring = RING ? ctx->ring_ws.p : nullptr;
+    B.ring = RING && RINGMEM ? ctx->ring_ws.p : nullptr;
     B.frames = w.f4.p;
     PoolBuffers Q;
     Q.cq = ctx->pool_f4.p;
@@ -551,9 +553,9 @@ int launch_pool(prt_ctx * ctx, bool count, const DevCamera & cam, DevParams P, u
     HIP_TRY(ctx, ctx->pool_args.ensure(1));
     hipLaunchKernelGGL(k_pool_store_args, dim3(1), dim3(64), 0, ctx->stream, A, ctx->pool_args.p);
     if (count)
-        hipLaunchKernelGGL((k_pool<BLOCK, WAVES, LDSTAB, RING, true, TEX, ADAPT>), dim3(grid), dim3(BLOCK), lds, ctx->stream, ctx->pool_args.p, ctx->counters.p);
+        hipLaunchKernelGGL((k_pool<BLOCK, WAVES, LDSTAB, RING, true, TEX, ADAPT, RINGMEM>), dim3(grid), dim3(BLOCK), lds, ctx->stream, ctx->pool_args.p, ctx->counters.p);
     else
-        hipLaunchKernelGGL((k_pool<BLOCK, WAVES, LDSTAB, RING, false, TEX, ADAPT>), dim3(grid), dim3(BLOCK), lds, ctx->stream, ctx->pool_args.p, ctx->counters.p);
+        hipLaunchKernelGGL((k_pool<BLOCK, WAVES, LDSTAB, RING, false, TEX, ADAPT, RINGMEM>), dim3(grid), dim3(BLOCK), lds, ctx->stream, ctx->pool_args.p, ctx->counters.p);
     return 0;
 }
 
@@ -709,7 +711,7 @@ int render_pixels(prt_ctx * ctx, const prt_camera * cam_in, const prt_params * p
     unsigned int pass_pixels = px.n_pixels;
     {
         const unsigned long long lv = std::max(1u, P.bounce_depth), fr4 = ctx->textured ? 7 : ring_eff ? 5 : 4, nl = std::max(1u, ctx->scene.light_count);
-        unsigned long long per_sample = 16 + (ring_eff && pipeline != PRT_PIPELINE_PERSISTENT ? 128 : 0);
+        unsigned long long per_sample = 16 + (ring && pipeline != PRT_PIPELINE_PERSISTENT ? 128 : 0);
         if (pipeline == PRT_PIPELINE_WAVEFRONT) per_sample += (lv * fr4 + 7 + 3 * nl) * 16 + (ring ? 32 : 16) + 4 * (1 + nl);
         if (pipeline == PRT_PIPELINE_POOL) per_sample += lv * fr4 * 16 + 32;
         if (adaptive) per_sample += ((unsigned long long)P.max_spp + 2) * 16;
@@ -729,7 +731,7 @@ int render_pixels(prt_ctx * ctx, const prt_camera * cam_in, const prt_params * p
     if (n_samples64 > 0x7FFFFFFFull) { ctx->error = "prt_render: spp too large for one pixel per pass"; return -1; }
     HIP_TRY(ctx, ctx->sample_rgb.ensure(n_samples64));
     HIP_TRY(ctx, ctx->counters.ensure(1));
-    if (ring_eff && pipeline != PRT_PIPELINE_PERSISTENT) HIP_TRY(ctx, ctx->ring_ws.ensure(n_samples64 * 16));
+    if (ring && pipeline != PRT_PIPELINE_PERSISTENT) HIP_TRY(ctx, ctx->ring_ws.ensure(n_samples64 * 16));
 
     // Traversal stack: LDS column of up to STACK_LDS_CAP entries per lane (occupancy); rays that would need more
     // - 3 pushes per 4-wide level are possible, nothing real comes close - are re-traced on a full-height global
@@ -806,7 +808,8 @@ int render_pixels(prt_ctx * ctx, const prt_camera * cam_in, const prt_params * p
                                    : launch_pool<256, 4, false, true, false, true>(ctx, count_visits, cam, P, n_samples, stack_entries);
             else
                 rc = ctx->textured ? launch_pool<256, 4, false, true, true, false>(ctx, count_visits, cam, P, n_samples, stack_entries)
-                                   : launch_pool<256, 5, false, true, false, false>(ctx, count_visits, cam, P, n_samples, stack_entries);
+                   : ring ? launch_pool<256, 5, false, true, false, false>(ctx, count_visits, cam, P, n_samples, stack_entries)
+                          : launch_pool<256, 5, false, true, false, false, false>(ctx, count_visits, cam, P, n_samples, stack_entries);
             launches += 1;
         } else {
             unsigned long long rays = 0;
