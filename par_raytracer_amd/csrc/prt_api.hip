@@ -559,6 +559,20 @@ int launch_pool(prt_ctx * ctx, bool count, const DevCamera & cam, DevParams P, u
     return 0;
 }
 
+// sample colours -> pixels: the coalesced kernel for power-of-two spp up to 64, the one-lane-per-pixel kernel otherwise
+void launch_resolve(hipStream_t stream, const float4 * samples, float4 * out, unsigned int n_px, unsigned int spp) {
+    const unsigned int grid2 = (unsigned int)(((unsigned long long)n_px * spp + 255ull) / 256ull);
+    switch (spp) {
+        case 2: hipLaunchKernelGGL(k_resolve_pow2<2>, dim3(grid2), dim3(256), 0, stream, samples, out, n_px); break;
+        case 4: hipLaunchKernelGGL(k_resolve_pow2<4>, dim3(grid2), dim3(256), 0, stream, samples, out, n_px); break;
+        case 8: hipLaunchKernelGGL(k_resolve_pow2<8>, dim3(grid2), dim3(256), 0, stream, samples, out, n_px); break;
+        case 16: hipLaunchKernelGGL(k_resolve_pow2<16>, dim3(grid2), dim3(256), 0, stream, samples, out, n_px); break;
+        case 32: hipLaunchKernelGGL(k_resolve_pow2<32>, dim3(grid2), dim3(256), 0, stream, samples, out, n_px); break;
+        case 64: hipLaunchKernelGGL(k_resolve_pow2<64>, dim3(grid2), dim3(256), 0, stream, samples, out, n_px); break;
+        default: hipLaunchKernelGGL(k_resolve, dim3((n_px + 255) / 256), dim3(256), 0, stream, samples, out, n_px, spp);
+    }
+}
+
 // GPU radix-tree build + host collapse / quantise.  verts: 9 floats per triangle.
 int build_bvh_lbvh(prt_ctx * ctx, const float * verts, uint32_t n_tris, uint32_t leaf_max, Bvh4Result * bvh) {
     float lo[3] = { 0, 0, 0 }, hi[3] = { 0, 0, 0 };
@@ -827,7 +841,7 @@ int render_pixels(prt_ctx * ctx, const prt_camera * cam_in, const prt_params * p
             hipLaunchKernelGGL(k_resolve, dim3((n_px + 255) / 256), dim3(256), 0, stream,
                                ctx->adapt_f4.p + ((size_t)P.max_spp + 1u) * n_samples, d_out + p0, n_px, 1u);
         else
-            hipLaunchKernelGGL(k_resolve, dim3((n_px + 255) / 256), dim3(256), 0, stream, ctx->sample_rgb.p, d_out + p0, n_px, P.spp);
+            launch_resolve(stream, ctx->sample_rgb.p, d_out + p0, n_px, P.spp);
         HIP_TRY(ctx, hipGetLastError());
         if (single_launch && (counters || !last_pass)) {
             // the next pass reuses ev[2] / ev[3] (and the workspace is stream ordered anyway): take this pass's time now
