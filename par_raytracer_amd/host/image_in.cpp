@@ -20,6 +20,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <new>
 #include <string>
 #include <vector>
 
@@ -96,6 +97,7 @@ bool DecodePng(const std::vector<u8> & d, Image * out) {
         pos += 12 + (size_t)len;
     }
     if (!have_header || !w || !h) return Fail("PNG without a header");
+    if ((unsigned long long)w * h > (1ull << 28)) return Fail("PNG larger than 2^28 pixels");
     if (interlace) return Fail("interlaced PNG is not supported");
     if (depth != 8 && depth != 16) return Fail("PNG bit depth other than 8 / 16 is not supported");
     u32 file_ch = 0;
@@ -112,6 +114,9 @@ bool DecodePng(const std::vector<u8> & d, Image * out) {
     const size_t bps = depth / 8;                              // bytes per sample
     const size_t bpp = bps * file_ch;                          // bytes per pixel in the filtered stream
     const size_t stride = (size_t)w * bpp;
+    // deflate expands at most ~1032:1: a header that promises more than the data can hold is corrupt (and would
+    // otherwise make us allocate whatever it says)
+    if ((stride + 1) * (size_t)h > idat.size() * 1032 + 1024) return Fail("PNG data too short for the image size");
     std::vector<u8> raw((stride + 1) * (size_t)h);
     uLongf raw_len = (uLongf)raw.size();
     int zr = uncompress(raw.data(), &raw_len, idat.data(), (uLong)idat.size());
@@ -176,8 +181,10 @@ bool DecodeTga(const std::vector<u8> & d, Image * out) {
     if (grey ? bits != 8 : (bits != 24 && bits != 32)) return Fail("unsupported TGA pixel depth");
     const u32 ch = bits / 8;
     size_t pos = 18 + (size_t)id_len;
-    std::vector<u8> px((size_t)w * h * ch);
     const size_t n_px = (size_t)w * h;
+    // a raw image needs n_px * ch bytes of data, a run-length one at least one (1 + ch)-byte packet per 128 pixels
+    if (pos > d.size() || (rle ? (n_px + 127) / 128 * (1 + ch) : n_px * ch) > d.size() - pos) return Fail("TGA pixel data truncated");
+    std::vector<u8> px(n_px * ch);
     if (!rle) {
         if (pos + n_px * ch > d.size()) return Fail("TGA pixel data truncated");
         memcpy(px.data(), &d[pos], n_px * ch);
@@ -269,13 +276,15 @@ Texture * LoadTexture(const char * filename) {
     Bytes file;
     Image img;
     bool ok = file.Read(filename);
-    if (ok) {
+    if (ok) try {
         const std::vector<u8> & d = file.data;
         if (d.size() >= 8 && d[0] == 0x89 && d[1] == 'P') ok = DecodePng(d, &img);
         else if (d.size() >= 2 && d[0] == 'B' && d[1] == 'M') ok = DecodeBmp(d, &img);
         else if (d.size() >= 2 && d[0] == 'P' && (d[1] == '5' || d[1] == '6')) ok = DecodePnm(d, &img);
         else if (d.size() >= 3 && d[0] == 0xFF && d[1] == 0xD8) ok = Fail("JPEG is not supported");
         else ok = DecodeTga(d, &img);                          // TGA has no signature: last
+    } catch (const std::bad_alloc &) {
+        ok = Fail("out of memory while decoding");
     }
     if (!ok) {
         fprintf(stderr, "Failed to load image [%s] :: %s\n", filename, gImageError.c_str());

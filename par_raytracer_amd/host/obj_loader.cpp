@@ -96,13 +96,27 @@ void ReadFaceRecord(const char * p, u32 line, Mesh * mesh, MeshGroup * group) {
             fprintf(stderr, "obj: more than 8 corners on line %u, rest ignored\n", line);
             break;
         }
+        // p/t/n (obj_parser.cpp:130-140).  The reference steps over whatever separates the numbers; here a corner that is
+        // not three '/'-separated integers ends the face (never read past the end of the buffer, always move forward).
         char * end;
         long ip = strtol(p, &end, 10);
-        if (*end != '/') fprintf(stderr, "obj: expected '/' on line %u\n", line);
-        long it = strtol(end + 1, &end, 10);
-        if (*end != '/') fprintf(stderr, "obj: expected '/' on line %u\n", line);
-        long in = strtol(end + 1, &end, 10);
-        if (!isspace((unsigned char)*end)) fprintf(stderr, "obj: expected whitespace after face corner on line %u\n", line);
+        bool ok = end != p && *end == '/';
+        long it = 0, in = 0;
+        if (ok) {
+            const char * q = end + 1;
+            it = strtol(q, &end, 10);
+            ok = end != q && *end == '/';
+        }
+        if (ok) {
+            const char * q = end + 1;
+            in = strtol(q, &end, 10);
+            ok = end != q;
+        }
+        if (!ok) {
+            fprintf(stderr, "obj: malformed face corner on line %u (expected p/t/n), rest of the face ignored\n", line);
+            break;
+        }
+        if (*end && !isspace((unsigned char)*end)) fprintf(stderr, "obj: expected whitespace after face corner on line %u\n", line);
         pos[corners] = ResolveIndex(ip, mesh->positions.size());
         tex[corners] = ResolveIndex(it, mesh->texcoords.size());
         nrm[corners] = ResolveIndex(in, mesh->normals.size());
@@ -264,6 +278,21 @@ Mesh * ParseOBJ(const char * working_dir, const char * filename, Matrix33 transf
         }
     }
     free(bytes);
+    // Indices may name vertices that appear later in the file, so they can only be checked now.  The reference never
+    // checks them (out-of-range indices are wild reads in CalculateTangents, BuildHierarchy and the triangle test);
+    // here such a file does not load.
+    for (size_t g = 0; g < mesh->groups.size(); ++g) {
+        const MeshGroup & mg = mesh->groups[g];
+        for (size_t i = 0; i < mg.idx_positions.size(); ++i) {
+            if (mg.idx_positions[i] >= mesh->positions.size() || mg.idx_texcoords[i] >= mesh->texcoords.size() ||
+                mg.idx_normals[i] >= mesh->normals.size()) {
+                fprintf(stderr, "obj: face index out of range in group %s (%zu positions, %zu texcoords, %zu normals)\n",
+                        mg.name ? mg.name : "?", mesh->positions.size(), mesh->texcoords.size(), mesh->normals.size());
+                delete mesh;
+                return NULL;
+            }
+        }
+    }
     return mesh;
 }
 

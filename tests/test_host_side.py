@@ -173,6 +173,30 @@ def test_unsupported_images_leave_the_slot_empty_like_a_decoder_failure(tmp_path
     assert hs.desc.contents.texture_count == 0 and hs.n_tris == 1
 
 
+def test_malformed_obj_and_image_files_fail_cleanly(tmp_path):
+    """Found by fuzzing the loader under AddressSanitizer (tools/fuzz_obj_loader.py, tools/fuzz_image_decoders.py): face
+    indices past the vertex arrays (a wild read in the reference's CalculateTangents / BuildHierarchy), a face record cut
+    off at the end of the file, an image header that promises 4 Gpixels."""
+    base = "v 0 0 0\nv 1 0 0\nv 0 1 0\nvt 0 0\nvn 0 0 1\ng a\n"
+    (tmp_path / "range.obj").write_text(base + "f 1/1/1 2/1/1 9/1/1\n")
+    with pytest.raises(RuntimeError):
+        api.HostScene(str(tmp_path), "range.obj")
+    (tmp_path / "cut.obj").write_text(base + "f 1/1/1 2/1/1 3/1/1\nf 1/1/1 2/1/1 3/")           # no newline, truncated corner
+    hs = api.HostScene(str(tmp_path), "cut.obj")
+    assert hs.n_tris == 1
+    (tmp_path / "later.obj").write_text("vt 0 0\nvn 0 0 1\ng a\nf 1/1/1 2/1/1 3/1/1\nv 0 0 0\nv 1 0 0\nv 0 1 0\n")   # vertices after the face: fine
+    assert api.HostScene(str(tmp_path), "later.obj").n_tris == 1
+    png = bytearray()
+    scenes.write_texture(str(tmp_path / "ok.png"), np.zeros((4, 4, 3), dtype=np.uint8), "png")
+    png = bytearray((tmp_path / "ok.png").read_bytes())
+    png[16:24] = b"\xff\xff\xff\xf0\xff\xff\xff\xf0"                                            # IHDR width / height
+    (tmp_path / "huge.png").write_bytes(bytes(png))
+    assert _load_texture(capi.host_lib(), str(tmp_path / "huge.png")) is None
+    tga = bytearray(18); tga[2] = 10; tga[12:16] = b"\xff\xff\xff\xff"; tga[16] = 24                  # 65535 x 65535 run-length TGA, no data
+    (tmp_path / "huge.tga").write_bytes(bytes(tga))
+    assert _load_texture(capi.host_lib(), str(tmp_path / "huge.tga")) is None
+
+
 def test_loader_matches_generator_arrays():
     s, d = scene_dir("cornell_box")
     hs = host_scene("cornell_box")

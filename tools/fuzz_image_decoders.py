@@ -1,0 +1,37 @@
+"""Mutated image files / OBJ+MTL files through the host loader; run against an AddressSanitizer build of libprt_host.so
+(PRT_HOST_LIB=<path>, LD_PRELOAD=libasan.so) on the CPU: nothing may crash or read out of bounds."""
+import sys, os, ctypes as C, tempfile
+sys.path.insert(0, "/root/repo")
+import numpy as np
+from par_raytracer_amd import scenes
+lib = C.CDLL(os.environ.get("PRT_HOST_LIB", "/root/repo/par_raytracer_amd/libprt_host.so"))
+lib.prt_host_load_texture.restype = C.POINTER(C.c_uint8)
+lib.prt_host_load_texture.argtypes = [C.c_char_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+lib.prt_host_free_texture.argtypes = [C.POINTER(C.c_uint8)]
+rng = np.random.default_rng(1)
+d = tempfile.mkdtemp()
+img3 = rng.integers(0, 256, size=(19, 23, 3), dtype=np.uint8); img1 = img3[:, :, 0]; img4 = np.concatenate([img3, img3[:, :, :1]], axis=2)
+seeds = []
+for enc, im in (("png", img3), ("png", img1), ("png", img4), ("png16", img3), ("png_palette", img3 // 64 * 64), ("tga", img3), ("tga_rle", img4), ("tga_rle", img1), ("bmp", img3), ("pnm", img1), ("pnm", img3)):
+    p = os.path.join(d, "s%d.img" % len(seeds)); scenes.write_texture(p, im, enc); seeds.append(open(p, "rb").read())
+n_ok = n_fail = 0
+for it in range(6000):
+    b = bytearray(seeds[it % len(seeds)])
+    mode = rng.integers(0, 4)
+    if mode == 0: b = b[:rng.integers(0, len(b))]
+    elif mode == 1:
+        for _ in range(int(rng.integers(1, 6))): b[int(rng.integers(0, len(b)))] = int(rng.integers(0, 256))
+    elif mode == 2:
+        i = int(rng.integers(0, len(b))); b[i:i + 4] = bytes(rng.integers(0, 256, size=4, dtype=np.uint8))
+    else:
+        b += bytes(rng.integers(0, 256, size=int(rng.integers(1, 64)), dtype=np.uint8))
+    p = os.path.join(d, "f.img"); open(p, "wb").write(bytes(b))
+    sx, sy, ch = C.c_uint32(), C.c_uint32(), C.c_uint32()
+    ptr = lib.prt_host_load_texture(p.encode(), C.byref(sx), C.byref(sy), C.byref(ch))
+    if ptr:
+        n_ok += 1
+        a = np.ctypeslib.as_array(ptr, shape=(sx.value * sy.value * ch.value,)).sum()     # touch every byte
+        lib.prt_host_free_texture(ptr)
+    else:
+        n_fail += 1
+print("decoded", n_ok, "rejected", n_fail)
