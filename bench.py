@@ -160,6 +160,7 @@ def main():
     NB = F + 2 if world > 1 else F
     shards = [torch.zeros((max_rows, width, 4), dtype=torch.float32, device=dev) for _ in range(NB)]
     shard = shards[0]
+    torch.cuda.synchronize()               # the zero fills ran on torch's stream; the renderer writes from its own streams
     gathered = [None] * NB                 # per buffer: event recorded after the RCCL gather that read it
     gather_list = None
     row_index = None
