@@ -174,7 +174,9 @@ int prt_render(prt_ctx * ctx, const prt_camera * cam, const prt_params * params,
 
 /* Same, but d_rgba_out is a DEVICE pointer on the context's device (hipMalloc'ed or a torch tensor's
  * data_ptr): used by the multi-GPU path, which gathers the shards with RCCL afterwards.  The call
- * returns after the context's stream has drained, so the buffer may be consumed on any stream. */
+ * returns after the context's stream has drained, so the buffer may be consumed on any stream.  The library's
+ * streams are NOT ordered against the caller's: work of the caller that still touches the buffer (a fill queued on
+ * another stream, a collective reading the previous frame) must have finished - or be waited for - before the call. */
 int prt_render_device(prt_ctx * ctx, const prt_camera * cam, const prt_params * params,
                       uint32_t width, uint32_t height, uint32_t start_idx, uint32_t end_idx,
                       void * d_rgba_out, prt_counters * counters);
