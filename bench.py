@@ -221,8 +221,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # ---- set-up of every context (workspace allocation; the library's first-call try-out of its two production pipelines
-    # for this configuration, include/prt.h PRT_PIPELINE_DEFAULT) - like the scene upload, not a step
+    # ---- set-up of every context (workspace allocation on the first call) - like the scene upload, not a step
     for slot in range(F):
         render_frame(slot)
     # ---- W warmup steps, then EXACTLY K timed steps

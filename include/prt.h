@@ -132,15 +132,18 @@ typedef struct prt_params {
     float variance_threshold;
 } prt_params;
 
-/* DEFAULT: POOL (one launch, wave-private ray pools) up to 1 M samples per call; above, the first call of a (scene,
- * pixel set, sampling) configuration renders the frame (its first 32 M samples if it is larger than 64 M) with POOL and
- * with WAVEFRONT (one launch per bounce round, global ray queues) and the context keeps the faster one.  Adaptive sampling always runs on POOL.  All
- * pipelines produce the same image (tests/test_gpu_parity.py); prt_counters.pipeline reports which ran. */
+/* DEFAULT = POOL: one launch, wave-private ray pools; the faster pipeline on everything measured except a full 1080p frame
+ * of the 1M-triangle scene, where WAVEFRONT (one launch per bounce round, global ray queues) is level or 2 % ahead.
+ * With PRT_FLAG_TRYOUT the first DEFAULT call of a (scene, pixel set, sampling) configuration above 1 M samples renders
+ * the frame (its first 32 M samples if it is larger than 64 M) with both, twice each, and the context keeps WAVEFRONT if
+ * POOL is not at least 3 % faster - worth it for many frames of one configuration, not for a single one.  Adaptive
+ * sampling always runs on POOL.  All pipelines produce the same image (tests/test_gpu_parity.py); prt_counters.pipeline
+ * reports which ran. */
 enum { PRT_PIPELINE_DEFAULT = 0, PRT_PIPELINE_MEGAKERNEL = 1, PRT_PIPELINE_WAVEFRONT = 2, PRT_PIPELINE_PERSISTENT = 3,
        PRT_PIPELINE_POOL = 4, PRT_PIPELINE_MASK = 0xFF };
 /* OR-ed into prt_params.pipeline: also count BVH node visits and triangle tests (costs a few percent;
  * ray_count and shaded_hits are always counted). */
-enum { PRT_FLAG_COUNT_VISITS = 0x100 };
+enum { PRT_FLAG_COUNT_VISITS = 0x100, PRT_FLAG_TRYOUT = 0x200 };
 
 /* DebugCounters (globals.h:3-7) re-cast for a per-triangle BVH.  ray_count has the reference's
  * meaning (one per TraceRay call, raytracer.cpp:161) and must equal the CPU value exactly. */

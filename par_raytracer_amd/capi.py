@@ -90,6 +90,7 @@ class PrtSceneInfo(C.Structure):
 
 PIPELINE_DEFAULT, PIPELINE_MEGAKERNEL, PIPELINE_WAVEFRONT, PIPELINE_PERSISTENT, PIPELINE_POOL = 0, 1, 2, 3, 4
 FLAG_COUNT_VISITS = 0x100
+FLAG_TRYOUT = 0x200
 
 # Every symbol include/prt.h declares; tests/test_capi_symbols.py checks the library exports them all.
 PRT_SYMBOLS = ["prt_create", "prt_destroy", "prt_last_error", "prt_abi_version", "prt_upload_scene", "prt_render",

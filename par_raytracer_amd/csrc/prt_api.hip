@@ -662,11 +662,13 @@ int render_pixels(prt_ctx * ctx, const prt_camera * cam_in, const prt_params * p
         // the range where either can win the first call of a configuration renders the frame with both (twice each: the
         // first run of a pipeline allocates its workspace) and keeps the faster; the images are the same.  Outside
         // that range - and always when PRT_POOL_MAX_SAMPLES is set - the size decides.  (Below 1 M samples: pool.)
+        // The try-out is opt-in (PRT_FLAG_TRYOUT): without it DEFAULT is the pool pipeline.
         const unsigned long long ns = (unsigned long long)px.n_pixels * params->spp;
         const char * forced = getenv("PRT_POOL_MAX_SAMPLES");
-        if (forced || ns <= (1ull << 20)) {
-            const unsigned long long pool_max = forced ? strtoull(forced, nullptr, 10) : 5000000ull;
-            pipeline = ns <= pool_max ? PRT_PIPELINE_POOL : PRT_PIPELINE_WAVEFRONT;
+        if (forced) {
+            pipeline = ns <= strtoull(forced, nullptr, 10) ? PRT_PIPELINE_POOL : PRT_PIPELINE_WAVEFRONT;
+        } else if (!(params->pipeline & PRT_FLAG_TRYOUT) || ns <= (1ull << 20)) {
+            pipeline = PRT_PIPELINE_POOL;       // no try-out asked for (a one-off render would pay for it five-fold), or too small to matter
         } else {
             prt_ctx::TuneEntry e;
             e.key[0] = ctx->scene_epoch;

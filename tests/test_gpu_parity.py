@@ -304,14 +304,17 @@ def test_random_configurations_against_the_oracle(cfg):
 
 
 def test_default_pipeline_try_out_is_invisible(gpu_renderer_factory):
-    """Between 1 M and 64 M samples the first PRT_PIPELINE_DEFAULT call of a configuration renders the frame with both
-    production pipelines and keeps the faster one: the image is the same whichever wins, later calls stick to it."""
+    """PRT_PIPELINE_DEFAULT is the pool pipeline.  With PRT_FLAG_TRYOUT, between 1 M and 64 M samples the first DEFAULT
+    call of a configuration renders the frame with both production pipelines and keeps the faster one: the image is the
+    same whichever wins, later calls stick to it."""
     g = load_golden("terrain192_d2")
     r = gpu_renderer_factory(str(g["scene"]), 0)
     w, h = 640, 480                                               # x 4 spp = 1.23 M samples
-    from par_raytracer_amd import api
+    from par_raytracer_amd import api, capi
     cam = api.make_camera(float(g["fov"]), w, h, g["camera_position"], g["camera_facing"])
-    p0 = api.default_params(4, 99)
+    plain, c0 = r.render(cam, api.default_params(4, 99), w, h)
+    assert c0.pipeline == PIPELINES["pool"], "without the flag DEFAULT is the pool pipeline"
+    p0 = api.default_params(4, 99, pipeline=capi.FLAG_TRYOUT)
     first, c1 = r.render(cam, p0, w, h)
     second, c2 = r.render(cam, p0, w, h)
     assert c1.pipeline in (PIPELINES["pool"], PIPELINES["wavefront"]) and c2.pipeline in (PIPELINES["pool"], PIPELINES["wavefront"])
@@ -319,8 +322,9 @@ def test_default_pipeline_try_out_is_invisible(gpu_renderer_factory):
     assert c3.pipeline == c2.pipeline, "the choice is kept"
     for name in ("pool", "wavefront"):
         img, c = r.render(cam, api.default_params(4, 99, pipeline=PIPELINES[name]), w, h)
-        assert c.ray_count == c1.ray_count == c2.ray_count
-        assert np.array_equal(img.view(np.uint32), first.view(np.uint32)) and np.array_equal(img.view(np.uint32), second.view(np.uint32))
+        assert c.ray_count == c0.ray_count == c1.ray_count == c2.ray_count
+        for other in (plain, first, second, third):
+            assert np.array_equal(img.view(np.uint32), other.view(np.uint32))
 
 
 @pytest.mark.parametrize("pipeline", sorted(PIPELINES))
