@@ -170,7 +170,9 @@ int prt_abi_version(void);
 int prt_upload_scene(prt_ctx * ctx, const prt_scene_desc * scene);
 
 /* Replaces RenderTask (main.cpp:267-283): pixels [start_idx, end_idx) of a w x h image, 16 B/pixel,
- * row-major, w component = 1.  rgba_out is a HOST pointer of (end_idx-start_idx)*4 floats. */
+ * row-major, w component = 1.  rgba_out is a HOST pointer of (end_idx-start_idx)*4 floats.
+ * An empty request (start_idx == end_idx here, a shard that owns no rows, a pixel list of length 0) is not an error:
+ * nothing is rendered, the counters come back zero and the output pointer may be NULL. */
 int prt_render(prt_ctx * ctx, const prt_camera * cam, const prt_params * params,
                uint32_t width, uint32_t height, uint32_t start_idx, uint32_t end_idx,
                float * rgba_out, prt_counters * counters);

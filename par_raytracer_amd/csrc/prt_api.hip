@@ -599,6 +599,10 @@ int render_pixels(prt_ctx * ctx, const prt_camera * cam_in, const prt_params * p
     if (params->spp == 0 || params->spp > 65535) { ctx->error = "prt_render: spp must be in 1..65535 (prt_key.h packs the sample in 16 bits)"; return -1; }
     if (params->bounce_depth > 16) { ctx->error = "prt_render: bounce_depth > 16 not supported"; return -1; }
     if ((uint64_t)width * height >= (1ull << 32)) { ctx->error = "prt_render: image has 2^32 pixels or more"; return -1; }
+    if (px.n_pixels == 0) {                 // RenderTask with start_idx == end_idx (main.cpp:273): nothing to do, not an error
+        if (counters) { memset(counters, 0, sizeof(*counters)); counters->pipeline = params->pipeline & PRT_PIPELINE_MASK; }
+        return 0;
+    }
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t stream = ctx->stream;
 
@@ -1254,7 +1258,7 @@ int prt_get_scene_info(const prt_ctx * ctx, prt_scene_info * info) {
 int prt_render_device(prt_ctx * ctx, const prt_camera * cam, const prt_params * params, uint32_t width, uint32_t height,
                       uint32_t start_idx, uint32_t end_idx, void * d_rgba_out, prt_counters * counters) {
     if (!ctx) return -1;
-    if (!d_rgba_out || end_idx < start_idx || (uint64_t)end_idx > (uint64_t)width * height) {
+    if ((!d_rgba_out && end_idx != start_idx) || end_idx < start_idx || (uint64_t)end_idx > (uint64_t)width * height) {
         ctx->error = "prt_render: bad output pointer or pixel range";
         return -1;
     }
@@ -1265,7 +1269,7 @@ int prt_render_device(prt_ctx * ctx, const prt_camera * cam, const prt_params * 
 int prt_render(prt_ctx * ctx, const prt_camera * cam, const prt_params * params, uint32_t width, uint32_t height,
                uint32_t start_idx, uint32_t end_idx, float * rgba_out, prt_counters * counters) {
     if (!ctx) return -1;
-    if (!rgba_out || end_idx < start_idx) { ctx->error = "prt_render: bad output pointer or pixel range"; return -1; }
+    if ((!rgba_out && end_idx != start_idx) || end_idx < start_idx) { ctx->error = "prt_render: bad output pointer or pixel range"; return -1; }
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const size_t n = end_idx - start_idx;
     HIP_TRY(ctx, ctx->frame_out.ensure(n));
@@ -1285,7 +1289,8 @@ uint32_t prt_shard_rows(uint32_t height, uint32_t block_rows, uint32_t rank, uin
 int prt_render_shard_device(prt_ctx * ctx, const prt_camera * cam, const prt_params * params, uint32_t width, uint32_t height,
                             uint32_t block_rows, uint32_t rank, uint32_t nranks, void * d_rgba_out, prt_counters * counters) {
     if (!ctx) return -1;
-    if (!d_rgba_out || !block_rows || !nranks || rank >= nranks) { ctx->error = "prt_render_shard: bad arguments"; return -1; }
+    if (!block_rows || !nranks || rank >= nranks) { ctx->error = "prt_render_shard: bad arguments"; return -1; }
+    if (!d_rgba_out && prt_shard_rows(height, block_rows, rank, nranks)) { ctx->error = "prt_render_shard: null output"; return -1; }
     PixelSet px = { prt_shard_rows(height, block_rows, rank, nranks) * width, 0, block_rows, rank, nranks, nullptr };
     if (nranks == 1) { px.block_rows = 1; }
     return render_pixels(ctx, cam, params, width, height, px, (float4 *)d_rgba_out, counters);
@@ -1294,9 +1299,9 @@ int prt_render_shard_device(prt_ctx * ctx, const prt_camera * cam, const prt_par
 int prt_render_shard(prt_ctx * ctx, const prt_camera * cam, const prt_params * params, uint32_t width, uint32_t height,
                      uint32_t block_rows, uint32_t rank, uint32_t nranks, float * rgba_out, prt_counters * counters) {
     if (!ctx) return -1;
-    if (!rgba_out) { ctx->error = "prt_render_shard: null output"; return -1; }
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
     const size_t n = (size_t)prt_shard_rows(height, block_rows, rank, nranks) * width;
+    if (!rgba_out && n) { ctx->error = "prt_render_shard: null output"; return -1; }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, ctx->frame_out.ensure(n));
     int rc = prt_render_shard_device(ctx, cam, params, width, height, block_rows, rank, nranks, ctx->frame_out.p, counters);
     if (rc) return rc;
@@ -1307,7 +1312,7 @@ int prt_render_shard(prt_ctx * ctx, const prt_camera * cam, const prt_params * p
 int prt_render_pixel_list(prt_ctx * ctx, const prt_camera * cam, const prt_params * params, uint32_t width, uint32_t height,
                           const uint32_t * pixel_ids, uint32_t n_pixels, float * rgba_out, prt_counters * counters) {
     if (!ctx) return -1;
-    if (!pixel_ids || !rgba_out) { ctx->error = "prt_render_pixel_list: null pixel list or output"; return -1; }
+    if ((!pixel_ids || !rgba_out) && n_pixels) { ctx->error = "prt_render_pixel_list: null pixel list or output"; return -1; }
     for (uint32_t i = 0; i < n_pixels; ++i)
         if ((uint64_t)pixel_ids[i] >= (uint64_t)width * height) { ctx->error = "prt_render_pixel_list: pixel id outside the image"; return -1; }
     HIP_TRY(ctx, hipSetDevice(ctx->device));
