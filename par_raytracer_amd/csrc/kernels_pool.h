@@ -186,7 +186,10 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_pool(const PoolArgs * args, De
     float4 * const ct = cd + cap;                                                                     \
     (void)hits; (void)sq_o; (void)sq_c; (void)sq_d; (void)ct
 
+    unsigned long long ph_topup = 0ull, ph_trace = 0ull, ph_shade = 0ull;      // COUNT: wave-cycles per phase
+    const unsigned long long ph_begin = COUNT ? __builtin_readcyclecounter() : 0ull;
     for (;;) {
+        const unsigned long long ph_t0 = COUNT ? __builtin_readcyclecounter() : 0ull;
         // ---- top up: fresh samples into the free closest-hit slots ------------------------------------------
         if (!fetch_done) {
           const PoolArgs A = pool_args(args);
@@ -236,6 +239,7 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_pool(const PoolArgs * args, De
         }
         pool_fence();
         rays += total;                                                     // debug->ray_count++  raytracer.cpp:161
+        const unsigned long long ph_t1 = COUNT ? __builtin_readcyclecounter() : 0ull;
 
         // ---- trace: every ray of the pool ------------------------------------------------------------------
         {
@@ -337,6 +341,7 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_pool(const PoolArgs * args, De
             }
         }
         pool_fence();
+        const unsigned long long ph_t2 = COUNT ? __builtin_readcyclecounter() : 0ull;
 
         // ---- shade: every closest hit of the pool, 64 per pass ----------------------------------------------
         {
@@ -452,6 +457,10 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_pool(const PoolArgs * args, De
             cur = nxt;
         }
         pool_fence();
+        if (COUNT) {
+            const unsigned long long ph_t3 = __builtin_readcyclecounter();
+            ph_topup += ph_t1 - ph_t0; ph_trace += ph_t2 - ph_t1; ph_shade += ph_t3 - ph_t2;
+        }
     }
 
     // ---- counters: one atomic per workgroup and counter ----------------------------------------------------
@@ -473,6 +482,12 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_pool(const PoolArgs * args, De
         atomicAdd(&ctr->wave_refills, (unsigned long long)st.wrefills);
         atomicMax(&ctr->max_sp, (unsigned long long)st.max_sp);
         atomicAdd(&ctr->culled, (unsigned long long)st.culled);
+        if (lane == 0) {
+            atomicAdd(&ctr->phase_cycles[0], ph_topup);
+            atomicAdd(&ctr->phase_cycles[1], ph_trace);
+            atomicAdd(&ctr->phase_cycles[2], ph_shade);
+            atomicAdd(&ctr->phase_cycles[3], __builtin_readcyclecounter() - ph_begin);
+        }
     }
 }
 
