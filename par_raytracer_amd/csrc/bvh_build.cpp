@@ -5,6 +5,7 @@
 #include <atomic>
 #include <cfloat>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <thread>
 
@@ -283,14 +284,76 @@ void finish_bvh4q(Builder & b, uint32_t n_tris, Bvh4Result * out) {
     auto is_leaf = [&](uint32_t t) { return b.pool[t].left < 0; };
     auto leaf_link = [&](uint32_t t) -> int32_t { return ~(int32_t)((b.pool[t].first << 2) | (b.pool[t].count - 1)); };
 
-    // ---- collapse: each wide node adopts up to 4 binary-tree descendants, opening the largest box first
+    // ---- collapse: each wide node adopts up to 4 binary-tree descendants.
+    // Every visit of a wide node costs the same (all four boxes are tested), and under the surface-area heuristic a
+    // node is visited in proportion to the area of its box, so the best collapse of a given binary tree is the one
+    // with the smallest total area of wide nodes (the leaves stay what they are).  That optimum is a small dynamic
+    // programme over the binary tree (Ylitie, Karras, Laine 2017, section 3.1, here for width 4 and fixed leaves):
+    //   F(m, k) = least area needed below binary node m if it may occupy up to k child slots of its parent
+    //   F(m, 1) = area(m) + min over i of F(left, i) + F(right, 4 - i)          (m becomes a wide node; 0 for a leaf)
+    //   F(m, k) = min(F(m, k - 1), min over i of F(left, i) + F(right, k - i))  (m is dissolved into its parent)
+    // Measured on MI355X: 18-20 % fewer wide nodes, but only 1-2 % fewer node visits per frame and 2.5 % MORE triangle
+    // tests on C4 (the rays of a terrain seen from above are far from the uniform distribution the heuristic assumes):
+    // frame time unchanged within noise.  So the default stays the first version - open the child with the largest box
+    // until four are there - and PRT_BVH_COLLAPSE=dp selects this one.
     struct Item { uint32_t tmp; uint32_t slot; uint32_t depth; };
     std::vector<Wide> wide;
     std::vector<Item> work;
+    const char * collapse_env = getenv("PRT_BVH_COLLAPSE");
+    const bool greedy = !(collapse_env && !strcmp(collapse_env, "dp"));
+    const uint32_t n_tmp = b.next_node.load();
+    struct Dp { float f[3]; uint8_t root_split, split[2]; };   // f[k-1] = F(m, k); split: i of the best distribution, 0 = "use k - 1"
+    std::vector<Dp> dp;
+    if (!greedy) {
+        dp.resize(n_tmp);
+        for (uint32_t t = n_tmp; t-- > 0;) {                  // children are allocated after their parent: bottom-up
+            Dp & d = dp[t];
+            if (is_leaf(t)) { d.f[0] = d.f[1] = d.f[2] = 0.0f; d.root_split = 0; d.split[0] = d.split[1] = 0; continue; }
+            const Dp & l = dp[(uint32_t)b.pool[t].left], & r = dp[(uint32_t)b.pool[t].right];
+            float best = FLT_MAX;
+            for (int i = 1; i <= 3; ++i) {
+                const float c = l.f[i - 1] + r.f[3 - i];
+                if (c < best) { best = c; d.root_split = (uint8_t)i; }
+            }
+            d.f[0] = b.pool[t].box.half_area() + best;
+            for (int k = 2; k <= 3; ++k) {
+                float bk = d.f[k - 2];
+                uint8_t sk = 0;
+                for (int i = 1; i < k; ++i) {
+                    const float c = l.f[i - 1] + r.f[k - i - 1];
+                    if (c < bk) { bk = c; sk = (uint8_t)i; }
+                }
+                d.f[k - 1] = bk;
+                d.split[k - 2] = sk;
+            }
+        }
+    }
     auto make_wide = [&](uint32_t root_tmp) -> Wide {
         Wide w;
         w.n = 0;
         if (is_leaf(root_tmp)) { w.tmp[w.n++] = root_tmp; return w; }
+        if (!greedy) {
+            // unfold the stored decisions: (node, slots it may occupy)
+            struct Todo { uint32_t t; int k; };
+            Todo stack[8];
+            int sp = 0;
+            const int i0 = dp[root_tmp].root_split;
+            stack[sp++] = Todo{ (uint32_t)b.pool[root_tmp].right, 4 - i0 };
+            stack[sp++] = Todo{ (uint32_t)b.pool[root_tmp].left, i0 };
+            while (sp > 0) {
+                Todo cur = stack[--sp];
+                while (cur.k > 1 && !is_leaf(cur.t) && dp[cur.t].split[cur.k - 2] == 0) cur.k--;      // "use k - 1 slots"
+                if (cur.k == 1 || is_leaf(cur.t)) { w.tmp[w.n++] = cur.t; continue; }
+                const int i = dp[cur.t].split[cur.k - 2];
+                stack[sp++] = Todo{ (uint32_t)b.pool[cur.t].right, cur.k - i };
+                stack[sp++] = Todo{ (uint32_t)b.pool[cur.t].left, i };
+            }
+            // largest box first: the slot order is the visiting order of equal keys
+            for (uint32_t i = 1; i < w.n; ++i)
+                for (uint32_t j = i; j > 0 && b.pool[w.tmp[j]].box.half_area() > b.pool[w.tmp[j - 1]].box.half_area(); --j)
+                    std::swap(w.tmp[j], w.tmp[j - 1]);
+            return w;
+        }
         w.tmp[w.n++] = (uint32_t)b.pool[root_tmp].left;
         w.tmp[w.n++] = (uint32_t)b.pool[root_tmp].right;
         while (w.n < 4) {

@@ -262,6 +262,28 @@ def test_gpu_lbvh_renders_the_same_image(name, monkeypatch):
     assert np.abs(img[:, :, :3] - g["rgb"]).max() <= TOL
 
 
+@pytest.mark.parametrize("name", ["terrain192_d2", "gallery_160x120", "icosphere_l3_two_lights", "c2_cornell_128"])
+def test_area_optimal_collapse_renders_the_same_image(name, monkeypatch):
+    """PRT_BVH_COLLAPSE=dp (the binary tree collapsed into 4-wide nodes by dynamic programming instead of greedily): another
+    conservative tree over the same triangles, so the fixtures still match the reference, on both production pipelines."""
+    from conftest import host_scene
+    from par_raytracer_amd import api
+    g = load_golden(name)
+    hs = host_scene(str(g["scene"]), int(g["light_mode"]))
+    monkeypatch.setenv("PRT_BVH_COLLAPSE", "dp")
+    r = api.Renderer(0)
+    try:
+        info = r.upload(hs)
+        monkeypatch.delenv("PRT_BVH_COLLAPSE")
+        for pl in (PIPELINES["pool"], PIPELINES["wavefront"]):
+            cam, p = camera_and_params(g, pl)
+            img, ctr = r.render_lattice(cam, p, int(g["width"]), int(g["height"]), int(g["lattice"]))
+            assert ctr.ray_count == int(g["ray_count"])
+            assert np.abs(img[:, :, :3] - g["rgb"]).max() <= TOL
+    finally:
+        r.close()
+
+
 def _random_configs():
     rng = np.random.default_rng(20241003)
     scenes_ = ["cornell_box", "sphere_plane", "icosphere_l3", "terrain_64", "many_materials", "textured_gallery"]

@@ -255,6 +255,21 @@ def test_bvh_is_conservative_and_complete(name):
     assert bound == 3 * depth + 2
 
 
+@pytest.mark.parametrize("name", ["cornell_box", "icosphere_l3", "terrain_64", "textured_gallery"])
+def test_area_optimal_collapse_is_conservative_and_smaller(name, monkeypatch):
+    """PRT_BVH_COLLAPSE=dp: same leaves, every triangle still inside every ancestor's box, never more wide nodes than the
+    greedy collapse of the same binary tree."""
+    hs = host_scene(name)
+    out = (C.c_uint64 * 6)()
+    assert capi.hip_lib().prt_debug_check_bvh(hs.desc, out) == 0
+    greedy = list(out)
+    monkeypatch.setenv("PRT_BVH_COLLAPSE", "dp")
+    assert capi.hip_lib().prt_debug_check_bvh(hs.desc, out) == 0
+    violations, nodes, depth, bound, leaves, refs = list(out)
+    assert violations == 0 and refs == hs.n_tris
+    assert leaves == greedy[4] and nodes <= greedy[1]
+
+
 def test_bvh_degenerate_scenes(tmp_path):
     # one triangle, and many coincident triangles (all centroids equal -> median splits)
     (tmp_path / "one.obj").write_text("v 0 0 0\nv 1 0 0\nv 0 1 0\nvt 0 0\nvn 0 0 1\ng t\nf 1/1/1 2/1/1 3/1/1\n")
