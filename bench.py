@@ -285,7 +285,13 @@ def main():
                 "algorithmic_bytes_per_frame": int(alg_bytes), "kernel_ms_per_frame": round(kernel_ms, 4),
                 "per_frame": {"rays": int(cc.ray_count), "node_visits": int(cc.node_visits), "tri_tests": int(cc.tri_tests),
                                "shaded_hits": int(cc.shaded_hits), "pixels": int(n_px_local)},
-                "bytes_per_unit": {"ray": B_RAY, "node": B_NODE, "tri_test": B_TRI, "shaded_hit": B_SHADE, "pixel": B_PIXEL}}
+                "bytes_per_unit": {"ray": B_RAY, "node": B_NODE, "tri_test": B_TRI, "shaded_hit": B_SHADE, "pixel": B_PIXEL},
+                # SURVEY.md §8d asks for these two beside the algorithmic figure: what the kernel really moved through HBM
+                # (PMC, per second of kernel time, as a fraction of the 8 TB/s peak) and the compulsory minimum of a frame
+                # (every ray record once, the resident scene once, the framebuffer once)
+                "hbm_measured": ({"GBps": round(traffic / (kernel_ms * 1e-3) / 1e9, 1),
+                                  "frac_of_peak": round(traffic / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)} if traffic and kernel_ms > 0 else None),
+                "compulsory_bytes_per_frame": int(cc.ray_count * B_RAY + info.device_bytes + n_px_local * B_PIXEL)}
 
     # ---- CPU baseline + parity on a sparse lattice of the same frame (rank 0, N = 1 only)
     cpu_baseline = None
