@@ -426,7 +426,10 @@ void finish_bvh4q(Builder & b, uint32_t n_tris, Bvh4Result * out) {
             scale[a] = std::ldexp(1.0, e);
             d[a] = float_bits(u.lo[a]);
         }
-        d[3] = ebyte[0] | (ebyte[1] << 8) | (ebyte[2] << 16) | (w.n << 24);
+        // the grid steps 2^e as ready-made floats (the exponent byte in place): the traversal multiplies, it does not decode
+        d[3] = ebyte[0] << 23;
+        d[14] = ebyte[1] << 23;
+        d[15] = ebyte[2] << 23;
         for (uint32_t k = 0; k < 4; ++k) {
             uint32_t qlo[3] = { 255, 255, 255 }, qhi[3] = { 0, 0, 0 };      // empty slot: inverted (and masked by its link)
             if (k < w.n) {

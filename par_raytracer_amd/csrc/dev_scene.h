@@ -7,9 +7,10 @@
 //   nodes      4-wide BVH, 64 B per node = 16 dwords, child boxes quantised to 8 bits per plane on the
 //              node's own power-of-two grid (plane = origin + q * 2^e, rounded outward at build time):
 //                d0-2  origin xyz (float: lo corner of the union of the children)
-//                d3    e_x+127 | (e_y+127) << 8 | (e_z+127) << 16 | child_count << 24
+//                d3    2^e_x as a float (the grid step along x; a multiply away from the slab test)
 //                d4-6  lo planes x / y / z, one byte per child      d7-9  hi planes x / y / z
-//                d10-13 child links                                 d14-15 unused
+//                d10-13 child links                                 d14-15 2^e_y, 2^e_z
+//              (children fill the slots from 0; an empty slot has lo = 255 > hi = 0 on every axis)
 //              link >= 0: node index; link < 0: leaf, ~link = (first_tri << 2) | (count - 1).
 //              One node visit = one 64 B fetch that decides about four subtrees: half the bytes per ray of
 //              an uncompressed binary node with the same fetch size, and half the dependent fetches.

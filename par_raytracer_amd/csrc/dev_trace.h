@@ -159,9 +159,9 @@ PRT_D void trav_node_step(const DevScene & sc, TravRay & r, const STK & stk, Tra
     const uint4 * np = reinterpret_cast<const uint4 *>(sc.nodes) + 4 * (size_t)r.node;
     const uint4 w0 = np[0], w1 = np[1], w2 = np[2], w3 = np[3];
     if (COUNT) { st.nodes++; if (first_active_lane()) st.wnodes++; if ((unsigned int)r.sp > st.max_sp) st.max_sp = (unsigned int)r.sp; }
-    const float kx = __uint_as_float((w0.w & 0xFFu) << 23) * r.ix;
-    const float ky = __uint_as_float(((w0.w >> 8) & 0xFFu) << 23) * r.iy;
-    const float kz = __uint_as_float(((w0.w >> 16) & 0xFFu) << 23) * r.iz;
+    const float kx = __uint_as_float(w0.w) * r.ix;
+    const float ky = __uint_as_float(w3.z) * r.iy;
+    const float kz = __uint_as_float(w3.w) * r.iz;
     const float ox = __uint_as_float(w0.x), oy = __uint_as_float(w0.y), oz = __uint_as_float(w0.z);
     // entry / exit parameter of the node origin on each axis; the ray's direction signs pick, per axis, which
     // quantised plane set (lo or hi bytes) is the entry side - no per-plane min/max, and an empty child slot

@@ -1388,13 +1388,15 @@ static int check_bvh4q(const std::vector<float> & verts, uint32_t n_tris, const 
         if (it.node >= bvh.node_count) { violations++; continue; }
         const uint32_t * d = &bvh.nodes[(size_t)it.node * 16];
         float org[3], scale[3];
+        const int scale_dword[3] = { 3, 14, 15 };
         for (int a = 0; a < 3; ++a) {
             memcpy(&org[a], &d[a], 4);
-            uint32_t bits = ((d[3] >> (8 * a)) & 0xFFu) << 23;
-            memcpy(&scale[a], &bits, 4);
+            memcpy(&scale[a], &d[scale_dword[a]], 4);
+            if ((d[scale_dword[a]] & 0x807FFFFFu) != 0u || d[scale_dword[a]] == 0u) violations++;      // a positive power of two
         }
-        const uint32_t count = d[3] >> 24;
-        if (count < 1 || count > 4) violations++;
+        uint32_t count = 0;                                  // children come first; an empty slot has inverted planes on every axis
+        while (count < 4 && !(((d[4] >> (8 * count)) & 0xFFu) == 255u && ((d[7] >> (8 * count)) & 0xFFu) == 0u)) ++count;
+        if (count < 1) violations++;
         for (uint32_t k = 0; k < 4; ++k) {
             Item ch;
             if (k >= count) {
