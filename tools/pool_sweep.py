@@ -33,6 +33,7 @@ print("wavefront: full %.2f  1/8 shard %.2f" % (run(2, 1)[0], run(2, 8)[0]), flu
 which = sys.argv[1:] or ["cap", "keep", "blocks"]
 if "cap" in which: sweep("cap", {"PRT_POOL_CAP": [64, 128, 256, 512, 1024, 2048]})
 if "keep" in which: sweep("keep", {"PRT_KEEP_MIN": [24, 32, 40, 48], "PRT_NODE_MIN": [16, 32]})
+if "keep2" in which: sweep("keep2", {"PRT_KEEP_MIN": [36, 40, 44, 48, 56], "PRT_NODE_MIN": [24, 32, 40, 48]})
 if "blocks" in which: sweep("blocks", {"PRT_POOL_BLOCKS_PER_CU": [1, 2]})
 if "topup" in which: sweep("topup", {"PRT_POOL_CAP": [256, 512], "PRT_POOL_TOPUP": [64, 128, 256]})
 if "default" in which: sweep("default", {"PRT_POOL_NOP": [0]})
