@@ -19,7 +19,7 @@ HIP_FLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -shared -ffp-contract=o
              -Wall -Wno-unused-function -I$(ROOT)/include
 
 HOST_SRCS := $(PKG)/host/obj_loader.cpp $(PKG)/host/sphere_tree.cpp $(PKG)/host/host_scene.cpp \
-             $(PKG)/host/image_out.cpp $(PKG)/host/image_in.cpp $(PKG)/host/host_capi.cpp $(PKG)/host/render_host.cpp
+             $(PKG)/host/image_out.cpp $(PKG)/host/image_in.cpp $(PKG)/host/image_jpeg.cpp $(PKG)/host/host_capi.cpp $(PKG)/host/render_host.cpp
 HOST_DEPS := $(wildcard $(PKG)/host/*.h) $(ROOT)/include/prt.h $(ROOT)/include/prt_host.h
 HOST_FLAGS := -O2 -std=c++14 -fPIC -ffp-contract=off -fno-strict-aliasing -Wall -Wno-unused-function -pthread -I$(ROOT)/include
 

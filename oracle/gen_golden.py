@@ -48,6 +48,9 @@ FIXTURES = {
     # row N1: texture / alpha / bump path (14 texture files in 9 encodings; alpha holes, translucency, bump frames)
     "gallery_160x120": dict(scene="textured_gallery", width=160, height=120, spp=4, lattice=1),
     "gallery_two_lights_d4": dict(scene="textured_gallery", width=96, height=72, spp=2, lattice=1, depth=4, light_mode=1, rs=2, ss=2),
+    # JPEG textures: 12 baseline files of every sampling layout (grey, 4:4:4 ... 4:1:1, restart intervals, one scan per
+    # component, RGB ids) as diffuse / bump / alpha maps; pins the decoder's IDCT, upsampling and colour arithmetic
+    "jpeg_gallery_128x96": dict(scene="jpeg_gallery", width=128, height=96, spp=4, lattice=1),
     # row N4: the reference's adaptive loop (main.cpp:245-258), one RNG stream per pixel; spp = min_samples
     "cornell_adaptive_4_16": dict(scene="cornell_box", width=96, height=72, spp=4, max_spp=16, lattice=1),
     "gallery_adaptive_10_50": dict(scene="textured_gallery", width=64, height=48, spp=10, max_spp=50, lattice=1),      # reference defaults

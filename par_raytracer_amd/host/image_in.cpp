@@ -11,7 +11,8 @@
 //          flipped to top-down;
 //   * BMP  24-bit uncompressed, BGR -> RGB, bottom-up flipped;
 //   * PNM  binary P5 (grey) / P6 (RGB), maxval <= 255.
-// Anything else (JPEG, interlaced PNG, 1/2/4-bit PNG, colour-mapped TGA ...) is reported and the texture slot
+//   * JPEG baseline (image_jpeg.cpp): grey -> 1 channel, colour -> 3, every sampling layout, restart intervals.
+// Anything else (progressive JPEG, interlaced PNG, 1/2/4-bit PNG, colour-mapped TGA ...) is reported and the texture slot
 // stays empty, which is how the reference treats a file its decoder rejects (obj_parser.cpp:201-204).
 // tests/test_host_side.py compares the decoded bytes with the reference's on generated files of every kind.
 #include <zlib.h>
@@ -25,6 +26,10 @@
 #include <vector>
 
 #include "prt_scene.h"
+
+namespace prt_jpeg {
+const char * Decode(const std::vector<u8> & file, u32 * w, u32 * h, u32 * channels, std::vector<u8> * px);   // image_jpeg.cpp
+}
 
 namespace {
 
@@ -281,7 +286,10 @@ Texture * LoadTexture(const char * filename) {
         if (d.size() >= 8 && d[0] == 0x89 && d[1] == 'P') ok = DecodePng(d, &img);
         else if (d.size() >= 2 && d[0] == 'B' && d[1] == 'M') ok = DecodeBmp(d, &img);
         else if (d.size() >= 2 && d[0] == 'P' && (d[1] == '5' || d[1] == '6')) ok = DecodePnm(d, &img);
-        else if (d.size() >= 3 && d[0] == 0xFF && d[1] == 0xD8) ok = Fail("JPEG is not supported");
+        else if (d.size() >= 3 && d[0] == 0xFF && d[1] == 0xD8) {
+            const char * err = prt_jpeg::Decode(d, &img.w, &img.h, &img.channels, &img.px);
+            ok = err ? Fail(err) : true;
+        }
         else ok = DecodeTga(d, &img);                          // TGA has no signature: last
     } catch (const std::bad_alloc &) {
         ok = Fail("out of memory while decoding");

@@ -12,6 +12,7 @@ value the generator produced.
 from __future__ import annotations
 
 import os
+import struct
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -256,6 +257,230 @@ def write_pnm(path: str, img: np.ndarray) -> None:
         f.write(np.ascontiguousarray(a).tobytes())
 
 
+_JPEG_ZIGZAG = [0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28,
+                35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63]
+
+
+def _jpeg_huffman_table(freq: dict):
+    """Code lengths (1..16) for the symbols of `freq` by the procedure of ITU T.81 Annex K.2: Huffman's algorithm with one
+    reserved symbol (so that no code is all ones), lengths above 16 folded back.  Returns (counts[16], symbols in code order,
+    {symbol: (code, length)})."""
+    import heapq
+    items = [(f, 0, [sym]) for sym, f in freq.items() if f > 0]
+    items.append((0, 1, [256]))                                        # the reserved symbol: least frequent, longest code
+    depth = {sym: 0 for _, _, syms in items for sym in syms}
+    heap = [(f, tie, i, syms) for i, (f, tie, syms) in enumerate(items)]
+    heapq.heapify(heap)
+    n = len(heap)
+    if n == 1:
+        depth[heap[0][3][0]] = 1
+    while len(heap) > 1:
+        a = heapq.heappop(heap)
+        b = heapq.heappop(heap)
+        for sym in a[3] + b[3]:
+            depth[sym] += 1
+        n += 1
+        heapq.heappush(heap, (a[0] + b[0], max(a[1], b[1]), n, a[3] + b[3]))
+    bits = [0] * 64
+    for sym, d in depth.items():
+        bits[d] += 1
+    for i in range(63, 16, -1):                                         # K.2 figure K.3: fold lengths above 16 back
+        while bits[i] > 0:
+            j = i - 2
+            while bits[j] == 0:
+                j -= 1
+            bits[i] -= 2
+            bits[i - 1] += 1
+            bits[j + 1] += 2
+            bits[j] -= 1
+    i = 16
+    while bits[i] == 0:
+        i -= 1
+    bits[i] -= 1                                                        # drop the reserved symbol's code
+    order = sorted((sym for sym in depth if sym != 256), key=lambda sym: (depth[sym], sym))
+    counts = bits[1:17]
+    codes, code, k = {}, 0, 0
+    for length in range(1, 17):
+        for _ in range(counts[length - 1]):
+            codes[order[k]] = (code, length)
+            code += 1
+            k += 1
+        code <<= 1
+    assert k == len(order)
+    return counts, order, codes
+
+
+def write_jpeg(path: str, img: np.ndarray, sampling: Tuple[int, int] = (1, 1), restart: int = 0, interleaved: bool = True,
+               rgb_ids: bool = False, q_step: Tuple[int, int] = (2, 3)) -> None:
+    """Baseline (SOF0) JPEG with its own optimal Huffman tables.  img: [h, w] grey or [h, w, 3] RGB.  `sampling` = luma
+    (h, v) factors against 1x1 chroma: (1,1) 4:4:4, (2,1) 4:2:2, (1,2) 4:4:0, (2,2) 4:2:0, (4,1) 4:1:1.  `restart`:
+    restart interval in MCUs (0 = none).  `interleaved` False writes one scan per component.  `rgb_ids`: store R, G, B
+    themselves under the component ids 'R', 'G', 'B' (no colour transform on either side)."""
+    img = np.asarray(img, dtype=np.uint8)
+    grey = img.ndim == 2 or img.shape[2] == 1
+    H, W = img.shape[:2]
+    if grey:
+        planes = [img.reshape(H, W).astype(np.float64)]
+        factors = [(1, 1)]
+    else:
+        rgb = img[:, :, :3].astype(np.float64)
+        if rgb_ids:
+            planes = [rgb[:, :, 0], rgb[:, :, 1], rgb[:, :, 2]]
+        else:
+            r, g, b = rgb[:, :, 0], rgb[:, :, 1], rgb[:, :, 2]
+            planes = [0.299 * r + 0.587 * g + 0.114 * b,
+                      128.0 - 0.168736 * r - 0.331264 * g + 0.5 * b,
+                      128.0 + 0.5 * r - 0.418688 * g - 0.081312 * b]
+        factors = [tuple(sampling), (1, 1), (1, 1)]
+    hmax = max(f[0] for f in factors)
+    vmax = max(f[1] for f in factors)
+    mcu_w, mcu_h = 8 * hmax, 8 * vmax
+    mcus_x, mcus_y = (W + mcu_w - 1) // mcu_w, (H + mcu_h - 1) // mcu_h
+    # DCT-II basis
+    k = np.arange(8)
+    C = np.sqrt(2.0 / 8.0) * np.cos((2 * k[None, :] + 1) * k[:, None] * np.pi / 16.0)
+    C[0, :] = np.sqrt(1.0 / 8.0)
+    ii, jj = np.mgrid[0:8, 0:8]
+    qtabs = [np.clip(2 + (ii + jj) * q_step[0], 1, 255).astype(np.int64), np.clip(3 + (ii + jj) * q_step[1], 1, 255).astype(np.int64)]
+    comps = []
+    for ci, (plane, (fh, fv)) in enumerate(zip(planes, factors)):
+        full = np.pad(plane, ((0, mcus_y * mcu_h - H), (0, mcus_x * mcu_w - W)), mode="edge")
+        sh, sv = hmax // fh, vmax // fv                                 # down-sampling of this component
+        sub = full.reshape(full.shape[0] // sv, sv, full.shape[1] // sh, sh).mean(axis=(1, 3))
+        q = qtabs[0 if ci == 0 else 1]
+        by, bx = sub.shape[0] // 8, sub.shape[1] // 8
+        coef = np.zeros((by, bx, 64), dtype=np.int64)
+        for y in range(by):
+            for x in range(bx):
+                blk = sub[8 * y:8 * y + 8, 8 * x:8 * x + 8] - 128.0
+                d = C @ blk @ C.T
+                coef[y, x] = np.rint(d / q).astype(np.int64).reshape(64)[_JPEG_ZIGZAG]
+        comps.append(dict(h=fh, v=fv, coef=coef, tq=0 if ci == 0 else 1, td=0 if ci == 0 else 1,
+                          real_bx=((W * fh + hmax - 1) // hmax + 7) // 8, real_by=((H * fv + vmax - 1) // vmax + 7) // 8))
+
+    # ---- scans as lists of (component, block) in coding order, with restart boundaries
+    def scan_blocks(component_ids):
+        units = []                                                      # one entry per MCU: [(ci, zigzag coefficients), ...]
+        if len(component_ids) == 1:
+            c = comps[component_ids[0]]
+            for y in range(c["real_by"]):
+                for x in range(c["real_bx"]):
+                    units.append([(component_ids[0], c["coef"][y, x])])
+        else:
+            for my in range(mcus_y):
+                for mx in range(mcus_x):
+                    u = []
+                    for ci in component_ids:
+                        c = comps[ci]
+                        for y in range(c["v"]):
+                            for x in range(c["h"]):
+                                u.append((ci, c["coef"][my * c["v"] + y, mx * c["h"] + x]))
+                    units.append(u)
+        return units
+
+    def symbols_of(units):
+        """[(kind, table, symbol, extra bits value, extra bits count) | ('rst', n)]"""
+        out = []
+        pred = {}
+        for n, u in enumerate(units):
+            if restart and n and n % restart == 0:
+                out.append(("rst", (n // restart - 1) % 8))
+                pred = {}
+            for ci, zz in u:
+                diff = int(zz[0]) - pred.get(ci, 0)
+                pred[ci] = int(zz[0])
+                size = abs(diff).bit_length()
+                out.append(("dc", comps[ci]["td"], size, diff if diff >= 0 else diff + (1 << size) - 1, size))
+                run = 0
+                last = max([i for i in range(1, 64) if zz[i] != 0], default=0)
+                for i in range(1, last + 1):
+                    v = int(zz[i])
+                    if v == 0:
+                        run += 1
+                        continue
+                    while run > 15:
+                        out.append(("ac", comps[ci]["td"], 0xF0, 0, 0))
+                        run -= 16
+                    size = abs(v).bit_length()
+                    out.append(("ac", comps[ci]["td"], (run << 4) | size, v if v >= 0 else v + (1 << size) - 1, size))
+                    run = 0
+                if last < 63:
+                    out.append(("ac", comps[ci]["td"], 0x00, 0, 0))
+        return out
+
+    scans = [list(range(len(comps)))] if (interleaved or len(comps) == 1) else [[ci] for ci in range(len(comps))]
+    scan_syms = [symbols_of(scan_blocks(ids)) for ids in scans]
+    freq = {("dc", 0): {}, ("dc", 1): {}, ("ac", 0): {}, ("ac", 1): {}}
+    for syms in scan_syms:
+        for s_ in syms:
+            if s_[0] != "rst":
+                f = freq[(s_[0], s_[1])]
+                f[s_[2]] = f.get(s_[2], 0) + 1
+    tables = {key: _jpeg_huffman_table(f) for key, f in freq.items() if f}
+
+    def seg(marker, body):
+        return bytes([0xFF, marker]) + struct.pack(">H", len(body) + 2) + body
+
+    out = bytearray(b"\xFF\xD8")
+    out += seg(0xE0, b"JFIF\0\x01\x01\x00\x00\x01\x00\x01\x00\x00")
+    out += seg(0xFE, b"par_raytracer_amd test texture")
+    ntab = 1 if len(comps) == 1 else 2
+    out += seg(0xDB, b"".join(bytes([t]) + bytes(int(v) for v in qtabs[t].reshape(64)[_JPEG_ZIGZAG]) for t in range(ntab)))
+    ids = [ord(c) for c in "RGB"] if rgb_ids else [1, 2, 3]
+    sof = struct.pack(">BHHB", 8, H, W, len(comps))
+    for ci, c in enumerate(comps):
+        sof += bytes([ids[ci], (c["h"] << 4) | c["v"], c["tq"]])
+    out += seg(0xC0, sof)
+    dht = b""
+    for (kind, t), (counts, order, _) in sorted(tables.items()):
+        dht += bytes([(0x10 if kind == "ac" else 0x00) | t]) + bytes(counts) + bytes(order)
+    out += seg(0xC4, dht)
+    if restart:
+        out += seg(0xDD, struct.pack(">H", restart))
+    for comp_ids, syms in zip(scans, scan_syms):
+        sos = bytes([len(comp_ids)])
+        for ci in comp_ids:
+            sos += bytes([ids[ci], (comps[ci]["td"] << 4) | comps[ci]["td"]])
+        out += seg(0xDA, sos + b"\x00\x3F\x00")
+        acc, nacc = 0, 0
+        data = bytearray()
+
+        def flush_bits():
+            nonlocal acc, nacc
+            while nacc >= 8:
+                byte = (acc >> (nacc - 8)) & 0xFF
+                data.append(byte)
+                if byte == 0xFF:
+                    data.append(0)
+                nacc -= 8
+            acc &= (1 << nacc) - 1
+
+        def put(value, nbits):
+            nonlocal acc, nacc
+            acc = (acc << nbits) | (value & ((1 << nbits) - 1))
+            nacc += nbits
+            flush_bits()
+
+        def pad():
+            if nacc % 8:
+                put((1 << (8 - nacc % 8)) - 1, 8 - nacc % 8)
+
+        for s_ in syms:
+            if s_[0] == "rst":
+                pad()
+                data += bytes([0xFF, 0xD0 + s_[1]])
+                continue
+            code, length = tables[(s_[0], s_[1])][2][s_[2]]
+            put(code, length)
+            if s_[4]:
+                put(s_[3], s_[4])
+        pad()
+        out += data
+    out += b"\xFF\xD9"
+    with open(path, "wb") as f:
+        f.write(bytes(out))
+
+
 def write_texture(path: str, img: np.ndarray, encoding: str) -> None:
     enc = {
         "png": lambda: write_png(path, img),
@@ -267,6 +492,14 @@ def write_texture(path: str, img: np.ndarray, encoding: str) -> None:
         "tga_rle": lambda: write_tga(path, img, rle=True),
         "bmp": lambda: write_bmp(path, img),
         "pnm": lambda: write_pnm(path, img),
+        "jpg": lambda: write_jpeg(path, img),                                             # 4:4:4 (or grey)
+        "jpg422": lambda: write_jpeg(path, img, sampling=(2, 1)),
+        "jpg440": lambda: write_jpeg(path, img, sampling=(1, 2)),
+        "jpg420": lambda: write_jpeg(path, img, sampling=(2, 2)),
+        "jpg411": lambda: write_jpeg(path, img, sampling=(4, 1)),
+        "jpg420_rst": lambda: write_jpeg(path, img, sampling=(2, 2), restart=3),
+        "jpg_scans": lambda: write_jpeg(path, img, sampling=(2, 2), interleaved=False, restart=5),
+        "jpg_rgb": lambda: write_jpeg(path, img, rgb_ids=True),
     }
     enc[encoding]()
 
@@ -651,6 +884,64 @@ def textured_gallery(sphere_segments: int = 20, sphere_rings: int = 10) -> ObjSc
         camera_position=(0.3, 1.4, 4.6), camera_facing=(-0.05, -0.18, -1.0), fov=60.0)
 
 
+def jpeg_gallery() -> ObjScene:
+    """JPEG textures through the loader and the texture path: eight panels in two rows over a floor, one per JPEG layout
+    write_jpeg produces - grey, 4:4:4, 4:2:2, 4:4:0, 4:2:0, 4:1:1, 4:2:0 with a restart interval, one scan per component
+    with a restart interval, RGB component ids - with sizes that are not multiples of the MCU, plus grey JPEGs as bump
+    and alpha maps.  The decoded bytes depend on the decoder's inverse DCT, upsampling filter and colour arithmetic,
+    which is what the fixture pins against the reference's decoder."""
+    rng = np.random.default_rng(20241004)
+    pos, nrm, uv = [], [], []
+    groups = []
+
+    def add(name, tris, material):
+        groups.append(ObjGroup(name, _faces_same_index(np.array(tris)), material))
+
+    add("floor", _quad(pos, nrm, uv, [(-4, 0, 3), (4, 0, 3), (4, 0, -3), (-4, 0, -3)], (0, 1, 0),
+                       [(0, 0), (2, 0), (2, 1.5), (0, 1.5)]), "floor")
+
+    def picture(h, w, kind):
+        yy, xx = np.mgrid[0:h, 0:w]
+        base = np.stack([128 + 100 * np.sin(2 * np.pi * (xx / w * 1.5 + kind * 0.13)) * np.cos(2 * np.pi * yy / h),
+                         128 + 110 * np.cos(2 * np.pi * (yy / h * 2.0 + kind * 0.07)),
+                         ((xx // 5 + yy // 7 + kind) % 2) * 200 + 30], axis=2)
+        img = base + rng.integers(-25, 26, size=base.shape)
+        img[h // 3:h // 3 + 4, :, :] = (255, 0, 0) if kind % 2 else (0, 0, 255)      # saturated edges: clamping in the colour arithmetic
+        img[:, w // 2:w // 2 + 2, :] = 255
+        return img.clip(0, 255).astype(np.uint8)
+
+    layouts = [("grey", "jpg", (23, 41)), ("c444", "jpg", (30, 37)), ("c422", "jpg422", (33, 47)), ("c440", "jpg440", (45, 26)),
+               ("c420", "jpg420", (50, 61)), ("c411", "jpg411", (19, 70)), ("c420r", "jpg420_rst", (64, 48)),
+               ("scans", "jpg_scans", (35, 52)), ("rgbid", "jpg_rgb", (17, 24))]
+    textures = {}
+    materials = [MtlMaterial("floor", Ns=20.0, Ka=(0.6, 0.6, 0.6), Kd=(0.9, 0.9, 0.9), Ks=(0.2, 0.2, 0.2), map_Kd="floor_kd.jpg",
+                             map_bump="floor_bump.jpg")]
+    textures["floor_kd.jpg"] = (picture(72, 96, 11), "jpg420")
+    yy, xx = np.mgrid[0:40, 0:56]
+    textures["floor_bump.jpg"] = ((127.5 + 120 * np.sin(xx * 0.7) * np.cos(yy * 0.5)).astype(np.uint8), "jpg")       # grey height map
+    for k, (name, enc, (h, w)) in enumerate(layouts):
+        col, row = k % 5, k // 5
+        x0, y0 = -3.6 + col * 1.5, 0.15 + row * 1.55
+        z = -1.5 - 0.25 * row
+        add("panel_" + name, _quad(pos, nrm, uv, [(x0, y0, z), (x0 + 1.3, y0, z), (x0 + 1.3, y0 + 1.3, z), (x0, y0 + 1.3, z)], (0, 0, 1),
+                                   [(0, 0), (1, 0), (1, 1), (0, 1)]), name)
+        img = picture(h, w, k)
+        textures[name + ".jpg"] = (img[:, :, 1] if name == "grey" else img, enc)
+        kw = {}
+        if name == "c444":                                              # a grey JPEG as alpha map: holes in the panel
+            a = (128 + 127 * np.sin(xx[:32, :32] * 0.9) * np.sin(yy[:32, :32] * 0.8))
+            a[a < 100] = 0
+            textures["c444_d.jpg"] = (a.astype(np.uint8), "jpg")
+            kw["map_d"] = "c444_d.jpg"
+        materials.append(MtlMaterial(name, Ns=25.0, d=1.0, Ka=(0.7, 0.7, 0.7), Kd=(1.0, 1.0, 1.0), Ks=(0.15, 0.15, 0.15),
+                                     map_Kd=name + ".jpg", **kw))
+    return ObjScene(
+        name="jpeg_gallery",
+        positions=np.array(pos, dtype=F32), texcoords=np.array(uv, dtype=F32), normals=np.array(nrm, dtype=F32),
+        groups=groups, materials=materials, textures=textures,
+        camera_position=(0.0, 1.7, 4.4), camera_facing=(0.0, -0.12, -1.0), fov=62.0)
+
+
 # ----------------------------------------------------------------------------------------
 # registry: name -> (factory, render defaults)
 # ----------------------------------------------------------------------------------------
@@ -675,6 +966,7 @@ SCENES = {
     "terrain_192": lambda: terrain(192, 8, size=192.0),       # 73,728 tris in 64 groups
     "many_materials": lambda: many_materials(),               # 1,282 tris, 42 materials (LDS table fallback), translucent clusters
     "textured_gallery": lambda: textured_gallery(),           # 192 tris, 7 materials, 14 texture files (row N1)
+    "jpeg_gallery": lambda: jpeg_gallery(),                   # 20 tris, 10 materials, 12 baseline JPEG files of every sampling layout
 }
 
 CONFIGS: Dict[str, RenderConfig] = {
