@@ -11,8 +11,8 @@
 //          flipped to top-down;
 //   * BMP  24-bit uncompressed, BGR -> RGB, bottom-up flipped;
 //   * PNM  binary P5 (grey) / P6 (RGB), maxval <= 255.
-//   * JPEG baseline (image_jpeg.cpp): grey -> 1 channel, colour -> 3, every sampling layout, restart intervals.
-// Anything else (progressive JPEG, interlaced PNG, 1/2/4-bit PNG, colour-mapped TGA ...) is reported and the texture slot
+//   * JPEG baseline and progressive (image_jpeg.cpp): grey -> 1 channel, colour -> 3, every sampling layout, restart intervals.
+// Anything else (arithmetic-coded JPEG, interlaced PNG, 1/2/4-bit PNG, colour-mapped TGA ...) is reported and the texture slot
 // stays empty, which is how the reference treats a file its decoder rejects (obj_parser.cpp:201-204).
 // tests/test_host_side.py compares the decoded bytes with the reference's on generated files of every kind.
 #include <zlib.h>

@@ -1,4 +1,4 @@
-// image_jpeg.cpp - baseline JPEG decoder behind LoadTexture (obj_parser.cpp:197-213).
+// image_jpeg.cpp - baseline and progressive JPEG decoder behind LoadTexture (obj_parser.cpp:197-213).
 //
 // The reference reads JPEG textures through its third-party image library (lib/stb_image.h v2.14,
 // `stbi_load(name, &x, &y, &channels, 0)`).  The hot path indexes the decoded bytes directly (texture.cpp:17-51), so a
@@ -16,8 +16,10 @@
 //     12-bit constants, the cb term of g truncated to 16 bits before the sum, rounding by + 2^19; files whose component
 //     ids are 'R', 'G', 'B' are copied through.
 // Output convention: 1 channel for a grey file, 3 for a colour file, rows top to bottom.
-// Not handled (reported, the texture slot stays empty like a decoder failure in the reference): progressive (SOF2),
-// arithmetic coding, 12-bit samples, 4 components.  tests/test_host_side.py compares the decoded bytes with the
+// Progressive files (SOF2, T.81 Annex G: spectral selection and successive approximation, end-of-band runs, DC and AC
+// refinement scans) build their coefficients up scan by scan and are dequantised and transformed at the end.
+// Not handled (reported, the texture slot stays empty like a decoder failure in the reference): arithmetic coding,
+// lossless / hierarchical processes, 12-bit samples, 4 components.  tests/test_host_side.py compares the decoded bytes with the
 // reference's on generated files of every sampling layout.
 #include <cstdint>
 #include <cstring>
@@ -60,6 +62,8 @@ struct Component {
     int w2 = 0, h2 = 0;      // plane size, whole MCUs
     int dc_pred = 0;
     std::vector<u8> plane;
+    std::vector<short> coeff;   // progressive: 64 coefficients per block of the (MCU-padded) plane, coeff_w blocks per row
+    int coeff_w = 0;
 };
 
 struct Decoder {
@@ -68,6 +72,8 @@ struct Decoder {
     int width = 0, height = 0, ncomp = 0, rgb_ids = 0;
     int h_max = 1, v_max = 1, mcu_x = 0, mcu_y = 0;
     int restart_interval = 0;
+    bool progressive = false;
+    int ss = 0, se = 63, ah = 0, al = 0, eob_run = 0;      // progressive: the current scan's band, bit positions and pending end-of-band run
     unsigned char dequant[4][64];
     bool have_dqt[4] = { false, false, false, false };
     Huffman dc[4], ac[4];
@@ -117,6 +123,7 @@ struct Decoder {
         bits = 0;
         nbits = 0;
         marker = 0;
+        eob_run = 0;
         for (int i = 0; i < 3; ++i) comp[i].dc_pred = 0;
     }
 
@@ -145,6 +152,96 @@ struct Decoder {
             }
         }
         return true;
+    }
+
+    // ---- progressive scans (T.81 G.1.2): coefficients are built up over several scans in `coeff`, natural order ------
+    bool ProgDc(Component & c, short * data) {
+        if (ah == 0) {                                       // first DC scan: the difference, scaled by the point transform
+            memset(data, 0, 64 * sizeof(short));
+            const int t = Decode(dc[c.hd]);
+            if (t < 0 || t > 15) return Fail("bad huffman code");
+            const int diff = t ? Extend(GetBits(t), t) : 0;
+            c.dc_pred += diff;
+            data[0] = (short)((unsigned int)c.dc_pred << al);
+        } else if (GetBits(1)) {                             // refinement: one more bit
+            data[0] = (short)(data[0] + (short)(1 << al));
+        }
+        return true;
+    }
+    void Refine(short * p, short bit) {                      // a coefficient that is already non-zero takes one correction bit
+        if (GetBits(1) && (*p & bit) == 0) *p = (short)(*p > 0 ? *p + bit : *p - bit);
+    }
+    bool ProgAc(Component & c, short * data) {
+        const Huffman & ha = ac[c.ha];
+        if (ah == 0) {                                       // first scan of the band ss..se
+            if (eob_run) { --eob_run; return true; }
+            int k = ss;
+            do {
+                const int rs = Decode(ha);
+                if (rs < 0) return Fail("bad huffman code");
+                const int s = rs & 15, r = rs >> 4;
+                if (s == 0) {
+                    if (r < 15) {                            // EOBn: this block and eob_run more end here
+                        eob_run = (1 << r) - 1;
+                        if (r) eob_run += GetBits(r);
+                        break;
+                    }
+                    k += 16;
+                } else {
+                    k += r;
+                    if (k > 63) return Fail("bad huffman code");
+                    data[kZigzag[k++]] = (short)((unsigned int)Extend(GetBits(s), s) << al);
+                }
+            } while (k <= se);
+            return true;
+        }
+        const short bit = (short)(1 << al);                  // refinement scan of the band
+        if (eob_run) {
+            --eob_run;
+            for (int k = ss; k <= se; ++k) {
+                short * p = &data[kZigzag[k]];
+                if (*p != 0) Refine(p, bit);
+            }
+            return true;
+        }
+        int k = ss;
+        do {
+            const int rs = Decode(ha);
+            if (rs < 0) return Fail("bad huffman code");
+            int s = rs & 15, r = rs >> 4;
+            if (s == 0) {
+                if (r < 15) {
+                    eob_run = (1 << r) - 1;
+                    if (r) eob_run += GetBits(r);
+                    r = 64;                                  // the rest of the band only takes correction bits
+                }                                            // else ZRL: sixteen zero-history coefficients are skipped
+            } else {
+                if (s != 1) return Fail("bad huffman code");
+                s = GetBits(1) ? bit : -bit;                 // the new coefficient's sign
+            }
+            while (k <= se) {
+                short * p = &data[kZigzag[k++]];
+                if (*p != 0) {
+                    Refine(p, bit);
+                } else {
+                    if (r == 0) { *p = (short)s; break; }
+                    --r;
+                }
+            }
+        } while (k <= se);
+        return true;
+    }
+    void FinishProgressive() {                               // dequantise and transform what the scans have built
+        for (int n = 0; n < ncomp; ++n) {
+            Component & c = comp[n];
+            const int bw = (c.x + 7) >> 3, bh = (c.y + 7) >> 3;
+            for (int j = 0; j < bh; ++j)
+                for (int i = 0; i < bw; ++i) {
+                    short * data = c.coeff.data() + 64 * ((size_t)i + (size_t)j * c.coeff_w);
+                    for (int q = 0; q < 64; ++q) data[q] = (short)(data[q] * dequant[c.tq][q]);
+                    IdctBlock(c.plane.data() + (size_t)c.w2 * j * 8 + i * 8, c.w2, data);
+                }
+        }
     }
 
     // ---- inverse DCT -------------------------------------------------------------------------------------------
@@ -316,6 +413,10 @@ struct Decoder {
             c.w2 = mcu_x * c.h * 8;
             c.h2 = mcu_y * c.v * 8;
             c.plane.assign((size_t)c.w2 * c.h2, 0);
+            if (progressive) {
+                c.coeff_w = c.w2 / 8;
+                c.coeff.assign((size_t)c.w2 * c.h2, 0);
+            }
         }
         return true;
     }
@@ -333,14 +434,27 @@ struct Decoder {
             comp[which].hd = q >> 4;
             comp[which].ha = q & 15;
             if (comp[which].hd > 3 || comp[which].ha > 3) return Fail("bad huffman table index");
-            if (!dc[comp[which].hd].defined || !ac[comp[which].ha].defined) return Fail("scan uses an undefined huffman table");
-            if (!have_dqt[comp[which].tq]) return Fail("scan uses an undefined quantisation table");
+            if (!progressive && !have_dqt[comp[which].tq]) return Fail("scan uses an undefined quantisation table");
             order[i] = which;
         }
-        const int ss = Get8();
-        Get8();                                              // Se: 63 for a sequential scan
+        ss = Get8();
+        se = Get8();
         const int aa = Get8();
-        if (ss != 0 || aa != 0) return Fail("bad SOS");
+        ah = aa >> 4;
+        al = aa & 15;
+        if (progressive) {
+            if (ss > 63 || se > 63 || ss > se || ah > 13 || al > 13) return Fail("bad SOS");
+            if (ss == 0 && se != 0) return Fail("a progressive scan cannot hold DC and AC coefficients");
+            if (ss != 0 && n != 1) return Fail("a progressive AC scan holds one component");
+        } else {
+            if (ss != 0 || ah != 0 || al != 0) return Fail("bad SOS");
+            se = 63;
+        }
+        for (int i = 0; i < n; ++i) {
+            const Component & c = comp[order[i]];
+            const bool need_dc = !progressive || (ss == 0 && ah == 0), need_ac = !progressive || ss != 0;
+            if ((need_dc && !dc[c.hd].defined) || (need_ac && !ac[c.ha].defined)) return Fail("scan uses an undefined huffman table");
+        }
         ResetEntropy();
         int todo = restart_interval ? restart_interval : 0x7FFFFFFF;
         short data[64];
@@ -352,13 +466,21 @@ struct Decoder {
             todo = restart_interval ? restart_interval : 0x7FFFFFFF;
             return 1;
         };
+        auto block = [&](Component & c, int bx, int by) -> bool {      // one 8 x 8 block of component c at block position (bx, by)
+            if (progressive) {
+                short * cf = c.coeff.data() + 64 * ((size_t)bx + (size_t)by * c.coeff_w);
+                return ss == 0 ? ProgDc(c, cf) : ProgAc(c, cf);
+            }
+            if (!DecodeBlock(c, data)) return false;
+            IdctBlock(c.plane.data() + (size_t)c.w2 * by * 8 + bx * 8, c.w2, data);
+            return true;
+        };
         if (n == 1) {                                        // one component: its blocks in raster order
             Component & c = comp[order[0]];
             const int bw = (c.x + 7) >> 3, bh = (c.y + 7) >> 3;
             for (int j = 0; j < bh; ++j)
                 for (int i = 0; i < bw; ++i) {
-                    if (!DecodeBlock(c, data)) return false;
-                    IdctBlock(c.plane.data() + (size_t)c.w2 * j * 8 + i * 8, c.w2, data);
+                    if (!block(c, i, j)) return false;
                     if (!restart()) return true;
                 }
         } else {                                             // interleaved: MCU by MCU, h x v blocks of every component
@@ -367,10 +489,8 @@ struct Decoder {
                     for (int k = 0; k < n; ++k) {
                         Component & c = comp[order[k]];
                         for (int y = 0; y < c.v; ++y)
-                            for (int x = 0; x < c.h; ++x) {
-                                if (!DecodeBlock(c, data)) return false;
-                                IdctBlock(c.plane.data() + (size_t)c.w2 * ((j * c.v + y) * 8) + (i * c.h + x) * 8, c.w2, data);
-                            }
+                            for (int x = 0; x < c.h; ++x)
+                                if (!block(c, i * c.h + x, j * c.v + y)) return false;
                     }
                     if (!restart()) return true;
                 }
@@ -388,12 +508,11 @@ struct Decoder {
                 continue;                                     // junk between segments
             }
             if (m == 0xD9) break;
-            if (m == 0xC0 || m == 0xC1) {
+            if (m == 0xC0 || m == 0xC1 || m == 0xC2) {
                 if (have_frame) return Fail("two frame headers");
+                progressive = m == 0xC2;
                 if (!ReadSof()) return false;
                 have_frame = true;
-            } else if (m == 0xC2) {
-                return Fail("progressive JPEG is not supported");
             } else if (m == 0xC3 || (m >= 0xC5 && m <= 0xCF && m != 0xC8 && m != 0xCC)) {
                 return Fail("this JPEG process (lossless / hierarchical / arithmetic) is not supported");
             } else if (m == 0xDB) {
@@ -418,6 +537,11 @@ struct Decoder {
             }
         }
         if (!have_frame || !have_scan) return Fail("no image data");
+        if (progressive) {
+            for (int i = 0; i < ncomp; ++i)
+                if (!have_dqt[comp[i].tq]) return Fail("component uses an undefined quantisation table");
+            FinishProgressive();
+        }
         return true;
     }
 

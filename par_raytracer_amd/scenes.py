@@ -310,9 +310,205 @@ def _jpeg_huffman_table(freq: dict):
     return counts, order, codes
 
 
+class _JpegBits:
+    """Entropy-coded segment writer: MSB-first bits, 0xFF byte stuffing, 1-padding before markers."""
+    def __init__(self):
+        self.data = bytearray()
+        self.acc = 0
+        self.n = 0
+
+    def put(self, value, nbits):
+        self.acc = (self.acc << nbits) | (value & ((1 << nbits) - 1))
+        self.n += nbits
+        while self.n >= 8:
+            byte = (self.acc >> (self.n - 8)) & 0xFF
+            self.data.append(byte)
+            if byte == 0xFF:
+                self.data.append(0)
+            self.n -= 8
+        self.acc &= (1 << self.n) - 1
+
+    def pad(self):
+        if self.n % 8:
+            self.put((1 << (8 - self.n % 8)) - 1, 8 - self.n % 8)
+
+    def marker(self, m):
+        self.pad()
+        self.data += bytes([0xFF, m])
+
+
+def _write_progressive_jpeg(path, H, W, comps, qtabs, mcus_x, mcus_y, restart, rgb_ids, scan_blocks) -> None:
+    """ITU T.81 Annex G.  Scan script: DC of all components (point transform 1); per component AC 1..5 and 6..63 (point
+    transform 2); per component AC refinement to 1; DC refinement; per component AC refinement to 0.  Every scan that uses
+    Huffman coding is preceded by its own optimal table(s).  Operations are collected symbolically first (('sym', table,
+    symbol) | ('bits', value, count) | ('rst', n)) so that the tables can be built from their statistics."""
+    n_comp = len(comps)
+
+    def dc_first(units, al):
+        ops, pred = [], {}
+        for n, u in enumerate(units):
+            if restart and n and n % restart == 0:
+                ops.append(("rst", (n // restart - 1) % 8))
+                pred = {}
+            for ci, zz in u:
+                v = int(zz[0]) >> al                                     # arithmetic shift: the DC point transform
+                diff = v - pred.get(ci, 0)
+                pred[ci] = v
+                size = abs(diff).bit_length()
+                ops.append(("sym", ("dc", comps[ci]["td"]), size))
+                if size:
+                    ops.append(("bits", diff if diff >= 0 else diff + (1 << size) - 1, size))
+        return ops
+
+    def dc_refine(units, al):
+        ops = []
+        for n, u in enumerate(units):
+            if restart and n and n % restart == 0:
+                ops.append(("rst", (n // restart - 1) % 8))
+            for ci, zz in u:
+                ops.append(("bits", (int(zz[0]) >> al) & 1, 1))
+        return ops
+
+    def eob_flush(ops, state):
+        if state["eobrun"] > 0:
+            nbits = state["eobrun"].bit_length() - 1
+            ops.append(("sym", ("ac", 0), nbits << 4))
+            if nbits:
+                ops.append(("bits", state["eobrun"] & ((1 << nbits) - 1), nbits))
+            state["eobrun"] = 0
+        for b in state["be"]:
+            ops.append(("bits", b, 1))
+        state["be"] = []
+
+    def ac_first(units, ss, se, al):
+        ops, state = [], {"eobrun": 0, "be": []}
+        for n, u in enumerate(units):
+            if restart and n and n % restart == 0:
+                eob_flush(ops, state)
+                ops.append(("rst", (n // restart - 1) % 8))
+            (ci, zz), = u
+            r = 0
+            for k in range(ss, se + 1):
+                v = int(zz[k])
+                t = abs(v) >> al                                         # the AC point transform truncates towards zero
+                if t == 0:
+                    r += 1
+                    continue
+                eob_flush(ops, state)
+                while r > 15:
+                    ops.append(("sym", ("ac", 0), 0xF0))
+                    r -= 16
+                size = t.bit_length()
+                ops.append(("sym", ("ac", 0), (r << 4) | size))
+                ops.append(("bits", t if v >= 0 else ((1 << size) - 1) ^ t, size))
+                r = 0
+            if r > 0:
+                state["eobrun"] += 1
+                if state["eobrun"] == 0x7FFF:
+                    eob_flush(ops, state)
+        eob_flush(ops, state)
+        return ops
+
+    def ac_refine(units, ss, se, al):
+        ops, state = [], {"eobrun": 0, "be": []}
+        for n, u in enumerate(units):
+            if restart and n and n % restart == 0:
+                eob_flush(ops, state)
+                ops.append(("rst", (n // restart - 1) % 8))
+            (ci, zz), = u
+            absval = {k: abs(int(zz[k])) >> al for k in range(ss, se + 1)}
+            eob = max([k for k in absval if absval[k] == 1], default=0)   # last coefficient that becomes non-zero in this scan
+            r, br = 0, []
+            for k in range(ss, se + 1):
+                t = absval[k]
+                if t == 0:
+                    r += 1
+                    continue
+                while r > 15 and k <= eob:                               # a run of sixteen zeros that cannot be folded into an end-of-band
+                    eob_flush(ops, state)
+                    ops.append(("sym", ("ac", 0), 0xF0))
+                    r -= 16
+                    ops.extend(("bits", b, 1) for b in br)
+                    br = []
+                if t > 1:                                                # non-zero before this scan: one correction bit
+                    br.append(t & 1)
+                    continue
+                eob_flush(ops, state)
+                ops.append(("sym", ("ac", 0), (r << 4) | 1))
+                ops.append(("bits", 0 if int(zz[k]) < 0 else 1, 1))
+                ops.extend(("bits", b, 1) for b in br)
+                br = []
+                r = 0
+            if r > 0 or br:
+                state["eobrun"] += 1
+                state["be"] += br
+                if state["eobrun"] == 0x7FFF or len(state["be"]) > 900:
+                    eob_flush(ops, state)
+        eob_flush(ops, state)
+        return ops
+
+    all_ids = list(range(n_comp))
+    script = [(all_ids, 0, 0, 0, 1, dc_first(scan_blocks(all_ids), 1))]
+    for ci in all_ids:
+        script.append(([ci], 1, 5, 0, 2, ac_first(scan_blocks([ci]), 1, 5, 2)))
+    for ci in all_ids:
+        script.append(([ci], 6, 63, 0, 2, ac_first(scan_blocks([ci]), 6, 63, 2)))
+    for ci in all_ids:
+        script.append(([ci], 1, 63, 2, 1, ac_refine(scan_blocks([ci]), 1, 63, 1)))
+    script.append((all_ids, 0, 0, 1, 0, dc_refine(scan_blocks(all_ids), 0)))
+    for ci in all_ids:
+        script.append(([ci], 1, 63, 1, 0, ac_refine(scan_blocks([ci]), 1, 63, 0)))
+
+    def seg(marker, body):
+        return bytes([0xFF, marker]) + struct.pack(">H", len(body) + 2) + body
+
+    out = bytearray(b"\xFF\xD8")
+    out += seg(0xE0, b"JFIF\0\x01\x01\x00\x00\x01\x00\x01\x00\x00")
+    ntab = 1 if n_comp == 1 else 2
+    out += seg(0xDB, b"".join(bytes([t]) + bytes(int(v) for v in qtabs[t].reshape(64)[_JPEG_ZIGZAG]) for t in range(ntab)))
+    ids = [ord(c) for c in "RGB"] if rgb_ids else [1, 2, 3]
+    sof = struct.pack(">BHHB", 8, H, W, n_comp)
+    for ci, c in enumerate(comps):
+        sof += bytes([ids[ci], (c["h"] << 4) | c["v"], c["tq"]])
+    out += seg(0xC2, sof)
+    if restart:
+        out += seg(0xDD, struct.pack(">H", restart))
+    for comp_ids, ss, se, ah, al, ops in script:
+        freq = {}
+        for op in ops:
+            if op[0] == "sym":
+                f = freq.setdefault(op[1], {})
+                f[op[2]] = f.get(op[2], 0) + 1
+        tables = {key: _jpeg_huffman_table(f) for key, f in freq.items()}
+        if tables:
+            dht = b""
+            for (kind, t), (counts, order, _) in sorted(tables.items()):
+                dht += bytes([(0x10 if kind == "ac" else 0x00) | t]) + bytes(counts) + bytes(order)
+            out += seg(0xC4, dht)
+        sos = bytes([len(comp_ids)])
+        for ci in comp_ids:
+            sos += bytes([ids[ci], (comps[ci]["td"] << 4) | 0])         # DC table by component, AC table 0 (redefined per scan)
+        out += seg(0xDA, sos + bytes([ss, se, (ah << 4) | al]))
+        w = _JpegBits()
+        for op in ops:
+            if op[0] == "sym":
+                code, length = tables[op[1]][2][op[2]]
+                w.put(code, length)
+            elif op[0] == "bits":
+                w.put(op[1], op[2])
+            else:
+                w.marker(0xD0 + op[1])
+        w.pad()
+        out += w.data
+    out += b"\xFF\xD9"
+    with open(path, "wb") as f:
+        f.write(bytes(out))
+
+
 def write_jpeg(path: str, img: np.ndarray, sampling: Tuple[int, int] = (1, 1), restart: int = 0, interleaved: bool = True,
-               rgb_ids: bool = False, q_step: Tuple[int, int] = (2, 3)) -> None:
-    """Baseline (SOF0) JPEG with its own optimal Huffman tables.  img: [h, w] grey or [h, w, 3] RGB.  `sampling` = luma
+               rgb_ids: bool = False, q_step: Tuple[int, int] = (2, 3), progressive: bool = False) -> None:
+    """Baseline (SOF0) or, with `progressive`, progressive (SOF2: spectral selection + successive approximation, ten
+    scans for a colour image) JPEG with its own optimal Huffman tables.  img: [h, w] grey or [h, w, 3] RGB.  `sampling` = luma
     (h, v) factors against 1x1 chroma: (1,1) 4:4:4, (2,1) 4:2:2, (1,2) 4:4:0, (2,2) 4:2:0, (4,1) 4:1:1.  `restart`:
     restart interval in MCUs (0 = none).  `interleaved` False writes one scan per component.  `rgb_ids`: store R, G, B
     themselves under the component ids 'R', 'G', 'B' (no colour transform on either side)."""
@@ -408,6 +604,9 @@ def write_jpeg(path: str, img: np.ndarray, sampling: Tuple[int, int] = (1, 1), r
                     out.append(("ac", comps[ci]["td"], 0x00, 0, 0))
         return out
 
+    if progressive:
+        _write_progressive_jpeg(path, H, W, comps, qtabs, mcus_x, mcus_y, restart, rgb_ids, scan_blocks)
+        return
     scans = [list(range(len(comps)))] if (interleaved or len(comps) == 1) else [[ci] for ci in range(len(comps))]
     scan_syms = [symbols_of(scan_blocks(ids)) for ids in scans]
     freq = {("dc", 0): {}, ("dc", 1): {}, ("ac", 0): {}, ("ac", 1): {}}
@@ -500,6 +699,9 @@ def write_texture(path: str, img: np.ndarray, encoding: str) -> None:
         "jpg420_rst": lambda: write_jpeg(path, img, sampling=(2, 2), restart=3),
         "jpg_scans": lambda: write_jpeg(path, img, sampling=(2, 2), interleaved=False, restart=5),
         "jpg_rgb": lambda: write_jpeg(path, img, rgb_ids=True),
+        "jpg_prog": lambda: write_jpeg(path, img, progressive=True),                      # progressive, 4:4:4 (or grey)
+        "jpg_prog420": lambda: write_jpeg(path, img, sampling=(2, 2), progressive=True),
+        "jpg_prog422_rst": lambda: write_jpeg(path, img, sampling=(2, 1), progressive=True, restart=4),
     }
     enc[encoding]()
 
@@ -885,10 +1087,10 @@ def textured_gallery(sphere_segments: int = 20, sphere_rings: int = 10) -> ObjSc
 
 
 def jpeg_gallery() -> ObjScene:
-    """JPEG textures through the loader and the texture path: eight panels in two rows over a floor, one per JPEG layout
-    write_jpeg produces - grey, 4:4:4, 4:2:2, 4:4:0, 4:2:0, 4:1:1, 4:2:0 with a restart interval, one scan per component
-    with a restart interval, RGB component ids - with sizes that are not multiples of the MCU, plus grey JPEGs as bump
-    and alpha maps.  The decoded bytes depend on the decoder's inverse DCT, upsampling filter and colour arithmetic,
+    """JPEG textures through the loader and the texture path: thirteen panels in two rows over a floor, one per JPEG layout
+    write_jpeg produces - baseline grey, 4:4:4, 4:2:2, 4:4:0, 4:2:0, 4:1:1, 4:2:0 with a restart interval, one scan per
+    component with a restart interval, RGB component ids; progressive 4:4:4, 4:2:0, 4:2:2 with a restart interval, grey -
+    with sizes that are not multiples of the MCU, plus grey JPEGs as bump and alpha maps.  The decoded bytes depend on the decoder's inverse DCT, upsampling filter and colour arithmetic,
     which is what the fixture pins against the reference's decoder."""
     rng = np.random.default_rng(20241004)
     pos, nrm, uv = [], [], []
@@ -912,7 +1114,9 @@ def jpeg_gallery() -> ObjScene:
 
     layouts = [("grey", "jpg", (23, 41)), ("c444", "jpg", (30, 37)), ("c422", "jpg422", (33, 47)), ("c440", "jpg440", (45, 26)),
                ("c420", "jpg420", (50, 61)), ("c411", "jpg411", (19, 70)), ("c420r", "jpg420_rst", (64, 48)),
-               ("scans", "jpg_scans", (35, 52)), ("rgbid", "jpg_rgb", (17, 24))]
+               ("scans", "jpg_scans", (35, 52)), ("rgbid", "jpg_rgb", (17, 24)),
+               ("prog", "jpg_prog", (29, 43)), ("prog420", "jpg_prog420", (54, 39)), ("prog422r", "jpg_prog422_rst", (31, 58)),
+               ("proggrey", "jpg_prog", (37, 21))]
     textures = {}
     materials = [MtlMaterial("floor", Ns=20.0, Ka=(0.6, 0.6, 0.6), Kd=(0.9, 0.9, 0.9), Ks=(0.2, 0.2, 0.2), map_Kd="floor_kd.jpg",
                              map_bump="floor_bump.jpg")]
@@ -920,13 +1124,13 @@ def jpeg_gallery() -> ObjScene:
     yy, xx = np.mgrid[0:40, 0:56]
     textures["floor_bump.jpg"] = ((127.5 + 120 * np.sin(xx * 0.7) * np.cos(yy * 0.5)).astype(np.uint8), "jpg")       # grey height map
     for k, (name, enc, (h, w)) in enumerate(layouts):
-        col, row = k % 5, k // 5
-        x0, y0 = -3.6 + col * 1.5, 0.15 + row * 1.55
+        col, row = k % 7, k // 7
+        x0, y0 = -4.15 + col * 1.2, 0.15 + row * 1.3
         z = -1.5 - 0.25 * row
-        add("panel_" + name, _quad(pos, nrm, uv, [(x0, y0, z), (x0 + 1.3, y0, z), (x0 + 1.3, y0 + 1.3, z), (x0, y0 + 1.3, z)], (0, 0, 1),
+        add("panel_" + name, _quad(pos, nrm, uv, [(x0, y0, z), (x0 + 1.05, y0, z), (x0 + 1.05, y0 + 1.05, z), (x0, y0 + 1.05, z)], (0, 0, 1),
                                    [(0, 0), (1, 0), (1, 1), (0, 1)]), name)
         img = picture(h, w, k)
-        textures[name + ".jpg"] = (img[:, :, 1] if name == "grey" else img, enc)
+        textures[name + ".jpg"] = (img[:, :, 1] if name in ("grey", "proggrey") else img, enc)
         kw = {}
         if name == "c444":                                              # a grey JPEG as alpha map: holes in the panel
             a = (128 + 127 * np.sin(xx[:32, :32] * 0.9) * np.sin(yy[:32, :32] * 0.8))
@@ -966,7 +1170,7 @@ SCENES = {
     "terrain_192": lambda: terrain(192, 8, size=192.0),       # 73,728 tris in 64 groups
     "many_materials": lambda: many_materials(),               # 1,282 tris, 42 materials (LDS table fallback), translucent clusters
     "textured_gallery": lambda: textured_gallery(),           # 192 tris, 7 materials, 14 texture files (row N1)
-    "jpeg_gallery": lambda: jpeg_gallery(),                   # 20 tris, 10 materials, 12 baseline JPEG files of every sampling layout
+    "jpeg_gallery": lambda: jpeg_gallery(),                   # 28 tris, 14 materials, 16 JPEG files: baseline and progressive, every sampling layout
 }
 
 CONFIGS: Dict[str, RenderConfig] = {

@@ -130,8 +130,9 @@ def test_texture_decoders_and_tangents_bit_identical_to_reference():
 
 
 def test_jpeg_decoder_bit_identical_to_reference():
-    """The 12 baseline JPEG files of the jpeg_gallery scene - grey, 4:4:4, 4:2:2, 4:4:0, 4:2:0, 4:1:1, restart intervals,
-    one scan per component, RGB component ids, sizes that are not multiples of the MCU - decode to the bytes the
+    """The 16 JPEG files of the jpeg_gallery scene - baseline grey, 4:4:4, 4:2:2, 4:4:0, 4:2:0, 4:1:1, restart intervals,
+    one scan per component, RGB component ids; progressive (spectral selection + successive approximation, ten scans)
+    4:4:4, 4:2:0, 4:2:2 with restarts, grey; sizes that are not multiples of the MCU - decode to the bytes the
     reference's decoder produced (its inverse DCT, chroma upsampling filter and YCbCr arithmetic), grey files to 1
     channel, colour files to 3; the bump map converts to the same normal map."""
     g = load_golden("jpeg_gallery_128x96")
@@ -140,7 +141,7 @@ def test_jpeg_decoder_bit_identical_to_reference():
     assert np.array_equal(a["group_texture_dims"], g["group_texture_dims"])
     assert np.array_equal(_sums(a["group_texture_bytes"]), g["sum_group_texture_bytes"])
     dims = a["group_texture_dims"].reshape(-1, 5, 3)
-    assert (dims[:, :, 0] > 0).sum() == 12 and set(np.unique(dims[:, :, 2])) == {0, 1, 3}
+    assert (dims[:, :, 0] > 0).sum() == 16 and set(np.unique(dims[:, :, 2])) == {0, 1, 3}
 
 
 def test_jpeg_files_decode_close_to_what_was_encoded(tmp_path):
@@ -150,7 +151,7 @@ def test_jpeg_files_decode_close_to_what_was_encoded(tmp_path):
     lib = capi.host_lib()
     yy, xx = np.mgrid[0:45, 0:70]
     img = np.stack([128 + 100 * np.sin(xx * 0.21) * np.cos(yy * 0.17), 128 + 90 * np.cos(yy * 0.3), 40 + 2.5 * xx], axis=2).clip(0, 255).astype(np.uint8)
-    for enc in ("jpg", "jpg422", "jpg440", "jpg420", "jpg411", "jpg420_rst", "jpg_scans", "jpg_rgb"):
+    for enc in ("jpg", "jpg422", "jpg440", "jpg420", "jpg411", "jpg420_rst", "jpg_scans", "jpg_rgb", "jpg_prog", "jpg_prog420", "jpg_prog422_rst"):
         path = str(tmp_path / ("t_%s.jpg" % enc))
         scenes.write_texture(path, img, enc)
         got = _load_texture(lib, path)
@@ -158,10 +159,11 @@ def test_jpeg_files_decode_close_to_what_was_encoded(tmp_path):
         err = np.abs(got.astype(np.int32) - img.astype(np.int32))
         assert err.mean() < 6.0 and np.percentile(err, 99) < 40, (enc, err.mean(), err.max())
     path = str(tmp_path / "grey.jpg")
-    scenes.write_texture(path, img[:, :, 0], "jpg")
-    got = _load_texture(lib, path)
-    assert got is not None and got.shape == (45, 70, 1)
-    assert np.abs(got[:, :, 0].astype(np.int32) - img[:, :, 0].astype(np.int32)).mean() < 4.0
+    for enc in ("jpg", "jpg_prog"):
+        scenes.write_texture(path, img[:, :, 0], enc)
+        got = _load_texture(lib, path)
+        assert got is not None and got.shape == (45, 70, 1), enc
+        assert np.abs(got[:, :, 0].astype(np.int32) - img[:, :, 0].astype(np.int32)).mean() < 4.0, enc
 
 
 def test_texture_writers_round_trip_through_the_loader(tmp_path):
@@ -190,16 +192,16 @@ def test_texture_writers_round_trip_through_the_loader(tmp_path):
 
 def test_unsupported_images_leave_the_slot_empty_like_a_decoder_failure(tmp_path):
     """obj_parser.cpp:201-204: a file the decoder rejects prints a message and yields no texture.  Same here for
-    progressive JPEG, truncated files and missing files - no crash, and the material simply has no map."""
+    arithmetic-coded JPEG, truncated files and missing files - no crash, and the material simply has no map."""
     lib = capi.host_lib()
     bad = tmp_path / "x.jpg"
     bad.write_bytes(b"\xff\xd8\xff\xe0" + b"\0" * 64)
     assert _load_texture(lib, str(bad)) is None
     from par_raytracer_amd import scenes as _scenes
-    prog = tmp_path / "progressive.jpg"
+    prog = tmp_path / "arithmetic.jpg"
     _scenes.write_texture(str(prog), np.full((16, 16, 3), 90, dtype=np.uint8), "jpg")
     raw = bytearray(prog.read_bytes())
-    raw[raw.index(b"\xff\xc0") + 1] = 0xC2                    # SOF0 -> SOF2: a progressive frame header
+    raw[raw.index(b"\xff\xc0") + 1] = 0xC9                    # SOF0 -> SOF9: arithmetic coding, which the reference's decoder rejects too
     prog.write_bytes(bytes(raw))
     assert _load_texture(lib, str(prog)) is None
     cut = tmp_path / "cut.jpg"

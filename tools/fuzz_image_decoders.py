@@ -14,7 +14,7 @@ img3 = rng.integers(0, 256, size=(19, 23, 3), dtype=np.uint8); img1 = img3[:, :,
 seeds = []
 for enc, im in (("png", img3), ("png", img1), ("png", img4), ("png16", img3), ("png_palette", img3 // 64 * 64), ("tga", img3), ("tga_rle", img4), ("tga_rle", img1), ("bmp", img3), ("pnm", img1), ("pnm", img3)):
     p = os.path.join(d, "s%d.img" % len(seeds)); scenes.write_texture(p, im, enc); seeds.append(open(p, "rb").read())
-for enc, im in (("jpg", img1), ("jpg", img3), ("jpg422", img3), ("jpg440", img3), ("jpg420", img3), ("jpg411", img3), ("jpg420_rst", img3), ("jpg_scans", img3), ("jpg_rgb", img3)):
+for enc, im in (("jpg", img1), ("jpg", img3), ("jpg422", img3), ("jpg440", img3), ("jpg420", img3), ("jpg411", img3), ("jpg420_rst", img3), ("jpg_scans", img3), ("jpg_rgb", img3), ("jpg_prog", img3), ("jpg_prog", img1), ("jpg_prog420", img3), ("jpg_prog422_rst", img3)):
     p = os.path.join(d, "s%d.img" % len(seeds)); scenes.write_texture(p, im, enc); seeds.append(open(p, "rb").read())
 n_ok = n_fail = 0
 for it in range(int(os.environ.get("PRT_FUZZ_ITERATIONS", "12000"))):
