@@ -6,13 +6,15 @@
 // path indexes the bytes directly (texture.cpp:17-51):
 //   * rows top to bottom, pixels left to right, `channels` interleaved bytes per pixel, channels = what the file
 //     stores (1 grey, 2 grey+alpha, 3 RGB, 4 RGBA); palettes are expanded to RGB (RGBA with a tRNS chunk);
-//   * PNG  8-bit and 16-bit (high byte kept) samples, all five scanline filters, non-interlaced;
+//   * PNG  1 / 2 / 4 / 8 / 16-bit samples (below 8 bits scaled to 0..255, 16-bit: high byte kept), all five scanline
+//          filters, Adam7 interlacing, palettes with tRNS, colour-key tRNS on grey / RGB (with the reference decoder's
+//          channel-count quirk, see DecodePng);
 //   * TGA  types 2 / 3 (raw) and 10 / 11 (run-length), 8 / 24 / 32 bits, BGR(A) -> RGB(A), bottom-up files
 //          flipped to top-down;
 //   * BMP  24-bit uncompressed, BGR -> RGB, bottom-up flipped;
 //   * PNM  binary P5 (grey) / P6 (RGB), maxval <= 255.
 //   * JPEG baseline and progressive (image_jpeg.cpp): grey -> 1 channel, colour -> 3, every sampling layout, restart intervals.
-// Anything else (arithmetic-coded JPEG, interlaced PNG, 1/2/4-bit PNG, colour-mapped TGA ...) is reported and the texture slot
+// Anything else (arithmetic-coded JPEG, colour-mapped TGA, palette / RLE BMP ...) is reported and the texture slot
 // stays empty, which is how the reference treats a file its decoder rejects (obj_parser.cpp:201-204).
 // tests/test_host_side.py compares the decoded bytes with the reference's on generated files of every kind.
 #include <zlib.h>
@@ -103,8 +105,7 @@ bool DecodePng(const std::vector<u8> & d, Image * out) {
     }
     if (!have_header || !w || !h) return Fail("PNG without a header");
     if ((unsigned long long)w * h > (1ull << 28)) return Fail("PNG larger than 2^28 pixels");
-    if (interlace) return Fail("interlaced PNG is not supported");
-    if (depth != 8 && depth != 16) return Fail("PNG bit depth other than 8 / 16 is not supported");
+    if (interlace > 1) return Fail("bad PNG interlace method");
     u32 file_ch = 0;
     switch (ctype) {
         case 0: file_ch = 1; break;
@@ -114,60 +115,116 @@ bool DecodePng(const std::vector<u8> & d, Image * out) {
         case 6: file_ch = 4; break;
         default: return Fail("bad PNG colour type");
     }
-    if (ctype == 3 && depth != 8) return Fail("PNG palette index depth other than 8 is not supported");
-    if (ctype != 3 && !trns.empty()) return Fail("PNG colour-key transparency is not supported");
-    const size_t bps = depth / 8;                              // bytes per sample
-    const size_t bpp = bps * file_ch;                          // bytes per pixel in the filtered stream
-    const size_t stride = (size_t)w * bpp;
+    const bool low = depth == 1 || depth == 2 || depth == 4;
+    if (!(depth == 8 || (depth == 16 && ctype != 3) || (low && (ctype == 0 || ctype == 3)))) return Fail("bad PNG bit depth for the colour type");
+    const bool colour_key = ctype != 3 && !trns.empty();         // tRNS on a grey / RGB image names ONE transparent colour
+    if (colour_key && (ctype == 4 || ctype == 6)) return Fail("PNG tRNS chunk on an image with alpha");
+    if (colour_key && trns.size() != 2u * file_ch) return Fail("bad PNG tRNS length");
+    const size_t bps = depth == 16 ? 2 : 1;                    // bytes per sample once unpacked
+    const size_t upp = bps * file_ch;                          // unpacked bytes per pixel
+    const size_t bits = (size_t)depth * file_ch;               // bits per pixel in the filtered stream
+    const size_t fbpp = bits >= 8 ? bits / 8 : 1;              // "bytes per pixel" of the scanline filters
+    // the seven Adam7 passes (x0, y0, dx, dy), or the whole image as one pass
+    static const u32 adam7[7][4] = { { 0, 0, 8, 8 }, { 4, 0, 8, 8 }, { 0, 4, 4, 8 }, { 2, 0, 4, 4 }, { 0, 2, 2, 4 }, { 1, 0, 2, 2 }, { 0, 1, 1, 2 } };
+    static const u32 whole[1][4] = { { 0, 0, 1, 1 } };
+    const u32 (*passes)[4] = interlace ? adam7 : whole;
+    const int n_pass = interlace ? 7 : 1;
+    size_t raw_size = 0;
+    for (int k = 0; k < n_pass; ++k) {
+        const u32 pw = (w - passes[k][0] + passes[k][2] - 1) / passes[k][2], ph = (h - passes[k][1] + passes[k][3] - 1) / passes[k][3];
+        if (w > passes[k][0] && h > passes[k][1] && pw && ph) raw_size += (((size_t)pw * bits + 7) / 8 + 1) * (size_t)ph;
+    }
     // deflate expands at most ~1032:1: a header that promises more than the data can hold is corrupt (and would
     // otherwise make us allocate whatever it says)
-    if ((stride + 1) * (size_t)h > idat.size() * 1032 + 1024) return Fail("PNG data too short for the image size");
-    std::vector<u8> raw((stride + 1) * (size_t)h);
+    if (raw_size > idat.size() * 1032 + 1024) return Fail("PNG data too short for the image size");
+    std::vector<u8> raw(raw_size);
     uLongf raw_len = (uLongf)raw.size();
     int zr = uncompress(raw.data(), &raw_len, idat.data(), (uLong)idat.size());
     if (zr != Z_OK || raw_len != raw.size()) return Fail("PNG data does not inflate to the image size");
-    std::vector<u8> img(stride * (size_t)h);
-    for (u32 y = 0; y < h; ++y) {
-        const u8 * src = &raw[(stride + 1) * (size_t)y];
-        u8 * dst = &img[stride * (size_t)y];
-        const u8 * up = y ? dst - stride : NULL;
-        const u8 filter = src[0];
-        ++src;
-        for (size_t i = 0; i < stride; ++i) {
-            int a = i >= bpp ? dst[i - bpp] : 0;
-            int b = up ? up[i] : 0;
-            int c = (up && i >= bpp) ? up[i - bpp] : 0;
-            int v = src[i];
-            switch (filter) {
-                case 0: break;
-                case 1: v += a; break;
-                case 2: v += b; break;
-                case 3: v += (a + b) >> 1; break;
-                case 4: v += Paeth(a, b, c); break;
-                default: return Fail("bad PNG filter");
+    std::vector<u8> img(upp * (size_t)w * h);                  // unpacked: one byte per sample (two for 16-bit), raw values
+    std::vector<u8> line, prev;
+    size_t rp = 0;
+    for (int k = 0; k < n_pass; ++k) {
+        if (!(w > passes[k][0] && h > passes[k][1])) continue;
+        const u32 pw = (w - passes[k][0] + passes[k][2] - 1) / passes[k][2], ph = (h - passes[k][1] + passes[k][3] - 1) / passes[k][3];
+        if (!pw || !ph) continue;
+        const size_t stride = ((size_t)pw * bits + 7) / 8;
+        line.assign(stride, 0);
+        prev.assign(stride, 0);
+        for (u32 y = 0; y < ph; ++y) {
+            const u8 filter = raw[rp++];
+            const u8 * src = &raw[rp];
+            rp += stride;
+            for (size_t i = 0; i < stride; ++i) {
+                int fa = i >= fbpp ? line[i - fbpp] : 0;
+                int fb = y ? prev[i] : 0;
+                int fc = (y && i >= fbpp) ? prev[i - fbpp] : 0;
+                int v = src[i];
+                switch (filter) {
+                    case 0: break;
+                    case 1: v += fa; break;
+                    case 2: v += fb; break;
+                    case 3: v += (fa + fb) >> 1; break;
+                    case 4: v += Paeth(fa, fb, fc); break;
+                    default: return Fail("bad PNG filter");
+                }
+                line[i] = (u8)v;
             }
-            dst[i] = (u8)v;
+            // unpack the scanline into its pixels of the full image
+            const size_t oy = (size_t)passes[k][1] + (size_t)y * passes[k][3];
+            for (u32 x = 0; x < pw; ++x) {
+                u8 * o = &img[((size_t)oy * w + passes[k][0] + (size_t)x * passes[k][2]) * upp];
+                if (low) {
+                    const size_t bit = (size_t)x * depth;
+                    o[0] = (u8)((line[bit >> 3] >> (8 - depth - (bit & 7))) & ((1u << depth) - 1u));
+                } else {
+                    memcpy(o, &line[(size_t)x * upp], upp);
+                }
+            }
+            prev.swap(line);
         }
     }
     out->w = w;
     out->h = h;
+    const size_t n_px = (size_t)w * h;
     if (ctype == 3) {
         const bool with_alpha = !trns.empty();
         out->channels = with_alpha ? 4 : 3;
-        out->px.resize((size_t)w * h * out->channels);
-        for (size_t i = 0; i < (size_t)w * h; ++i) {
+        out->px.resize(n_px * out->channels);
+        for (size_t i = 0; i < n_px; ++i) {
             u32 idx = img[i];
             u8 * o = &out->px[i * out->channels];
             for (int k = 0; k < 3; ++k) o[k] = (size_t)idx * 3 + k < palette.size() ? palette[(size_t)idx * 3 + k] : 0;
             if (with_alpha) o[3] = idx < trns.size() ? trns[idx] : 255;
         }
     } else {
-        out->channels = file_ch;
-        out->px.resize((size_t)w * h * file_ch);
-        if (bps == 1) {
-            out->px = img;
-        } else {
-            for (size_t i = 0; i < out->px.size(); ++i) out->px[i] = img[2 * i];      // 16 bit: the high byte
+        // grey / RGB samples below 8 bits are scaled to 0..255 (x 255, x 85, x 17); 16-bit samples keep their high byte; a
+        // colour key (compared at the file's own precision) adds an alpha channel that is 0 on the key colour, 255 elsewhere
+        const u32 scale = depth == 1 ? 255u : depth == 2 ? 85u : depth == 4 ? 17u : 1u;
+        out->channels = file_ch + (colour_key ? 1 : 0);
+        out->px.resize(n_px * out->channels);
+        for (size_t i = 0; i < n_px; ++i) {
+            const u8 * in = &img[i * upp];
+            u8 * o = &out->px[i * out->channels];
+            bool is_key = colour_key;
+            for (u32 k = 0; k < file_ch; ++k) {
+                if (bps == 2) {
+                    o[k] = in[2 * k];
+                    if (colour_key && !(in[2 * k] == trns[2 * k] && in[2 * k + 1] == trns[2 * k + 1])) is_key = false;
+                } else {
+                    o[k] = (u8)(in[k] * scale);
+                    if (colour_key && o[k] != (u8)(trns[2 * k + 1] * scale)) is_key = false;
+                }
+            }
+            if (colour_key) o[file_ch] = is_key ? 0 : 255;
+        }
+        if (colour_key) {
+            // The reference's decoder (stb_image 2.14, stbi__do_png) hands back this (channels + 1)-interleaved buffer but
+            // reports the FILE's channel count, and the reference indexes texels with what is reported (texture.cpp:17-51):
+            // it sees a w x h x channels texture made of the first w * h * channels bytes.  Same here - the picture is
+            // scrambled, but it is the reference's picture.
+            out->channels = file_ch;
+            out->px.resize(n_px * file_ch);
         }
     }
     return true;

@@ -122,9 +122,9 @@ def _png_chunk(tag: bytes, body: bytes) -> bytes:
     return struct.pack(">I", len(body)) + tag + body + struct.pack(">I", zlib.crc32(tag + body) & 0xFFFFFFFF)
 
 
-def _png_filter_rows(raw: np.ndarray, bpp: int) -> bytes:
+def _png_filter_rows(raw: np.ndarray, bpp: int, cycle=(0, 1, 2, 3, 4)) -> bytes:
     """raw: [h, stride] uint8 scanlines.  Rows cycle through the five PNG filter types so a decoder has to
-    implement all of them (None, Sub, Up, Average, Paeth)."""
+    implement all of them (None, Sub, Up, Average, Paeth), or through `cycle`."""
     h, stride = raw.shape
     out = bytearray()
     prev = np.zeros(stride, dtype=np.int32)
@@ -133,7 +133,7 @@ def _png_filter_rows(raw: np.ndarray, bpp: int) -> bytes:
         a = np.concatenate([np.zeros(bpp, dtype=np.int32), cur[:-bpp]]) if stride > bpp else np.zeros(stride, dtype=np.int32)
         b = prev
         c = np.concatenate([np.zeros(bpp, dtype=np.int32), prev[:-bpp]]) if stride > bpp else np.zeros(stride, dtype=np.int32)
-        ft = y % 5
+        ft = cycle[y % len(cycle)]
         if ft == 0:
             pred = np.zeros(stride, dtype=np.int32)
         elif ft == 1:
@@ -152,9 +152,25 @@ def _png_filter_rows(raw: np.ndarray, bpp: int) -> bytes:
     return bytes(out)
 
 
-def write_png(path: str, img: np.ndarray, sixteen_bit: bool = False, palette: bool = False, palette_alpha: bool = False) -> None:
+def _png_pack_bits(rows: np.ndarray, bits: int) -> np.ndarray:
+    """[h, n] sample values below 2^bits -> [h, ceil(n * bits / 8)] bytes, first sample in the high bits."""
+    h, n = rows.shape
+    per = 8 // bits
+    padded = np.zeros((h, (n + per - 1) // per * per), dtype=np.uint8)
+    padded[:, :n] = rows
+    out = np.zeros((h, padded.shape[1] // per), dtype=np.uint8)
+    for k in range(per):
+        out |= (padded[:, k::per] << (8 - bits * (k + 1))).astype(np.uint8)
+    return out
+
+
+def write_png(path: str, img: np.ndarray, sixteen_bit: bool = False, palette: bool = False, palette_alpha: bool = False,
+              interlace: bool = False, bits: int = 8, key=None, filters=None) -> None:
     """8-bit grey / grey+alpha / RGB / RGBA PNG; `sixteen_bit` stores every sample as (v, 255 - v) big endian
-    (a decoder keeping the high byte recovers v); `palette` quantises an RGB(A) image to <= 256 colours."""
+    (a decoder keeping the high byte recovers v); `palette` quantises an RGB(A) image to <= 256 colours.
+    `bits` 1 / 2 / 4: a grey image whose values are already below 2^bits, or palette indices packed that tightly.
+    `interlace`: Adam7, each of the seven passes filtered on its own.  `key`: a tRNS chunk naming one transparent
+    grey level / RGB colour (in the file's own sample values)."""
     import struct, zlib
     a = np.asarray(img, dtype=np.uint8)
     if a.ndim == 2:
@@ -164,9 +180,9 @@ def write_png(path: str, img: np.ndarray, sixteen_bit: bool = False, palette: bo
     if palette:
         flat = a.reshape(-1, c)
         colours, index = np.unique(flat, axis=0, return_inverse=True)
-        assert len(colours) <= 256, "too many colours for a palette"
-        ctype, depth, bpp = 3, 8, 1
-        raw = index.reshape(h, w).astype(np.uint8)
+        assert len(colours) <= (1 << bits), "too many colours for the palette"
+        ctype, depth = 3, bits
+        samples = index.reshape(h, w, 1).astype(np.uint8)
         chunks += _png_chunk(b"PLTE", colours[:, :3].astype(np.uint8).tobytes())
         if palette_alpha:
             assert c == 4
@@ -174,17 +190,42 @@ def write_png(path: str, img: np.ndarray, sixteen_bit: bool = False, palette: bo
     else:
         ctype = {1: 0, 2: 4, 3: 2, 4: 6}[c]
         if sixteen_bit:
-            depth, bpp = 16, 2 * c
-            raw = np.stack([a, 255 - a], axis=-1).reshape(h, w * c * 2)
+            depth = 16
+            samples = np.stack([a, 255 - a], axis=-1).reshape(h, w, c * 2)
         else:
-            depth, bpp = 8, c
-            raw = a.reshape(h, w * c)
-    data = zlib.compress(_png_filter_rows(np.ascontiguousarray(raw), bpp), 6)
+            depth = bits
+            assert bits == 8 or c == 1
+            samples = a
+        if key is not None:
+            kv = [int(v) for v in np.atleast_1d(key)]
+            assert len(kv) == c and c in (1, 3)
+            chunks += _png_chunk(b"tRNS", b"".join(struct.pack(">H", (v << 8 | (255 - v)) if sixteen_bit else v) for v in kv))
+    bpp = max(1, samples.shape[2] * (depth if depth < 8 else 8) // 8)     # the filters' "bytes per pixel"
+
+    def filtered(sub):                                                  # sub: [ph, pw, bytes or samples per pixel]
+        ph, pw = sub.shape[:2]
+        rows = sub.reshape(ph, -1)
+        if depth < 8:
+            rows = _png_pack_bits(rows, depth)
+        # Sub-byte samples: filters None and Sub only, unless asked otherwise.  The reference's decoder (stb_image 2.14) reads
+        # the previous row of such images at the wrong offset - partly memory it never wrote - so files that use Up /
+        # Average / Paeth there have no reference answer to compare with (real encoders default to None for them).
+        return _png_filter_rows(np.ascontiguousarray(rows), bpp, filters if filters else ((0, 1) if depth < 8 else (0, 1, 2, 3, 4)))
+
+    if interlace:
+        body = b""
+        for x0, y0, dx, dy in ((0, 0, 8, 8), (4, 0, 8, 8), (0, 4, 4, 8), (2, 0, 4, 4), (0, 2, 2, 4), (1, 0, 2, 2), (0, 1, 1, 2)):
+            sub = samples[y0::dy, x0::dx]
+            if sub.shape[0] and sub.shape[1]:
+                body += filtered(sub)
+    else:
+        body = filtered(samples)
+    data = zlib.compress(body, 6)
     # two IDAT chunks: a decoder must concatenate them
     cut = len(data) // 2
     with open(path, "wb") as f:
         f.write(b"\x89PNG\r\n\x1a\n")
-        f.write(_png_chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, depth, ctype, 0, 0, 0)))
+        f.write(_png_chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, depth, ctype, 0, 0, 1 if interlace else 0)))
         f.write(chunks)
         f.write(_png_chunk(b"IDAT", data[:cut]))
         f.write(_png_chunk(b"IDAT", data[cut:]))
@@ -686,6 +727,17 @@ def write_texture(path: str, img: np.ndarray, encoding: str) -> None:
         "png16": lambda: write_png(path, img, sixteen_bit=True),
         "png_palette": lambda: write_png(path, img, palette=True),
         "png_palette_alpha": lambda: write_png(path, img, palette=True, palette_alpha=True),
+        "png_i": lambda: write_png(path, img, interlace=True),                                  # Adam7
+        "png16_i": lambda: write_png(path, img, sixteen_bit=True, interlace=True),
+        "png_g1": lambda: write_png(path, img, bits=1),                                         # grey, values 0..1
+        "png_g2": lambda: write_png(path, img, bits=2),
+        "png_g4_i": lambda: write_png(path, img, bits=4, interlace=True),
+        "png_p4": lambda: write_png(path, img, palette=True, bits=4),                           # <= 16 colours
+        "png_p1_alpha_i": lambda: write_png(path, img, palette=True, palette_alpha=True, bits=1, interlace=True),
+        "png_key": lambda: write_png(path, img, key=np.asarray(img).reshape(-1, 1 if np.asarray(img).ndim == 2 else np.asarray(img).shape[2])[0]),
+        "png16_key_i": lambda: write_png(path, img, sixteen_bit=True, interlace=True,
+                                         key=np.asarray(img).reshape(-1, 1 if np.asarray(img).ndim == 2 else np.asarray(img).shape[2])[0]),
+        "png_g2_key": lambda: write_png(path, img, bits=2, key=[int(np.asarray(img).reshape(-1)[0])]),
         "tga": lambda: write_tga(path, img),
         "tga_top": lambda: write_tga(path, img, top_down=True),
         "tga_rle": lambda: write_tga(path, img, rle=True),
@@ -1146,6 +1198,63 @@ def jpeg_gallery() -> ObjScene:
         camera_position=(0.0, 1.7, 4.4), camera_facing=(0.0, -0.12, -1.0), fov=62.0)
 
 
+def png_gallery() -> ObjScene:
+    """The PNG corners of the loader through the texture path: a floor and twelve panels whose diffuse maps are Adam7
+    interlaced (8- and 16-bit), 1 / 2 / 4-bit grey, 4-bit and 1-bit palettes (the latter with tRNS, interlaced), and grey /
+    RGB images with a colour-key tRNS chunk (which adds an alpha channel: 2 and 4 channels), at sizes that leave some
+    interlace passes empty."""
+    rng = np.random.default_rng(20241005)
+    pos, nrm, uv = [], [], []
+    groups = []
+
+    def add(name, tris, material):
+        groups.append(ObjGroup(name, _faces_same_index(np.array(tris)), material))
+
+    add("floor", _quad(pos, nrm, uv, [(-4, 0, 3), (4, 0, 3), (4, 0, -3), (-4, 0, -3)], (0, 1, 0),
+                       [(0, 0), (2, 0), (2, 1.5), (0, 1.5)]), "floor")
+
+    def blobs(h, w, levels):
+        yy, xx = np.mgrid[0:h, 0:w]
+        v = 0.5 + 0.5 * np.sin(xx * 0.9 + 0.3) * np.cos(yy * 0.7) + rng.uniform(-0.15, 0.15, size=(h, w))
+        return np.clip((v * levels).astype(np.int64), 0, levels - 1).astype(np.uint8)
+
+    def colour(h, w):
+        yy, xx = np.mgrid[0:h, 0:w]
+        img = np.stack([40 + 200 * ((xx // 3 + yy // 2) % 2), 128 + 100 * np.sin(yy * 0.8), 30 + 7 * xx], axis=2) + rng.integers(-20, 21, size=(h, w, 3))
+        return img.clip(0, 255).astype(np.uint8)
+
+    def keyed(img):                                                     # make the key colour (pixel 0) occur in patches
+        out = img.copy()
+        out[::3, ::2] = img.reshape(-1, img.shape[-1] if img.ndim == 3 else 1)[0] if img.ndim == 3 else img.reshape(-1)[0]
+        return out
+
+    pal4 = (blobs(21, 30, 4)[:, :, None] * np.array([60, 30, 80], dtype=np.uint8) + np.array([10, 90, 0], dtype=np.uint8)).astype(np.uint8)
+    pal1 = np.where(blobs(13, 9, 2)[:, :, None] > 0, np.array([240, 200, 30, 255], dtype=np.uint8), np.array([30, 40, 200, 90], dtype=np.uint8)).astype(np.uint8)
+    layouts = [
+        ("i_rgb", colour(29, 23), "png_i"), ("i_rgba16", np.concatenate([colour(17, 35), rng.integers(120, 256, size=(17, 35, 1), dtype=np.uint8)], axis=2), "png16_i"),
+        ("g1", blobs(19, 27, 2), "png_g1"), ("g2", blobs(22, 13, 4), "png_g2"), ("g4_i", blobs(15, 31, 16), "png_g4_i"),
+        ("p4", pal4, "png_p4"), ("p1_alpha_i", pal1, "png_p1_alpha_i"),
+        ("key_grey", keyed(blobs(16, 20, 256)), "png_key"), ("key_rgb", keyed(colour(18, 26)), "png_key"),
+        ("key_rgb16_i", keyed(colour(11, 14)), "png16_key_i"), ("key_g2", keyed(blobs(9, 21, 4)), "png_g2_key"),
+        ("i_thin", colour(37, 2), "png_i"),                          # (a 1-pixel-wide texture makes the reference read out of bounds: its size - 2 scale wraps)
+    ]
+    textures = {"floor_kd.png": (colour(40, 64), "png_i")}
+    materials = [MtlMaterial("floor", Ns=20.0, Ka=(0.6, 0.6, 0.6), Kd=(0.9, 0.9, 0.9), Ks=(0.2, 0.2, 0.2), map_Kd="floor_kd.png")]
+    for k, (name, img, enc) in enumerate(layouts):
+        col, row = k % 6, k // 6
+        x0, y0 = -3.9 + col * 1.3, 0.15 + row * 1.4
+        z = -1.5 - 0.25 * row
+        add("panel_" + name, _quad(pos, nrm, uv, [(x0, y0, z), (x0 + 1.15, y0, z), (x0 + 1.15, y0 + 1.15, z), (x0, y0 + 1.15, z)], (0, 0, 1),
+                                   [(0, 0), (1, 0), (1, 1), (0, 1)]), name)
+        textures[name + ".png"] = (img, enc)
+        materials.append(MtlMaterial(name, Ns=25.0, d=1.0, Ka=(0.7, 0.7, 0.7), Kd=(1.0, 1.0, 1.0), Ks=(0.15, 0.15, 0.15), map_Kd=name + ".png"))
+    return ObjScene(
+        name="png_gallery",
+        positions=np.array(pos, dtype=F32), texcoords=np.array(uv, dtype=F32), normals=np.array(nrm, dtype=F32),
+        groups=groups, materials=materials, textures=textures,
+        camera_position=(0.0, 1.7, 4.4), camera_facing=(0.0, -0.12, -1.0), fov=62.0)
+
+
 # ----------------------------------------------------------------------------------------
 # registry: name -> (factory, render defaults)
 # ----------------------------------------------------------------------------------------
@@ -1170,6 +1279,7 @@ SCENES = {
     "terrain_192": lambda: terrain(192, 8, size=192.0),       # 73,728 tris in 64 groups
     "many_materials": lambda: many_materials(),               # 1,282 tris, 42 materials (LDS table fallback), translucent clusters
     "textured_gallery": lambda: textured_gallery(),           # 192 tris, 7 materials, 14 texture files (row N1)
+    "png_gallery": lambda: png_gallery(),                     # 26 tris, 13 materials, 13 PNG files: interlaced, 1 / 2 / 4-bit, colour keys
     "jpeg_gallery": lambda: jpeg_gallery(),                   # 28 tris, 14 materials, 16 JPEG files: baseline and progressive, every sampling layout
 }
 

@@ -144,6 +144,61 @@ def test_jpeg_decoder_bit_identical_to_reference():
     assert (dims[:, :, 0] > 0).sum() == 16 and set(np.unique(dims[:, :, 2])) == {0, 1, 3}
 
 
+def test_png_corner_cases_bit_identical_to_reference():
+    """The 13 files of the png_gallery scene - Adam7 interlaced 8- and 16-bit, 1 / 2 / 4-bit grey (scaled to 0..255), 4- and
+    1-bit palettes (one with tRNS, interlaced), colour-key tRNS on grey / RGB / 16-bit RGB / 2-bit grey - decode to the
+    bytes AND the channel counts the reference's decoder reported."""
+    g = load_golden("png_gallery_128x96")
+    hs = host_scene("png_gallery")
+    a = hs.arrays()
+    assert np.array_equal(a["group_texture_dims"], g["group_texture_dims"])
+    assert np.array_equal(_sums(a["group_texture_bytes"]), g["sum_group_texture_bytes"])
+    dims = a["group_texture_dims"].reshape(-1, 5, 3)
+    assert (dims[:, :, 0] > 0).sum() == 13 and set(np.unique(dims[:, :, 2])) == {0, 1, 3, 4}
+
+
+def test_png_variants_round_trip_with_every_filter(tmp_path):
+    """Adam7, sub-byte depths and colour keys against what was written, at sizes that leave interlace passes empty, with
+    all five scanline filters (the fixture above can only use None / Sub on sub-byte images: the reference's decoder reads
+    the previous row of those at the wrong offset).  A colour key comes back the way the reference's decoder hands it
+    over: the (channels + 1)-interleaved pixels cut off at width x height x channels bytes (image_in.cpp DecodePng)."""
+    from par_raytracer_amd import scenes
+    lib = capi.host_lib()
+    rng = np.random.default_rng(3)
+    allf = (0, 1, 2, 3, 4)
+
+    def check(img, expect, **kw):
+        path = str(tmp_path / "v.png")
+        scenes.write_png(path, img, filters=allf, **kw)
+        got = _load_texture(lib, path)
+        assert got is not None and got.shape == expect.shape and np.array_equal(got, expect), (img.shape, kw)
+
+    def keyed(expect_with_alpha):                                       # what the reference sees of an image with a colour key
+        h, w, c1 = expect_with_alpha.shape
+        return expect_with_alpha.reshape(-1)[:h * w * (c1 - 1)].reshape(h, w, c1 - 1)
+
+    for hh, ww in ((13, 7), (1, 1), (3, 5), (9, 1), (2, 17), (8, 8), (16, 33)):
+        rgb = rng.integers(0, 256, size=(hh, ww, 3), dtype=np.uint8)
+        rgba = rng.integers(0, 256, size=(hh, ww, 4), dtype=np.uint8)
+        check(rgb, rgb, interlace=True)
+        check(rgba, rgba, interlace=True, sixteen_bit=True)
+        for bits, scale in ((1, 255), (2, 85), (4, 17)):
+            gl = rng.integers(0, 1 << bits, size=(hh, ww), dtype=np.uint8)
+            for il in (False, True):
+                check(gl, (gl * scale)[:, :, None].astype(np.uint8), bits=bits, interlace=il)
+            k = np.stack([gl * scale, np.where(gl == gl[0, 0], 0, 255)], axis=2).astype(np.uint8)
+            check(gl, keyed(k), bits=bits, key=[int(gl[0, 0])])
+        p4 = (rng.integers(0, 2, size=(hh, ww, 3), dtype=np.uint8) * 120 + 7).astype(np.uint8)          # 8 colours
+        check(p4, p4, palette=True, bits=4, interlace=True)
+        p1 = np.where(rng.integers(0, 2, size=(hh, ww, 1)) > 0, np.array([10, 200, 30, 128], dtype=np.uint8),
+                      np.array([250, 0, 90, 255], dtype=np.uint8)).astype(np.uint8)
+        if len(np.unique(p1.reshape(-1, 4), axis=0)) == 2:
+            check(p1, p1, palette=True, palette_alpha=True, bits=1)
+        ka = np.concatenate([rgb, np.where((rgb == rgb[0, 0]).all(axis=2, keepdims=True), 0, 255).astype(np.uint8)], axis=2)
+        check(rgb, keyed(ka), key=rgb[0, 0])
+        check(rgb, keyed(ka), key=rgb[0, 0], sixteen_bit=True, interlace=True)
+
+
 def test_jpeg_files_decode_close_to_what_was_encoded(tmp_path):
     """scenes.write_jpeg is a real (lossy) encoder: what comes back is the picture that went in, within the quantisation
     error, for every layout - so the bit-identity test above is about pictures, not about noise."""

@@ -16,6 +16,9 @@ for enc, im in (("png", img3), ("png", img1), ("png", img4), ("png16", img3), ("
     p = os.path.join(d, "s%d.img" % len(seeds)); scenes.write_texture(p, im, enc); seeds.append(open(p, "rb").read())
 for enc, im in (("jpg", img1), ("jpg", img3), ("jpg422", img3), ("jpg440", img3), ("jpg420", img3), ("jpg411", img3), ("jpg420_rst", img3), ("jpg_scans", img3), ("jpg_rgb", img3), ("jpg_prog", img3), ("jpg_prog", img1), ("jpg_prog420", img3), ("jpg_prog422_rst", img3)):
     p = os.path.join(d, "s%d.img" % len(seeds)); scenes.write_texture(p, im, enc); seeds.append(open(p, "rb").read())
+g2 = (img1 // 64).astype(np.uint8)
+for enc, im in (("png_i", img3), ("png16_i", img4), ("png_g1", g2 // 2), ("png_g2", g2), ("png_g4_i", img1 // 16), ("png_p4", img3 // 128 * 100), ("png_key", img3), ("png16_key_i", img3), ("png_g2_key", g2)):
+    p = os.path.join(d, "s%d.img" % len(seeds)); scenes.write_texture(p, im, enc); seeds.append(open(p, "rb").read())
 n_ok = n_fail = 0
 for it in range(int(os.environ.get("PRT_FUZZ_ITERATIONS", "12000"))):
     b = bytearray(seeds[it % len(seeds)])
