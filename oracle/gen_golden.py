@@ -54,6 +54,10 @@ FIXTURES = {
     # the PNG corners of the loader: Adam7, 1 / 2 / 4-bit grey and palettes, colour-key tRNS (with the reference decoder's
     # channel-count quirk), 16-bit interlaced
     "png_gallery_128x96": dict(scene="png_gallery", width=128, height=96, spp=4, lattice=1),
+    # every BMP flavour the reference's decoder accepts (palettes, 16 / 24 / 32-bit, OS/2 and V4 headers, masks, alpha rules)
+    "bmp_gallery_128x96": dict(scene="bmp_gallery", width=128, height=96, spp=4, lattice=1),
+    # the TGA corners: 5-5-5 pixels, grey + alpha, colour maps with 15 / 24 / 32-bit entries and 8 / 16-bit indices
+    "tga_gallery_128x96": dict(scene="tga_gallery", width=128, height=96, spp=4, lattice=1),
     # row N4: the reference's adaptive loop (main.cpp:245-258), one RNG stream per pixel; spp = min_samples
     "cornell_adaptive_4_16": dict(scene="cornell_box", width=96, height=72, spp=4, max_spp=16, lattice=1),
     "gallery_adaptive_10_50": dict(scene="textured_gallery", width=64, height=48, spp=10, max_spp=50, lattice=1),      # reference defaults

@@ -9,17 +9,19 @@
 //   * PNG  1 / 2 / 4 / 8 / 16-bit samples (below 8 bits scaled to 0..255, 16-bit: high byte kept), all five scanline
 //          filters, Adam7 interlacing, palettes with tRNS, colour-key tRNS on grey / RGB (with the reference decoder's
 //          channel-count quirk, see DecodePng);
-//   * TGA  types 2 / 3 (raw) and 10 / 11 (run-length), 8 / 24 / 32 bits, BGR(A) -> RGB(A), bottom-up files
-//          flipped to top-down;
-//   * BMP  24-bit uncompressed, BGR -> RGB, bottom-up flipped;
+//   * TGA  types 1 / 2 / 3 (raw) and 9 / 10 / 11 (run-length): colour maps (8- / 16-bit indices; 15 / 16 / 24 / 32-bit
+//          entries), 15 / 16-bit 5-5-5, 16-bit grey + alpha, 8 / 24 / 32 bits, BGR(A) -> RGB(A), bottom-up files flipped;
+//   * BMP  4- / 8-bit palettes, 16-bit (5-5-5 or masks), 24-bit, 32-bit (plain or masks), OS/2 and V4 / V5 headers,
+//          BGR(A) -> RGB(A), bottom-up files flipped; channels and alpha handling as in the reference's decoder;
 //   * PNM  binary P5 (grey) / P6 (RGB), maxval <= 255.
 //   * JPEG baseline and progressive (image_jpeg.cpp): grey -> 1 channel, colour -> 3, every sampling layout, restart intervals.
-// Anything else (arithmetic-coded JPEG, colour-mapped TGA, palette / RLE BMP ...) is reported and the texture slot
+// Anything else (arithmetic-coded JPEG, run-length / 1-bit BMP, GIF, PSD, HDR ...) is reported and the texture slot
 // stays empty, which is how the reference treats a file its decoder rejects (obj_parser.cpp:201-204).
 // tests/test_host_side.py compares the decoded bytes with the reference's on generated files of every kind.
 #include <zlib.h>
 
 #include <cctype>
+#include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -231,45 +233,96 @@ bool DecodePng(const std::vector<u8> & d, Image * out) {
 }
 
 // ---- TGA ------------------------------------------------------------------------------------------------
+// The reference decoder's conventions: the channel count comes from the palette entry size of a colour-mapped file, else
+// from the pixel size - 8 bits: 1 (grey), 16 bits of a grey image: 2 (grey + alpha), 15 / 16 bits: 3 (5-5-5, each channel
+// c * 255 / 31, no alpha), 24 / 32 bits: 3 / 4 (BGR(A) -> RGB(A)); run-length packets may cross rows; an index past the
+// palette reads entry 0; the palette is found after the image id plus "first entry" BYTES.
+void TgaRgb16(const u8 * p, u8 * o) {
+    const u32 px = Le16(p);
+    o[0] = (u8)((((px >> 10) & 31u) * 255u) / 31u);
+    o[1] = (u8)((((px >> 5) & 31u) * 255u) / 31u);
+    o[2] = (u8)(((px & 31u) * 255u) / 31u);
+}
+
 bool DecodeTga(const std::vector<u8> & d, Image * out) {
     if (d.size() < 18) return Fail("TGA header truncated");
-    const u32 id_len = d[0], cmap_type = d[1], type = d[2];
+    const u32 id_len = d[0], cmap_type = d[1];
+    u32 type = d[2];
+    const u32 pal_start = Le16(&d[3]), pal_len = Le16(&d[5]), pal_bits = d[7];
     const u32 w = Le16(&d[12]), h = Le16(&d[14]), bits = d[16], desc = d[17];
-    if (cmap_type != 0) return Fail("colour-mapped TGA is not supported");
-    const bool rle = type == 10 || type == 11;
-    const bool grey = type == 3 || type == 11;
-    if (!(type == 2 || type == 3 || rle)) return Fail("unsupported TGA image type");
+    if (cmap_type > 1) return Fail("bad TGA colour map type");
+    const bool rle = type >= 8;
+    if (rle) type -= 8;
+    const bool indexed = cmap_type == 1;
+    if (indexed ? type != 1 : (type != 2 && type != 3)) return Fail("unsupported TGA image type");
     if (!w || !h) return Fail("empty TGA");
-    if (grey ? bits != 8 : (bits != 24 && bits != 32)) return Fail("unsupported TGA pixel depth");
-    const u32 ch = bits / 8;
+    if (indexed && bits != 8 && bits != 16) return Fail("unsupported TGA index size");
+    const u32 fmt_bits = indexed ? pal_bits : bits;
+    u32 ch = 0;
+    bool rgb16 = false;
+    switch (fmt_bits) {
+        case 8: ch = 1; break;
+        case 16: if (!indexed && type == 3) { ch = 2; break; }   // grey + alpha; else 5-5-5
+        // fall through
+        case 15: ch = 3; rgb16 = true; break;
+        case 24: ch = 3; break;
+        case 32: ch = 4; break;
+        default: return Fail("unsupported TGA pixel depth");
+    }
+    const u32 in_bytes = indexed ? bits / 8 : (rgb16 ? 2 : ch);   // bytes per pixel in the file
     size_t pos = 18 + (size_t)id_len;
+    std::vector<u8> palette;
+    if (indexed) {
+        const size_t entry = rgb16 ? 2 : ch;
+        pos += pal_start;
+        if (pos > d.size() || (size_t)pal_len * entry > d.size() - pos) return Fail("TGA palette truncated");
+        palette.resize((size_t)pal_len * ch);
+        for (u32 i = 0; i < pal_len; ++i) {
+            if (rgb16) TgaRgb16(&d[pos + (size_t)i * 2], &palette[(size_t)i * 3]);
+            else memcpy(&palette[(size_t)i * ch], &d[pos + (size_t)i * ch], ch);
+        }
+        pos += (size_t)pal_len * entry;
+        if (!pal_len) return Fail("TGA palette is empty");
+    }
     const size_t n_px = (size_t)w * h;
-    // a raw image needs n_px * ch bytes of data, a run-length one at least one (1 + ch)-byte packet per 128 pixels
-    if (pos > d.size() || (rle ? (n_px + 127) / 128 * (1 + ch) : n_px * ch) > d.size() - pos) return Fail("TGA pixel data truncated");
+    // a raw image needs n_px * in_bytes bytes of data, a run-length one at least one packet per 128 pixels
+    if (pos > d.size() || (rle ? (n_px + 127) / 128 * (1 + in_bytes) : n_px * in_bytes) > d.size() - pos) return Fail("TGA pixel data truncated");
     std::vector<u8> px(n_px * ch);
+    auto pixel = [&](const u8 * p, u8 * o) {                     // one file pixel -> ch output bytes (still BGR order for 24 / 32 bits)
+        if (indexed) {
+            u32 idx = bits == 8 ? p[0] : Le16(p);
+            if (idx >= pal_len) idx = 0;
+            memcpy(o, &palette[(size_t)idx * ch], ch);
+        } else if (rgb16) {
+            TgaRgb16(p, o);
+        } else {
+            memcpy(o, p, ch);
+        }
+    };
     if (!rle) {
-        if (pos + n_px * ch > d.size()) return Fail("TGA pixel data truncated");
-        memcpy(px.data(), &d[pos], n_px * ch);
+        for (size_t i = 0; i < n_px; ++i) pixel(&d[pos + i * in_bytes], &px[i * ch]);
     } else {
         size_t i = 0;
         while (i < n_px) {
             if (pos >= d.size()) return Fail("TGA run-length data truncated");
             const u32 head = d[pos++];
-            const size_t count = (head & 127u) + 1u;
-            if (i + count > n_px) return Fail("TGA run crosses the end of the image");
+            size_t count = (head & 127u) + 1u;
+            if (count > n_px - i) count = n_px - i;               // the last packet may promise more pixels than are left
             if (head & 128u) {
-                if (pos + ch > d.size()) return Fail("TGA run-length data truncated");
-                for (size_t k = 0; k < count; ++k) memcpy(&px[(i + k) * ch], &d[pos], ch);
-                pos += ch;
+                if (in_bytes > d.size() - pos) return Fail("TGA run-length data truncated");
+                u8 one[4];
+                pixel(&d[pos], one);
+                for (size_t k = 0; k < count; ++k) memcpy(&px[(i + k) * ch], one, ch);
+                pos += in_bytes;
             } else {
-                if (pos + count * ch > d.size()) return Fail("TGA run-length data truncated");
-                memcpy(&px[i * ch], &d[pos], count * ch);
-                pos += count * ch;
+                if (count * in_bytes > d.size() - pos) return Fail("TGA run-length data truncated");
+                for (size_t k = 0; k < count; ++k) pixel(&d[pos + k * in_bytes], &px[(i + k) * ch]);
+                pos += count * in_bytes;
             }
             i += count;
         }
     }
-    if (ch >= 3) for (size_t i = 0; i < n_px; ++i) std::swap(px[i * ch], px[i * ch + 2]);        // BGR(A) -> RGB(A)
+    if (ch >= 3 && !rgb16) for (size_t i = 0; i < n_px; ++i) std::swap(px[i * ch], px[i * ch + 2]);        // BGR(A) -> RGB(A)
     const bool top_down = (desc & 0x20u) != 0;
     out->w = w; out->h = h; out->channels = ch;
     out->px.resize(px.size());
@@ -279,25 +332,163 @@ bool DecodeTga(const std::vector<u8> & d, Image * out) {
 }
 
 // ---- BMP ------------------------------------------------------------------------------------------------
+// What the reference's decoder accepts, with its conventions: header sizes 12 (OS/2) / 40 / 56 / 108 / 124; 4- and 8-bit
+// palettes, 16-bit (5-5-5, or BITFIELDS masks), 24-bit, 32-bit; no RLE, no 1-bit.  Channels: 4 when the format has an
+// alpha mask - a plain 32-bit file counts as having one, and if every alpha byte of it is 0 they all become 255 - else
+// 3.  Masked channels of fewer than 8 bits are widened by repeating their top bits.  A positive height is bottom-up.
+int BmpHighBit(u32 z) {
+    int n = 0;
+    if (z == 0) return -1;
+    if (z >= 0x10000) { n += 16; z >>= 16; }
+    if (z >= 0x00100) { n += 8; z >>= 8; }
+    if (z >= 0x00010) { n += 4; z >>= 4; }
+    if (z >= 0x00004) { n += 2; z >>= 2; }
+    if (z >= 0x00002) { n += 1; }
+    return n;
+}
+
+int BmpBitCount(u32 a) {
+    int n = 0;
+    for (; a; a >>= 1) n += (int)(a & 1u);
+    return n;
+}
+
+// the masked bits moved so that their top bit is bit 7, then repeated downwards until 8 bits are filled (32-bit
+// two's-complement arithmetic: a mask that reaches bit 31 shifts in sign bits, of which only the low byte is kept)
+u8 BmpChannel(u32 masked, int shift, int bits) {
+    int32_t v = (int32_t)masked;
+    if (shift < 0) v = (int32_t)((u32)v << (-shift)); else v >>= shift;
+    int32_t result = v;
+    for (int z = bits; z < 8 && bits > 0; z += bits) result += v >> z;
+    return (u8)(result & 255);
+}
+
 bool DecodeBmp(const std::vector<u8> & d, Image * out) {
-    if (d.size() < 54 || d[0] != 'B' || d[1] != 'M') return Fail("not a BMP");
-    const u32 offset = Le32(&d[10]), hsize = Le32(&d[14]);
-    if (hsize < 40) return Fail("unsupported BMP header");
-    const int32_t w = (int32_t)Le32(&d[18]);
-    const int32_t hs = (int32_t)Le32(&d[22]);
-    const u32 bits = Le16(&d[28]), comp = Le32(&d[30]);
-    if (bits != 24 || comp != 0) return Fail("only 24-bit uncompressed BMP is supported");
-    if (w <= 0 || hs == 0) return Fail("empty BMP");
-    const u32 h = (u32)(hs < 0 ? -hs : hs);
-    const size_t stride = (((size_t)w * 3) + 3) & ~(size_t)3;
-    if ((size_t)offset + stride * h > d.size()) return Fail("BMP pixel data truncated");
-    out->w = (u32)w; out->h = h; out->channels = 3;
-    out->px.resize((size_t)w * h * 3);
-    for (u32 y = 0; y < h; ++y) {
-        const u8 * src = &d[(size_t)offset + stride * (hs > 0 ? h - 1 - y : y)];
-        u8 * dst = &out->px[(size_t)w * 3 * y];
-        for (int32_t x = 0; x < w; ++x) { dst[3 * x] = src[3 * x + 2]; dst[3 * x + 1] = src[3 * x + 1]; dst[3 * x + 2] = src[3 * x]; }
+    if (d.size() < 26 || d[0] != 'B' || d[1] != 'M') return Fail("not a BMP");
+    const u32 offset = Le32(&d[10]), hsz = Le32(&d[14]);
+    if (hsz != 12 && hsz != 40 && hsz != 56 && hsz != 108 && hsz != 124) return Fail("unknown BMP header size");
+    if (d.size() < 14 + (size_t)hsz) return Fail("BMP header truncated");
+    int32_t w, hs;
+    u32 planes, bpp, compress = 0;
+    u32 mr = 0, mg = 0, mb = 0, ma = 0;
+    bool plain32 = false;
+    if (hsz == 12) {
+        w = (int32_t)Le16(&d[18]); hs = (int32_t)Le16(&d[20]); planes = Le16(&d[22]); bpp = Le16(&d[24]);
+    } else {
+        w = (int32_t)Le32(&d[18]); hs = (int32_t)Le32(&d[22]); planes = Le16(&d[26]); bpp = Le16(&d[28]);
+        compress = Le32(&d[30]);
     }
+    if (planes != 1) return Fail("bad BMP");
+    if (bpp == 1) return Fail("1-bit BMP is not supported");
+    if (compress == 1 || compress == 2) return Fail("run-length BMP is not supported");
+    if (hsz == 40 || hsz == 56) {
+        if (bpp == 16 || bpp == 32) {
+            if (compress == 0) {
+                if (bpp == 32) { mr = 0xFFu << 16; mg = 0xFFu << 8; mb = 0xFFu; ma = 0xFFu << 24; plain32 = true; }
+                else { mr = 31u << 10; mg = 31u << 5; mb = 31u; }
+            } else if (compress == 3) {
+                const size_t at = 14 + (size_t)hsz;                // the three masks follow the header
+                if (d.size() < at + 12) return Fail("BMP masks truncated");
+                mr = Le32(&d[at]); mg = Le32(&d[at + 4]); mb = Le32(&d[at + 8]);
+                if (mr == mg && mg == mb) return Fail("bad BMP masks");
+            } else {
+                return Fail("bad BMP compression");
+            }
+        }
+    } else if (hsz == 108 || hsz == 124) {
+        mr = Le32(&d[54]); mg = Le32(&d[58]); mb = Le32(&d[62]); ma = Le32(&d[66]);
+    }
+    if (w <= 0 || hs == 0 || hs == INT32_MIN) return Fail("empty BMP");
+    const bool bottom_up = hs > 0;
+    const u32 h = (u32)(hs < 0 ? -hs : hs);
+    if ((unsigned long long)w * h > (1ull << 28)) return Fail("BMP larger than 2^28 pixels");
+    const u32 channels = ma ? 4 : 3;
+    std::vector<u8> px;
+    size_t row_bytes;
+    u8 pal[256][3];
+    if (bpp < 16) {
+        if (bpp != 4 && bpp != 8) return Fail("bad BMP bit depth");
+        const long entry = hsz == 12 ? 3 : 4;
+        const long psize = hsz == 12 ? ((long)offset - 14 - 24) / 3 : ((long)offset - 14 - (long)hsz) >> 2;
+        if (psize <= 0 || psize > 256) return Fail("bad BMP palette size");
+        if (d.size() < 14 + (size_t)hsz + (size_t)psize * entry) return Fail("BMP palette truncated");
+        memset(pal, 0, sizeof(pal));
+        for (long i = 0; i < psize; ++i) {
+            const u8 * e = &d[14 + (size_t)hsz + (size_t)i * entry];
+            pal[i][0] = e[2]; pal[i][1] = e[1]; pal[i][2] = e[0];
+        }
+        const size_t width = bpp == 4 ? ((size_t)w + 1) >> 1 : (size_t)w;
+        row_bytes = (width + 3) & ~(size_t)3;
+    } else if (bpp == 16) {
+        row_bytes = ((size_t)w * 2 + 3) & ~(size_t)3;
+    } else if (bpp == 24) {
+        row_bytes = ((size_t)w * 3 + 3) & ~(size_t)3;
+    } else if (bpp == 32) {
+        row_bytes = (size_t)w * 4;
+    } else {
+        return Fail("bad BMP bit depth");
+    }
+    // With a 40- or 56-byte header and BITFIELDS masks the reference's decoder (stb_image 2.14) has already consumed the
+    // twelve mask bytes when it skips "offset - 14 - header size" bytes to the pixels: it starts twelve bytes late and
+    // reads zeros past the end of the file.  Same here, so that such a file gives the reference's (shifted) picture.
+    const size_t late = ((hsz == 40 || hsz == 56) && compress == 3 && (bpp == 16 || bpp == 32)) ? 12 : 0;
+    std::vector<u8> shifted;
+    const u8 * base = d.data();
+    size_t avail = d.size();
+    if (late) {
+        if ((size_t)offset > d.size() || row_bytes * h > d.size() - offset) return Fail("BMP pixel data truncated");
+        shifted.assign(d.begin(), d.end());
+        shifted.resize(d.size() + late, 0);
+        base = shifted.data();
+        avail = shifted.size();
+    }
+    if ((size_t)offset + late > avail || row_bytes * h > avail - offset - late) return Fail("BMP pixel data truncated");
+    const bool easy24 = bpp == 24;
+    const bool easy32 = bpp == 32 && mb == 0xFFu && mg == 0xFF00u && mr == 0x00FF0000u && ma == 0xFF000000u;
+    int rshift = 0, gshift = 0, bshift = 0, ashift = 0, rcount = 0, gcount = 0, bcount = 0, acount = 0;
+    if (bpp >= 16 && !easy24 && !easy32) {
+        if (!mr || !mg || !mb) return Fail("bad BMP masks");
+        rshift = BmpHighBit(mr) - 7; rcount = BmpBitCount(mr);
+        gshift = BmpHighBit(mg) - 7; gcount = BmpBitCount(mg);
+        bshift = BmpHighBit(mb) - 7; bcount = BmpBitCount(mb);
+        ashift = BmpHighBit(ma) - 7; acount = BmpBitCount(ma);
+    }
+    px.resize((size_t)w * h * channels);
+    u32 all_a = plain32 ? 0u : 255u;
+    for (u32 y = 0; y < h; ++y) {
+        const u8 * src = base + (size_t)offset + late + row_bytes * (bottom_up ? h - 1 - y : y);
+        u8 * dst = &px[(size_t)w * channels * y];
+        for (int32_t x = 0; x < w; ++x) {
+            u8 * o = dst + (size_t)x * channels;
+            u32 a = 255;
+            if (bpp < 16) {
+                const u32 v = bpp == 8 ? src[x] : (x & 1 ? src[x >> 1] & 15u : src[x >> 1] >> 4);
+                o[0] = pal[v][0]; o[1] = pal[v][1]; o[2] = pal[v][2];
+            } else if (easy24 || easy32) {
+                const u8 * e = src + (size_t)x * (bpp / 8);
+                o[0] = e[2]; o[1] = e[1]; o[2] = e[0];
+                if (easy32) a = e[3];
+            } else {
+                const u32 v = bpp == 16 ? Le16(src + 2 * (size_t)x) : Le32(src + 4 * (size_t)x);
+                o[0] = BmpChannel(v & mr, rshift, rcount);
+                o[1] = BmpChannel(v & mg, gshift, gcount);
+                o[2] = BmpChannel(v & mb, bshift, bcount);
+                if (ma) {                                      // the library keeps this one as a full int for its all-zero test
+                    int32_t t = (int32_t)(v & ma);
+                    if (ashift < 0) t = (int32_t)((u32)t << (-ashift)); else t >>= ashift;
+                    int32_t r = t;
+                    for (int z = acount; z < 8 && acount > 0; z += acount) r += t >> z;
+                    a = (u32)r;
+                }
+            }
+            all_a |= a;
+            if (channels == 4) o[3] = (u8)(a & 255u);
+        }
+    }
+    if (channels == 4 && all_a == 0)                           // an alpha channel that is 0 everywhere was never meant as one
+        for (size_t i = 3; i < px.size(); i += 4) px[i] = 255;
+    out->w = (u32)w; out->h = h; out->channels = channels;
+    out->px.swap(px);
     return true;
 }
 

@@ -232,20 +232,65 @@ def write_png(path: str, img: np.ndarray, sixteen_bit: bool = False, palette: bo
         f.write(_png_chunk(b"IEND", b""))
 
 
-def write_tga(path: str, img: np.ndarray, rle: bool = False, top_down: bool = False) -> None:
-    """Grey (type 3 / 11), BGR or BGRA (type 2 / 10) TGA; bottom-up unless `top_down` (descriptor bit 5)."""
+def write_tga(path: str, img: np.ndarray, rle: bool = False, top_down: bool = False, kind: str = "") -> None:
+    """Grey (type 3 / 11), BGR or BGRA (type 2 / 10) TGA; bottom-up unless `top_down` (descriptor bit 5).
+    kind: "" (8 / 24 / 32 bits from the channel count), "16" (5-5-5 pixels), "ga" (2 channels: 16-bit grey + alpha, type
+    3), "map24" / "map32" / "map16" (colour map with 24- / 32- / 15-bit entries, 8-bit indices; with an image id and a
+    non-zero first-entry field), "map24_i16" (16-bit indices)."""
     import struct
     a = np.asarray(img, dtype=np.uint8)
     if a.ndim == 2:
         a = a[:, :, None]
     h, w, c = a.shape
-    assert c in (1, 3, 4)
     rows = a if top_down else a[::-1]
-    if c >= 3:
-        rows = rows[:, :, [2, 1, 0] + ([3] if c == 4 else [])]
-    px = np.ascontiguousarray(rows).reshape(-1, c)
-    itype = (3 if c == 1 else 2) + (8 if rle else 0)
-    header = struct.pack("<BBBHHBHHHHBB", 0, 0, itype, 0, 0, 0, 0, 0, w, h, 8 * c, (0x20 if top_down else 0) | (8 if c == 4 else 0))
+    ident = b""
+    cmap = b""
+    cmap_spec = (0, 0, 0)
+
+    def bgr(x):
+        return x[..., [2, 1, 0] + ([3] if x.shape[-1] == 4 else [])] if x.shape[-1] >= 3 else x
+
+    def pack555(x):
+        v = ((x[..., 0].astype(np.uint16) >> 3) << 10) | ((x[..., 1].astype(np.uint16) >> 3) << 5) | (x[..., 2].astype(np.uint16) >> 3)
+        return v.astype("<u2")
+
+    if kind == "":
+        assert c in (1, 3, 4)
+        px = np.ascontiguousarray(bgr(rows)).reshape(-1, c)
+        itype, bits, abits = (3 if c == 1 else 2), 8 * c, (8 if c == 4 else 0)
+    elif kind == "16":
+        px = pack555(rows).reshape(-1, 1).view(np.uint8).reshape(-1, 2)
+        itype, bits, abits = 2, 16, 0
+    elif kind == "ga":
+        assert c == 2
+        px = np.ascontiguousarray(rows).reshape(-1, 2)
+        itype, bits, abits = 3, 16, 8
+    elif kind.startswith("map"):
+        flat = rows.reshape(-1, c)
+        colours, index = np.unique(flat, axis=0, return_inverse=True)
+        ident = b"id!"                                                  # an image id to skip
+        first = 5                                                       # "first entry index": the reference's decoder skips that many BYTES
+        if kind == "map16":
+            table = pack555(colours[:, :3]).view(np.uint8).reshape(-1, 2)
+            ebits = 15
+        else:
+            table = bgr(colours)
+            ebits = 8 * colours.shape[1]
+        cmap = bytes(first) + np.ascontiguousarray(table).tobytes()
+        cmap_spec = (first, len(colours), ebits)
+        if kind.endswith("_i16"):
+            px = index.astype("<u2").reshape(-1, 1).view(np.uint8).reshape(-1, 2)
+            bits = 16
+        else:
+            assert len(colours) <= 256
+            px = index.astype(np.uint8).reshape(-1, 1)
+            bits = 8
+        itype, abits = 1, 0
+    else:
+        raise ValueError(kind)
+    c = px.shape[1]
+    header = struct.pack("<BBBHHBHHHHBB", len(ident), 1 if cmap else 0, itype + (8 if rle else 0), cmap_spec[0], cmap_spec[1], cmap_spec[2],
+                         0, 0, w, h, bits, (0x20 if top_down else 0) | abits)
     body = bytearray()
     if not rle:
         body += px.tobytes()
@@ -268,21 +313,73 @@ def write_tga(path: str, img: np.ndarray, rle: bool = False, top_down: bool = Fa
                 i = j
     with open(path, "wb") as f:
         f.write(header)
+        f.write(ident)
+        f.write(cmap)
         f.write(bytes(body))
 
 
-def write_bmp(path: str, img: np.ndarray) -> None:
-    """24-bit uncompressed bottom-up BMP."""
+def write_bmp(path: str, img: np.ndarray, kind: str = "24") -> None:
+    """Uncompressed BMP.  kind: "24" (bottom-up BGR), "24_top" (negative height), "os2_24" / "os2_8" (12-byte header; the
+    palette has 3-byte entries), "8" / "4" (palette, <= 256 / 16 colours), "16" (5-5-5), "16_565" (40-byte header +
+    BITFIELDS masks), "32" (plain BGRA: img may have 4 channels), "32_v4" (108-byte header with R, G, B, A masks in an
+    unusual order)."""
     import struct
     a = np.asarray(img, dtype=np.uint8)
     h, w, c = a.shape
-    assert c == 3
-    stride = (w * 3 + 3) & ~3
+    top = kind == "24_top"
+    src = a if top else a[::-1]
+    masks = b""
+    pal = b""
+    comp = 0
+    hsz = 12 if kind.startswith("os2") else (108 if kind == "32_v4" else 40)
+    if kind in ("24", "24_top", "os2_24"):
+        bpp = 24
+        body = src[:, :, 2::-1].reshape(h, w * 3)
+    elif kind in ("8", "4", "os2_8"):
+        bpp = 4 if kind == "4" else 8
+        colours, index = np.unique(a[:, :, :3].reshape(-1, 3), axis=0, return_inverse=True)
+        assert len(colours) <= (1 << bpp)
+        idx = index.reshape(h, w)[::-1].astype(np.uint8)
+        body = _png_pack_bits(idx, 4) if bpp == 4 else idx
+        for col in colours:
+            pal += bytes([int(col[2]), int(col[1]), int(col[0])]) + (b"" if hsz == 12 else b"\0")
+        pal += bytes((3 if hsz == 12 else 4) * ((1 << bpp) - len(colours)))        # a full-size palette, as real files carry
+    elif kind in ("16", "16_565"):
+        bpp = 16
+        r, g, b_ = (src[:, :, k].astype(np.uint16) for k in range(3))
+        if kind == "16":
+            v = ((r >> 3) << 10) | ((g >> 3) << 5) | (b_ >> 3)
+        else:
+            v = ((r >> 3) << 11) | ((g >> 2) << 5) | (b_ >> 3)
+            comp = 3
+            masks = struct.pack("<III", 0xF800, 0x07E0, 0x001F)
+        body = v.astype("<u2").view(np.uint8).reshape(h, w * 2)
+    elif kind == "32":
+        bpp = 32
+        alpha = src[:, :, 3] if c == 4 else np.zeros((h, w), dtype=np.uint8)
+        body = np.stack([src[:, :, 2], src[:, :, 1], src[:, :, 0], alpha], axis=2).reshape(h, w * 4)
+    elif kind == "32_v4":
+        bpp = 32
+        comp = 3
+        alpha = src[:, :, 3] if c == 4 else np.full((h, w), 255, dtype=np.uint8)
+        body = np.stack([alpha, src[:, :, 0], src[:, :, 1], src[:, :, 2]], axis=2).reshape(h, w * 4)       # bytes A R G B = masks below
+    else:
+        raise ValueError(kind)
+    stride = (body.shape[1] + 3) & ~3
     rows = np.zeros((h, stride), dtype=np.uint8)
-    rows[:, :w * 3] = a[::-1, :, ::-1].reshape(h, w * 3)
+    rows[:, :body.shape[1]] = body
+    offset = 14 + hsz + len(masks) + len(pal)
     with open(path, "wb") as f:
-        f.write(b"BM" + struct.pack("<IHHI", 54 + stride * h, 0, 0, 54))
-        f.write(struct.pack("<IiiHHIIiiII", 40, w, h, 1, 24, 0, stride * h, 2835, 2835, 0, 0))
+        f.write(b"BM" + struct.pack("<IHHI", offset + stride * h, 0, 0, offset))
+        if hsz == 12:
+            f.write(struct.pack("<IHHHH", 12, w, h, 1, bpp))
+        else:
+            f.write(struct.pack("<IiiHHIIiiII", hsz, w, -h if top else h, 1, bpp, comp, stride * h, 2835, 2835, 0, 0))
+            if hsz == 108:
+                f.write(struct.pack("<IIII", 0x0000FF00, 0x00FF0000, 0xFF000000, 0x000000FF))     # R, G, B, A masks
+                f.write(b"BGRs" + b"\0" * 48)                                                       # colour space + endpoints + gammas
+        f.write(masks)
+        f.write(pal)
         f.write(rows.tobytes())
 
 
@@ -741,7 +838,23 @@ def write_texture(path: str, img: np.ndarray, encoding: str) -> None:
         "tga": lambda: write_tga(path, img),
         "tga_top": lambda: write_tga(path, img, top_down=True),
         "tga_rle": lambda: write_tga(path, img, rle=True),
+        "tga16": lambda: write_tga(path, img, kind="16"),
+        "tga16_rle": lambda: write_tga(path, img, kind="16", rle=True, top_down=True),
+        "tga_ga": lambda: write_tga(path, img, kind="ga"),
+        "tga_map24": lambda: write_tga(path, img, kind="map24"),
+        "tga_map32_rle": lambda: write_tga(path, img, kind="map32", rle=True),
+        "tga_map16": lambda: write_tga(path, img, kind="map16", top_down=True),
+        "tga_map24_i16": lambda: write_tga(path, img, kind="map24_i16"),
         "bmp": lambda: write_bmp(path, img),
+        "bmp_top": lambda: write_bmp(path, img, "24_top"),
+        "bmp_os2": lambda: write_bmp(path, img, "os2_24"),
+        "bmp_os2_8": lambda: write_bmp(path, img, "os2_8"),
+        "bmp8": lambda: write_bmp(path, img, "8"),
+        "bmp4": lambda: write_bmp(path, img, "4"),
+        "bmp16": lambda: write_bmp(path, img, "16"),
+        "bmp16_565": lambda: write_bmp(path, img, "16_565"),
+        "bmp32": lambda: write_bmp(path, img, "32"),
+        "bmp32_v4": lambda: write_bmp(path, img, "32_v4"),
         "pnm": lambda: write_pnm(path, img),
         "jpg": lambda: write_jpeg(path, img),                                             # 4:4:4 (or grey)
         "jpg422": lambda: write_jpeg(path, img, sampling=(2, 1)),
@@ -1255,6 +1368,100 @@ def png_gallery() -> ObjScene:
         camera_position=(0.0, 1.7, 4.4), camera_facing=(0.0, -0.12, -1.0), fov=62.0)
 
 
+def bmp_gallery() -> ObjScene:
+    """Every BMP flavour the reference's decoder accepts as diffuse maps: 24-bit bottom-up and top-down, OS/2 headers
+    (24-bit and 8-bit palette), 8- and 4-bit palettes, 16-bit 5-5-5, 16-bit 5-6-5 with BITFIELDS masks (which that decoder
+    reads twelve bytes late), plain 32-bit with a real alpha channel and with an all-zero one, and a 108-byte header with
+    masks in A, R, G, B byte order."""
+    rng = np.random.default_rng(20241006)
+    pos, nrm, uv = [], [], []
+    groups = []
+
+    def add(name, tris, material):
+        groups.append(ObjGroup(name, _faces_same_index(np.array(tris)), material))
+
+    add("floor", _quad(pos, nrm, uv, [(-4, 0, 3), (4, 0, 3), (4, 0, -3), (-4, 0, -3)], (0, 1, 0),
+                       [(0, 0), (2, 0), (2, 1.5), (0, 1.5)]), "floor")
+
+    def colour(h, w, levels=256):
+        yy, xx = np.mgrid[0:h, 0:w]
+        img = np.stack([40 + 200 * ((xx // 3 + yy // 2) % 2), 128 + 100 * np.sin(yy * 0.8), 30 + 7 * xx], axis=2) + rng.integers(-20, 21, size=(h, w, 3))
+        img = img.clip(0, 255)
+        if levels < 256:
+            img = img // (256 // levels) * (256 // levels)
+        return img.astype(np.uint8)
+
+    def with_alpha(img, zero=False):
+        a = np.zeros(img.shape[:2] + (1,), dtype=np.uint8) if zero else rng.integers(1, 256, size=img.shape[:2] + (1,), dtype=np.uint8)
+        return np.concatenate([img, a], axis=2)
+
+    layouts = [("b24", colour(21, 30), "bmp"), ("b24_top", colour(17, 23), "bmp_top"), ("os2_24", colour(13, 9), "bmp_os2"),
+               ("os2_8", colour(19, 22, 4), "bmp_os2_8"), ("b8", colour(26, 31, 4), "bmp8"), ("b4", colour(15, 13, 2), "bmp4"),
+               ("b16", colour(20, 27), "bmp16"), ("b16_565", colour(18, 25), "bmp16_565"), ("b32", with_alpha(colour(14, 19)), "bmp32"),
+               ("b32_zero_alpha", with_alpha(colour(12, 17), zero=True), "bmp32"), ("b32_v4", with_alpha(colour(16, 11)), "bmp32_v4")]
+    textures = {"floor_kd.bmp": (colour(40, 64), "bmp")}
+    materials = [MtlMaterial("floor", Ns=20.0, Ka=(0.6, 0.6, 0.6), Kd=(0.9, 0.9, 0.9), Ks=(0.2, 0.2, 0.2), map_Kd="floor_kd.bmp")]
+    for k, (name, img, enc) in enumerate(layouts):
+        col, row = k % 6, k // 6
+        x0, y0 = -3.9 + col * 1.3, 0.15 + row * 1.4
+        z = -1.5 - 0.25 * row
+        add("panel_" + name, _quad(pos, nrm, uv, [(x0, y0, z), (x0 + 1.15, y0, z), (x0 + 1.15, y0 + 1.15, z), (x0, y0 + 1.15, z)], (0, 0, 1),
+                                   [(0, 0), (1, 0), (1, 1), (0, 1)]), name)
+        textures[name + ".bmp"] = (img, enc)
+        materials.append(MtlMaterial(name, Ns=25.0, d=1.0, Ka=(0.7, 0.7, 0.7), Kd=(1.0, 1.0, 1.0), Ks=(0.15, 0.15, 0.15), map_Kd=name + ".bmp"))
+    return ObjScene(
+        name="bmp_gallery",
+        positions=np.array(pos, dtype=F32), texcoords=np.array(uv, dtype=F32), normals=np.array(nrm, dtype=F32),
+        groups=groups, materials=materials, textures=textures,
+        camera_position=(0.0, 1.7, 4.4), camera_facing=(0.0, -0.12, -1.0), fov=62.0)
+
+
+def tga_gallery() -> ObjScene:
+    """The TGA corners of the loader as diffuse maps: 15 / 16-bit 5-5-5 pixels (raw, and run-length top-down), 16-bit grey +
+    alpha (two channels), colour maps with 24-bit, 32-bit (run-length) and 15-bit entries, a colour map addressed by 16-bit
+    indices - all with an image id, and the maps with a non-zero first-entry field."""
+    rng = np.random.default_rng(20241007)
+    pos, nrm, uv = [], [], []
+    groups = []
+
+    def add(name, tris, material):
+        groups.append(ObjGroup(name, _faces_same_index(np.array(tris)), material))
+
+    add("floor", _quad(pos, nrm, uv, [(-4, 0, 3), (4, 0, 3), (4, 0, -3), (-4, 0, -3)], (0, 1, 0),
+                       [(0, 0), (2, 0), (2, 1.5), (0, 1.5)]), "floor")
+
+    def colour(h, w, levels=256):
+        yy, xx = np.mgrid[0:h, 0:w]
+        img = np.stack([40 + 200 * ((xx // 4 + yy // 3) % 2), 128 + 100 * np.sin(yy * 0.6), 30 + 6 * xx], axis=2) + rng.integers(-20, 21, size=(h, w, 3))
+        img = img.clip(0, 255)
+        if levels < 256:
+            img = img // (256 // levels) * (256 // levels)
+        return img.astype(np.uint8)
+
+    few = colour(19, 24, 4)
+    few_a = np.concatenate([few, ((few[:, :, :1].astype(np.int32) * 3 + 40) % 256).astype(np.uint8)], axis=2)
+    many = colour(24, 30)                                               # > 256 colours: needs 16-bit indices
+    layouts = [("t16", colour(21, 29), "tga16"), ("t16_rle", colour(18, 22, 8), "tga16_rle"),
+               ("ga", rng.integers(0, 256, size=(15, 20, 2), dtype=np.uint8), "tga_ga"),
+               ("map24", few, "tga_map24"), ("map32_rle", few_a, "tga_map32_rle"), ("map16", colour(17, 13, 4), "tga_map16"),
+               ("map24_i16", many, "tga_map24_i16")]
+    textures = {"floor_kd.tga": (colour(40, 64), "tga16")}
+    materials = [MtlMaterial("floor", Ns=20.0, Ka=(0.6, 0.6, 0.6), Kd=(0.9, 0.9, 0.9), Ks=(0.2, 0.2, 0.2), map_Kd="floor_kd.tga")]
+    for k, (name, img, enc) in enumerate(layouts):
+        col, row = k % 4, k // 4
+        x0, y0 = -3.4 + col * 1.75, 0.15 + row * 1.45
+        z = -1.5 - 0.25 * row
+        add("panel_" + name, _quad(pos, nrm, uv, [(x0, y0, z), (x0 + 1.5, y0, z), (x0 + 1.5, y0 + 1.25, z), (x0, y0 + 1.25, z)], (0, 0, 1),
+                                   [(0, 0), (1, 0), (1, 1), (0, 1)]), name)
+        textures[name + ".tga"] = (img, enc)
+        materials.append(MtlMaterial(name, Ns=25.0, d=1.0, Ka=(0.7, 0.7, 0.7), Kd=(1.0, 1.0, 1.0), Ks=(0.15, 0.15, 0.15), map_Kd=name + ".tga"))
+    return ObjScene(
+        name="tga_gallery",
+        positions=np.array(pos, dtype=F32), texcoords=np.array(uv, dtype=F32), normals=np.array(nrm, dtype=F32),
+        groups=groups, materials=materials, textures=textures,
+        camera_position=(0.0, 1.7, 4.4), camera_facing=(0.0, -0.12, -1.0), fov=62.0)
+
+
 # ----------------------------------------------------------------------------------------
 # registry: name -> (factory, render defaults)
 # ----------------------------------------------------------------------------------------
@@ -1279,6 +1486,8 @@ SCENES = {
     "terrain_192": lambda: terrain(192, 8, size=192.0),       # 73,728 tris in 64 groups
     "many_materials": lambda: many_materials(),               # 1,282 tris, 42 materials (LDS table fallback), translucent clusters
     "textured_gallery": lambda: textured_gallery(),           # 192 tris, 7 materials, 14 texture files (row N1)
+    "tga_gallery": lambda: tga_gallery(),                     # 16 tris, 8 materials, 8 TGA files: 5-5-5 pixels, grey + alpha, colour maps
+    "bmp_gallery": lambda: bmp_gallery(),                     # 24 tris, 12 materials, 12 BMP files of every flavour the reference decodes
     "png_gallery": lambda: png_gallery(),                     # 26 tris, 13 materials, 13 PNG files: interlaced, 1 / 2 / 4-bit, colour keys
     "jpeg_gallery": lambda: jpeg_gallery(),                   # 28 tris, 14 materials, 16 JPEG files: baseline and progressive, every sampling layout
 }

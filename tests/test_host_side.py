@@ -157,6 +157,73 @@ def test_png_corner_cases_bit_identical_to_reference():
     assert (dims[:, :, 0] > 0).sum() == 13 and set(np.unique(dims[:, :, 2])) == {0, 1, 3, 4}
 
 
+def test_bmp_flavours_bit_identical_to_reference():
+    """The 12 files of the bmp_gallery scene - 24-bit bottom-up / top-down, OS/2 headers, 8- and 4-bit palettes, 16-bit
+    5-5-5 and 5-6-5 BITFIELDS (read twelve bytes late, like the reference's decoder does), 32-bit with a real and with an
+    all-zero alpha channel, a 108-byte header with A-R-G-B masks - decode to the reference's bytes and channel counts."""
+    g = load_golden("bmp_gallery_128x96")
+    hs = host_scene("bmp_gallery")
+    a = hs.arrays()
+    assert np.array_equal(a["group_texture_dims"], g["group_texture_dims"])
+    assert np.array_equal(_sums(a["group_texture_bytes"]), g["sum_group_texture_bytes"])
+    dims = a["group_texture_dims"].reshape(-1, 5, 3)
+    assert (dims[:, :, 0] > 0).sum() == 12 and set(np.unique(dims[:, :, 2])) == {0, 3, 4}
+
+
+def test_tga_corner_cases_bit_identical_to_reference_and_round_trip(tmp_path):
+    """The 8 files of the tga_gallery scene - 5-5-5 pixels raw and run-length, 16-bit grey + alpha, colour maps with 24-,
+    32- and 15-bit entries, 16-bit indices, image ids, non-zero first-entry fields - decode to the reference's bytes; and
+    every flavour returns what was written (5-5-5 as c * 255 / 31)."""
+    g = load_golden("tga_gallery_128x96")
+    hs = host_scene("tga_gallery")
+    a = hs.arrays()
+    assert np.array_equal(a["group_texture_dims"], g["group_texture_dims"])
+    assert np.array_equal(_sums(a["group_texture_bytes"]), g["sum_group_texture_bytes"])
+    dims = a["group_texture_dims"].reshape(-1, 5, 3)
+    assert (dims[:, :, 0] > 0).sum() == 8 and set(np.unique(dims[:, :, 2])) == {0, 2, 3, 4}
+    from par_raytracer_amd import scenes
+    lib = capi.host_lib()
+    rng = np.random.default_rng(12)
+    rgb = rng.integers(0, 256, size=(9, 11, 3), dtype=np.uint8)
+    rgb[2:5, 3:9] = rgb[2, 3]
+    few = (rng.integers(0, 3, size=(9, 11, 3), dtype=np.uint8) * 100 + 20).astype(np.uint8)
+    few[4:7, 2:8] = few[4, 2]
+    few_a = np.concatenate([few, few[:, :, :1] // 2 + 60], axis=2).astype(np.uint8)
+    ga = rng.integers(0, 256, size=(9, 11, 2), dtype=np.uint8)
+    q = (rgb >> 3).astype(np.uint32)
+    for enc, img, expect in (("tga16", rgb, (q * 255 // 31).astype(np.uint8)), ("tga16_rle", rgb, (q * 255 // 31).astype(np.uint8)), ("tga_ga", ga, ga),
+                             ("tga_map24", few, few), ("tga_map32_rle", few_a, few_a), ("tga_map24_i16", rgb, rgb),
+                             ("tga_map16", few, ((few >> 3).astype(np.uint32) * 255 // 31).astype(np.uint8))):
+        path = str(tmp_path / ("t_%s.tga" % enc))
+        scenes.write_texture(path, img, enc)
+        got = _load_texture(lib, path)
+        assert got is not None and got.shape == expect.shape and np.array_equal(got, expect), enc
+
+
+def test_bmp_flavours_round_trip(tmp_path):
+    """What was written comes back: exactly for palettes, 24- and 32-bit; within the 5-bit quantisation (top bits repeated
+    into the low ones) for 16-bit 5-5-5; a 32-bit file whose alpha bytes are all 0 comes back opaque."""
+    from par_raytracer_amd import scenes
+    lib = capi.host_lib()
+    rng = np.random.default_rng(8)
+    rgb = rng.integers(0, 256, size=(9, 7, 3), dtype=np.uint8)
+    rgba = np.concatenate([rgb, rng.integers(1, 256, size=(9, 7, 1), dtype=np.uint8)], axis=2)
+    few = (rng.integers(0, 2, size=(9, 7, 3), dtype=np.uint8) * 200 + 20).astype(np.uint8)
+    for enc, img in (("bmp", rgb), ("bmp_top", rgb), ("bmp_os2", rgb), ("bmp_os2_8", few), ("bmp8", few), ("bmp4", few), ("bmp32", rgba), ("bmp32_v4", rgba)):
+        path = str(tmp_path / ("t_%s.bmp" % enc))
+        scenes.write_texture(path, img, enc)
+        got = _load_texture(lib, path)
+        assert got is not None and got.shape == img.shape and np.array_equal(got, img), enc
+    path = str(tmp_path / "t16.bmp")
+    scenes.write_texture(path, rgb, "bmp16")
+    got = _load_texture(lib, path)
+    q = rgb >> 3
+    assert got is not None and np.array_equal(got, ((q << 3) | (q >> 2)).astype(np.uint8))
+    scenes.write_texture(path, rgb, "bmp32")                          # alpha bytes all 0
+    got = _load_texture(lib, path)
+    assert got is not None and got.shape == (9, 7, 4) and np.array_equal(got[:, :, :3], rgb) and np.all(got[:, :, 3] == 255)
+
+
 def test_png_variants_round_trip_with_every_filter(tmp_path):
     """Adam7, sub-byte depths and colour keys against what was written, at sizes that leave interlace passes empty, with
     all five scanline filters (the fixture above can only use None / Sub on sub-byte images: the reference's decoder reads

@@ -19,6 +19,10 @@ for enc, im in (("jpg", img1), ("jpg", img3), ("jpg422", img3), ("jpg440", img3)
 g2 = (img1 // 64).astype(np.uint8)
 for enc, im in (("png_i", img3), ("png16_i", img4), ("png_g1", g2 // 2), ("png_g2", g2), ("png_g4_i", img1 // 16), ("png_p4", img3 // 128 * 100), ("png_key", img3), ("png16_key_i", img3), ("png_g2_key", g2)):
     p = os.path.join(d, "s%d.img" % len(seeds)); scenes.write_texture(p, im, enc); seeds.append(open(p, "rb").read())
+for enc, im in (("bmp_top", img3), ("bmp_os2", img3), ("bmp_os2_8", img3 // 128 * 100), ("bmp8", img3 // 128 * 100), ("bmp4", img3 // 128 * 100), ("bmp16", img3), ("bmp16_565", img3), ("bmp32", img4), ("bmp32_v4", img4)):
+    p = os.path.join(d, "s%d.img" % len(seeds)); scenes.write_texture(p, im, enc); seeds.append(open(p, "rb").read())
+for enc, im in (("tga16", img3), ("tga16_rle", img3 // 64 * 64), ("tga_ga", img4[:, :, :2]), ("tga_map24", img3 // 128 * 100), ("tga_map32_rle", img4 // 128 * 100), ("tga_map16", img3 // 128 * 100), ("tga_map24_i16", img3)):
+    p = os.path.join(d, "s%d.img" % len(seeds)); scenes.write_texture(p, im, enc); seeds.append(open(p, "rb").read())
 n_ok = n_fail = 0
 for it in range(int(os.environ.get("PRT_FUZZ_ITERATIONS", "12000"))):
     b = bytearray(seeds[it % len(seeds)])
