@@ -186,7 +186,7 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_pool(const PoolArgs * args, De
     float4 * const ct = cd + cap;                                                                     \
     (void)hits; (void)sq_o; (void)sq_c; (void)sq_d; (void)ct
 
-    unsigned long long ph_topup = 0ull, ph_trace = 0ull, ph_shade = 0ull;      // COUNT: wave-cycles per phase
+    unsigned long long ph_topup = 0ull, ph_trace = 0ull, ph_shade = 0ull, ph_final = 0ull;      // COUNT: wave-cycles per phase
     const unsigned long long ph_begin = COUNT ? __builtin_readcyclecounter() : 0ull;
     for (;;) {
         const unsigned long long ph_t0 = COUNT ? __builtin_readcyclecounter() : 0ull;
@@ -369,6 +369,7 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_pool(const PoolArgs * args, De
                 // RenderPixel's loops (main.cpp:236-258) one step at a time: store the sample, apply the stopping rule,
                 // start the next sample on the same RNG stream.
                 const size_t n_px = B.n_samples;
+                const unsigned long long ph_f0 = COUNT ? __builtin_readcyclecounter() : 0ull;
                 for (unsigned int b0 = 0; b0 < n_f; b0 += 64u) {
                     const unsigned int i = b0 + lane;
                     const bool live = i < n_f;
@@ -426,6 +427,7 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_pool(const PoolArgs * args, De
                 }
                 emit.m_f = 0;                                                       // the list is consumed; shading refills it from 0
                 pool_fence();
+                if (COUNT) ph_final += __builtin_readcyclecounter() - ph_f0;
             }
             for (unsigned int b0 = 0; b0 < n_c; b0 += 64u) {
                 const unsigned int i = b0 + lane;
@@ -487,6 +489,7 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_pool(const PoolArgs * args, De
             atomicAdd(&ctr->phase_cycles[1], ph_trace);
             atomicAdd(&ctr->phase_cycles[2], ph_shade);
             atomicAdd(&ctr->phase_cycles[3], __builtin_readcyclecounter() - ph_begin);
+            if (ADAPT) atomicAdd(&ctr->phase_cycles[4], ph_final);
         }
     }
 }

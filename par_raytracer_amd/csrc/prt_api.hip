@@ -878,6 +878,9 @@ int render_pixels(prt_ctx * ctx, const prt_camera * cam_in, const prt_params * p
             fprintf(stderr, "[prt] k_pool wave time by phase: top-up %.1f%%, trace %.1f%%, shade %.1f%% of the main loop\n",
                     100.0 * (double)h.phase_cycles[0] / (double)h.phase_cycles[3], 100.0 * (double)h.phase_cycles[1] / (double)h.phase_cycles[3],
                     100.0 * (double)h.phase_cycles[2] / (double)h.phase_cycles[3]);
+        if (getenv("PRT_DEBUG_UTIL") && h.phase_cycles[3] && h.phase_cycles[4])
+            fprintf(stderr, "[prt] k_pool adaptive finalise step (store the sample, variance rule, next camera ray): %.1f%% of the main loop\n",
+                    100.0 * (double)h.phase_cycles[4] / (double)h.phase_cycles[3]);
         if (getenv("PRT_DEBUG_UTIL") && h.wave_node_steps)
             fprintf(stderr, "[prt] deepest stack %llu entries (LDS column %u, bound %u); %llu of %llu node visits (%.1f%%) hit no child after a hit was known\n",
                     (unsigned long long)h.max_sp, stack_entries, ctx->stack_bound, (unsigned long long)h.culled,
