@@ -44,6 +44,28 @@ def test_host_library_exports_every_declared_symbol():
         assert hasattr(lib, n), "libprt_host.so does not export %s" % n
 
 
+def test_public_headers_are_plain_c(tmp_path):
+    """include/*.h is the drop-in boundary: it must compile as C99 (no C++, no torch types) and a C program must link
+    against the library with nothing but the header."""
+    import shutil
+    import subprocess
+    if not shutil.which("gcc"):
+        pytest.skip("no C compiler")
+    src = tmp_path / "abi.c"
+    src.write_text('#include "prt.h"\n#include "prt_host.h"\n#include "prt_key.h"\n#include <stdio.h>\n'
+                   'int main(void) {\n'
+                   '    prt_params p; prt_camera c; prt_counters k; prt_scene_desc d;\n'
+                   '    (void)p; (void)c; (void)k; (void)d;\n'
+                   '    printf("%d %u\\n", prt_abi_version(), (unsigned)prt_shard_rows(1080, 8, 3, 8));\n'
+                   '    return prt_last_error(0) ? 0 : 1;\n}\n')
+    pkg = os.path.join(ROOT, "par_raytracer_amd")
+    exe = tmp_path / "abi"
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe),
+                    "-L", pkg, "-lprt_hip", "-Wl,-rpath," + pkg], check=True)
+    out = subprocess.run([str(exe)], check=True, stdout=subprocess.PIPE).stdout.decode().split()
+    assert int(out[0]) == capi.hip_lib().prt_abi_version() and int(out[1]) == 136          # 17 of the 135 row blocks: 16 x 8 + 8 rows
+
+
 def test_struct_sizes_match_the_reference_layouts():
     # SURVEY.md §8a A19 [probed] sizes of the reference structs these mirror
     assert C.sizeof(capi.PrtBSphere) == 24          # BoundingSphere
