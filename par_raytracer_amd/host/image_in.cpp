@@ -13,9 +13,11 @@
 //          entries), 15 / 16-bit 5-5-5, 16-bit grey + alpha, 8 / 24 / 32 bits, BGR(A) -> RGB(A), bottom-up files flipped;
 //   * BMP  4- / 8-bit palettes, 16-bit (5-5-5 or masks), 24-bit, 32-bit (plain or masks), OS/2 and V4 / V5 headers,
 //          BGR(A) -> RGB(A), bottom-up files flipped; channels and alpha handling as in the reference's decoder;
-//   * PNM  binary P5 (grey) / P6 (RGB), maxval <= 255.
+//   * PNM  binary P5 (grey) / P6 (RGB), maxval <= 255;
+//   * GIF  the first image on the logical screen, always RGBA (background and transparent pixels: alpha 0), interlaced
+//          or not, global or local colour table.
 //   * JPEG baseline and progressive (image_jpeg.cpp): grey -> 1 channel, colour -> 3, every sampling layout, restart intervals.
-// Anything else (arithmetic-coded JPEG, run-length / 1-bit BMP, GIF, PSD, HDR ...) is reported and the texture slot
+// Anything else (arithmetic-coded JPEG, run-length / 1-bit BMP, PSD, HDR, PIC ...) is reported and the texture slot
 // stays empty, which is how the reference treats a file its decoder rejects (obj_parser.cpp:201-204).
 // tests/test_host_side.py compares the decoded bytes with the reference's on generated files of every kind.
 #include <zlib.h>
@@ -492,6 +494,162 @@ bool DecodeBmp(const std::vector<u8> & d, Image * out) {
     return true;
 }
 
+// ---- GIF ------------------------------------------------------------------------------------------------
+// The reference decoder's reading of a GIF: the FIRST image of the file on the logical screen, always 4 channels.  The
+// screen starts as the background colour (global palette entry `bgindex`; black without a global palette) with alpha 0;
+// the image's pixels overwrite it with alpha 255, except pixels of the transparent index of a preceding graphic control
+// extension, which leave the background (alpha 0) in place.  Interlaced images are de-interlaced.
+bool DecodeGif(const std::vector<u8> & d, Image * out) {
+    if (d.size() < 13 || memcmp(d.data(), "GIF8", 4) != 0 || (d[4] != '7' && d[4] != '9') || d[5] != 'a') return Fail("not a GIF");
+    const u32 W = Le16(&d[6]), H = Le16(&d[8]), flags = d[10], bgindex = d[11];
+    if (!W || !H) return Fail("empty GIF");
+    if ((unsigned long long)W * H > (1ull << 28)) return Fail("GIF larger than 2^28 pixels");
+    size_t pos = 13;
+    u8 gpal[256][4], lpal[256][4];
+    memset(gpal, 0, sizeof(gpal));
+    memset(lpal, 0, sizeof(lpal));
+    auto table = [&](u8 pal[256][4], u32 n, int transp) -> bool {
+        if (pos + (size_t)n * 3 > d.size()) return false;
+        for (u32 i = 0; i < n; ++i) {
+            pal[i][0] = d[pos]; pal[i][1] = d[pos + 1]; pal[i][2] = d[pos + 2];
+            pal[i][3] = transp == (int)i ? 0 : 255;
+            pos += 3;
+        }
+        return true;
+    };
+    if ((flags & 0x80u) && !table(gpal, 2u << (flags & 7u), -1)) return Fail("GIF colour table truncated");
+    // a header that promises far more pixels than the file could code (LZW: at most ~4096 pixels per 12-bit code)
+    if ((unsigned long long)W * H > ((unsigned long long)d.size() + 64u) * 4096ull) return Fail("GIF header promises more pixels than the file can hold");
+    int eflags = 0, transparent = -1;
+    for (;;) {
+        if (pos >= d.size()) return Fail("GIF without an image");
+        const u8 tag = d[pos++];
+        if (tag == 0x3B) return Fail("GIF without an image");
+        if (tag == 0x21) {                                       // extension
+            if (pos >= d.size()) return Fail("GIF extension truncated");
+            const u8 label = d[pos++];
+            if (label == 0xF9) {                                 // graphic control: flags, delay, transparent index
+                if (pos >= d.size()) return Fail("GIF extension truncated");
+                const u32 len = d[pos++];
+                if (len == 4) {
+                    if (pos + 4 > d.size()) return Fail("GIF extension truncated");
+                    eflags = d[pos]; transparent = d[pos + 3];
+                    pos += 4;
+                } else {
+                    pos += len;
+                    continue;                                    // (the library goes straight back to the next block here)
+                }
+            }
+            for (;;) {                                           // skip the data sub-blocks
+                if (pos >= d.size()) return Fail("GIF extension truncated");
+                const u32 len = d[pos++];
+                if (!len) break;
+                pos += len;
+            }
+            continue;
+        }
+        if (tag != 0x2C) return Fail("unknown GIF block");
+        if (pos + 9 > d.size()) return Fail("GIF image descriptor truncated");
+        const u32 x0 = Le16(&d[pos]), y0 = Le16(&d[pos + 2]), w = Le16(&d[pos + 4]), h = Le16(&d[pos + 6]), lflags = d[pos + 8];
+        pos += 9;
+        if (x0 + w > W || y0 + h > H) return Fail("bad GIF image descriptor");
+        const u8 (*pal)[4];
+        if (lflags & 0x80u) {
+            if (!table(lpal, 2u << (lflags & 7u), (eflags & 1) ? transparent : -1)) return Fail("GIF colour table truncated");
+            pal = lpal;
+        } else if (flags & 0x80u) {
+            if (transparent >= 0 && (eflags & 1)) gpal[transparent][3] = 0;
+            pal = gpal;
+        } else {
+            return Fail("GIF without a colour table");
+        }
+        out->w = W; out->h = H; out->channels = 4;
+        out->px.resize((size_t)W * H * 4);
+        for (size_t i = 0; i < (size_t)W * H; ++i) {             // the logical screen: background colour, alpha 0
+            u8 * o = &out->px[i * 4];
+            o[0] = gpal[bgindex][0]; o[1] = gpal[bgindex][1]; o[2] = gpal[bgindex][2]; o[3] = 0;
+        }
+        // LZW (variable code size, least significant bit first, data in sub-blocks)
+        if (pos >= d.size()) return Fail("GIF raster truncated");
+        const u32 lzw_cs = d[pos++];
+        if (lzw_cs > 12) return Fail("bad GIF code size");
+        const int clear = 1 << lzw_cs;
+        struct Code { int16_t prefix; u8 first, suffix; };
+        std::vector<Code> codes(8192);
+        for (int i = 0; i < clear; ++i) { codes[i].prefix = -1; codes[i].first = (u8)i; codes[i].suffix = (u8)i; }
+        int codesize = (int)lzw_cs + 1, codemask = (1 << codesize) - 1, avail = clear + 2, oldcode = -1;
+        bool first = true;
+        uint32_t bits = 0;
+        int valid = 0;
+        u32 block = 0;
+        // pixel cursor with the four interlace passes (rows 0, 8, ..; 4, 12, ..; 2, 6, ..; 1, 3, ..)
+        const bool interlaced = (lflags & 0x40u) != 0;
+        u32 cx = 0, cy = 0, step = interlaced ? 8 : 1;
+        int parse = interlaced ? 3 : 0;
+        std::vector<u8> chain;
+        auto emit = [&](u8 index) {
+            if (cy >= h) return;
+            const u8 * c = pal[index];
+            if (c[3] >= 128) {
+                u8 * o = &out->px[((size_t)(y0 + cy) * W + x0 + cx) * 4];
+                o[0] = c[0]; o[1] = c[1]; o[2] = c[2]; o[3] = c[3];
+            }
+            if (++cx >= w) {
+                cx = 0;
+                cy += step;
+                while (cy >= h && parse > 0) {
+                    step = 1u << parse;
+                    cy = step >> 1;
+                    --parse;
+                }
+            }
+        };
+        if (w == 0) return true;                                 // an empty image: the background stands
+        for (;;) {
+            if (valid < codesize) {
+                if (block == 0) {
+                    if (pos >= d.size()) return true;            // the data just stops: what was decoded stands (as in the library)
+                    block = d[pos++];
+                    if (block == 0) return true;
+                }
+                --block;
+                const u32 byte = pos < d.size() ? d[pos] : 0;
+                ++pos;
+                bits |= byte << valid;
+                valid += 8;
+                continue;
+            }
+            const int code = (int)(bits & (uint32_t)codemask);
+            bits >>= codesize;
+            valid -= codesize;
+            if (code == clear) {
+                codesize = (int)lzw_cs + 1; codemask = (1 << codesize) - 1; avail = clear + 2; oldcode = -1;
+                first = false;
+            } else if (code == clear + 1) {
+                return true;                                     // end of the image
+            } else if (code <= avail) {
+                if (first) return Fail("GIF raster without a clear code");
+                if (oldcode >= 0) {
+                    if (avail >= 4096) return Fail("too many GIF codes");
+                    Code & n = codes[avail++];
+                    n.prefix = (int16_t)oldcode;
+                    n.first = codes[oldcode].first;
+                    n.suffix = code == avail ? n.first : codes[code].first;
+                } else if (code == avail) {
+                    return Fail("illegal code in GIF raster");
+                }
+                chain.clear();
+                for (int c = code; c >= 0; c = codes[c].prefix) chain.push_back(codes[c].suffix);
+                for (size_t i = chain.size(); i-- > 0;) emit(chain[i]);
+                if ((avail & codemask) == 0 && avail <= 0x0FFF) { ++codesize; codemask = (1 << codesize) - 1; }
+                oldcode = code;
+            } else {
+                return Fail("illegal code in GIF raster");
+            }
+        }
+    }
+}
+
 // ---- PNM ------------------------------------------------------------------------------------------------
 bool PnmNumber(const std::vector<u8> & d, size_t * pos, u32 * value) {
     for (;;) {
@@ -533,6 +691,7 @@ Texture * LoadTexture(const char * filename) {
         const std::vector<u8> & d = file.data;
         if (d.size() >= 8 && d[0] == 0x89 && d[1] == 'P') ok = DecodePng(d, &img);
         else if (d.size() >= 2 && d[0] == 'B' && d[1] == 'M') ok = DecodeBmp(d, &img);
+        else if (d.size() >= 6 && d[0] == 'G' && d[1] == 'I' && d[2] == 'F' && d[3] == '8') ok = DecodeGif(d, &img);
         else if (d.size() >= 2 && d[0] == 'P' && (d[1] == '5' || d[1] == '6')) ok = DecodePnm(d, &img);
         else if (d.size() >= 3 && d[0] == 0xFF && d[1] == 0xD8) {
             const char * err = prt_jpeg::Decode(d, &img.w, &img.h, &img.channels, &img.px);

@@ -383,6 +383,88 @@ def write_bmp(path: str, img: np.ndarray, kind: str = "24") -> None:
         f.write(rows.tobytes())
 
 
+def write_gif(path: str, img: np.ndarray, interlace: bool = False, transparent: bool = False, local_table: bool = False,
+              canvas: Optional[Tuple[int, int, int, int]] = None, bgindex: int = 0) -> None:
+    """GIF89a with one image.  img: [h, w, 3] with at most 256 colours (255 with `transparent`: pixels equal to img[0, 0]
+    then get the transparent index of a graphic control extension).  `canvas` = (W, H, x, y): the image sits at (x, y) on a
+    larger logical screen.  `local_table`: the palette is the image's local colour table (a 2-entry global one remains)."""
+    import struct
+    a = np.asarray(img, dtype=np.uint8)
+    h, w, _ = a.shape
+    colours, index = np.unique(a.reshape(-1, 3), axis=0, return_inverse=True)
+    index = index.reshape(h, w)
+    n = len(colours)
+    assert n <= 256
+    bits = max(1, (max(n, 2) - 1).bit_length())
+    table = np.zeros((1 << bits, 3), dtype=np.uint8)
+    table[:n] = colours
+    W, H, x0, y0 = canvas if canvas else (w, h, 0, 0)
+    out = bytearray(b"GIF89a")
+    if local_table:
+        out += struct.pack("<HHBBB", W, H, 0x80 | 0, bgindex & 1, 0) + bytes([200, 30, 90, 10, 220, 140])       # 2-entry global table
+    else:
+        out += struct.pack("<HHBBB", W, H, 0x80 | (bits - 1), bgindex, 0) + table.tobytes()
+    out += b"\x21\xFE\x05hello\x00"                                                                                  # a comment extension
+    if transparent:
+        out += b"\x21\xF9\x04" + bytes([0x01, 0, 0, int(index[0, 0])]) + b"\x00"
+    out += b"\x2C" + struct.pack("<HHHHB", x0, y0, w, h, (0x40 if interlace else 0) | ((0x80 | (bits - 1)) if local_table else 0))
+    if local_table:
+        out += table.tobytes()
+    rows = list(range(h))
+    if interlace:
+        rows = list(range(0, h, 8)) + list(range(4, h, 8)) + list(range(2, h, 4)) + list(range(1, h, 2))
+    data = index[rows].reshape(-1)
+    # LZW, variable code size, codes packed least significant bit first
+    min_cs = max(2, bits)
+    clear, eoi = 1 << min_cs, (1 << min_cs) + 1
+    acc, nacc, stream = 0, 0, bytearray()
+
+    def put(code, size):
+        nonlocal acc, nacc
+        acc |= code << nacc
+        nacc += size
+        while nacc >= 8:
+            stream.append(acc & 0xFF)
+            acc >>= 8
+            nacc -= 8
+
+    size = min_cs + 1
+    dictionary = {}
+    nxt = eoi + 1
+    put(clear, size)
+    prefix = int(data[0])
+    for v in data[1:]:
+        v = int(v)
+        key = (prefix, v)
+        if key in dictionary:
+            prefix = dictionary[key]
+            continue
+        put(prefix, size)
+        if nxt < 4096:
+            dictionary[key] = nxt
+            nxt += 1
+            if nxt - 1 == (1 << size) and size < 12:
+                size += 1
+        else:
+            put(clear, size)
+            dictionary = {}
+            nxt = eoi + 1
+            size = min_cs + 1
+        prefix = v
+    put(prefix, size)
+    put(eoi, size)
+    if nacc:
+        stream.append(acc & 0xFF)
+    out.append(min_cs)
+    for i in range(0, len(stream), 255):
+        chunk = stream[i:i + 255]
+        out.append(len(chunk))
+        out += chunk
+    out += b"\x00\x3B"
+    with open(path, "wb") as f:
+        f.write(bytes(out))
+
+
 def write_pnm(path: str, img: np.ndarray) -> None:
     """Binary PGM (grey) / PPM (RGB) with a comment line in the header."""
     a = np.asarray(img, dtype=np.uint8)
@@ -856,6 +938,11 @@ def write_texture(path: str, img: np.ndarray, encoding: str) -> None:
         "bmp32": lambda: write_bmp(path, img, "32"),
         "bmp32_v4": lambda: write_bmp(path, img, "32_v4"),
         "pnm": lambda: write_pnm(path, img),
+        "gif": lambda: write_gif(path, img),
+        "gif_i": lambda: write_gif(path, img, interlace=True),
+        "gif_t": lambda: write_gif(path, img, transparent=True),
+        "gif_local_i_t": lambda: write_gif(path, img, interlace=True, transparent=True, local_table=True),
+        "gif_canvas": lambda: write_gif(path, img, canvas=(np.asarray(img).shape[1] + 7, np.asarray(img).shape[0] + 5, 3, 2), bgindex=1),
         "jpg": lambda: write_jpeg(path, img),                                             # 4:4:4 (or grey)
         "jpg422": lambda: write_jpeg(path, img, sampling=(2, 1)),
         "jpg440": lambda: write_jpeg(path, img, sampling=(1, 2)),
@@ -1462,6 +1549,51 @@ def tga_gallery() -> ObjScene:
         camera_position=(0.0, 1.7, 4.4), camera_facing=(0.0, -0.12, -1.0), fov=62.0)
 
 
+def gif_gallery() -> ObjScene:
+    """GIF diffuse maps the way the reference's decoder reads them (first image, always RGBA): plain, interlaced, with a
+    transparent index (those pixels keep the background colour with alpha 0), a local colour table, an image placed on a
+    larger logical screen, and a 256-colour image whose LZW stream fills and resets the code table."""
+    rng = np.random.default_rng(20241008)
+    pos, nrm, uv = [], [], []
+    groups = []
+
+    def add(name, tris, material):
+        groups.append(ObjGroup(name, _faces_same_index(np.array(tris)), material))
+
+    add("floor", _quad(pos, nrm, uv, [(-4, 0, 3), (4, 0, 3), (4, 0, -3), (-4, 0, -3)], (0, 1, 0),
+                       [(0, 0), (2, 0), (2, 1.5), (0, 1.5)]), "floor")
+
+    def colour(h, w, levels):
+        yy, xx = np.mgrid[0:h, 0:w]
+        img = np.stack([40 + 200 * ((xx // 4 + yy // 3) % 2), 128 + 100 * np.sin(yy * 0.6), 30 + 6 * xx], axis=2)
+        return (img.clip(0, 255) // (256 // levels) * (256 // levels)).astype(np.uint8)
+
+    def keyed(img):
+        out = img.copy()
+        out[2::4, 1::3] = img[0, 0]
+        return out
+
+    noisy = rng.integers(0, 256, size=(48, 56, 1), dtype=np.uint8).repeat(3, axis=2)
+    noisy[:, :, 1] = 255 - noisy[:, :, 0]
+    layouts = [("plain", colour(25, 33, 4), "gif"), ("inter", colour(30, 21, 4), "gif_i"), ("transp", keyed(colour(19, 28, 4)), "gif_t"),
+               ("local", keyed(colour(27, 18, 4)), "gif_local_i_t"), ("canvas", colour(16, 22, 4), "gif_canvas"), ("noisy", noisy, "gif_i")]
+    textures = {"floor_kd.gif": (colour(40, 64, 8), "gif")}
+    materials = [MtlMaterial("floor", Ns=20.0, Ka=(0.6, 0.6, 0.6), Kd=(0.9, 0.9, 0.9), Ks=(0.2, 0.2, 0.2), map_Kd="floor_kd.gif")]
+    for k, (name, img, enc) in enumerate(layouts):
+        col, row = k % 3, k // 3
+        x0, y0 = -3.3 + col * 2.3, 0.15 + row * 1.45
+        z = -1.5 - 0.25 * row
+        add("panel_" + name, _quad(pos, nrm, uv, [(x0, y0, z), (x0 + 2.0, y0, z), (x0 + 2.0, y0 + 1.25, z), (x0, y0 + 1.25, z)], (0, 0, 1),
+                                   [(0, 0), (1, 0), (1, 1), (0, 1)]), name)
+        textures[name + ".gif"] = (img, enc)
+        materials.append(MtlMaterial(name, Ns=25.0, d=1.0, Ka=(0.7, 0.7, 0.7), Kd=(1.0, 1.0, 1.0), Ks=(0.15, 0.15, 0.15), map_Kd=name + ".gif"))
+    return ObjScene(
+        name="gif_gallery",
+        positions=np.array(pos, dtype=F32), texcoords=np.array(uv, dtype=F32), normals=np.array(nrm, dtype=F32),
+        groups=groups, materials=materials, textures=textures,
+        camera_position=(0.0, 1.7, 4.4), camera_facing=(0.0, -0.12, -1.0), fov=62.0)
+
+
 # ----------------------------------------------------------------------------------------
 # registry: name -> (factory, render defaults)
 # ----------------------------------------------------------------------------------------
@@ -1486,6 +1618,7 @@ SCENES = {
     "terrain_192": lambda: terrain(192, 8, size=192.0),       # 73,728 tris in 64 groups
     "many_materials": lambda: many_materials(),               # 1,282 tris, 42 materials (LDS table fallback), translucent clusters
     "textured_gallery": lambda: textured_gallery(),           # 192 tris, 7 materials, 14 texture files (row N1)
+    "gif_gallery": lambda: gif_gallery(),                     # 14 tris, 7 materials, 7 GIF files: interlaced, transparent, local tables, offset images
     "tga_gallery": lambda: tga_gallery(),                     # 16 tris, 8 materials, 8 TGA files: 5-5-5 pixels, grey + alpha, colour maps
     "bmp_gallery": lambda: bmp_gallery(),                     # 24 tris, 12 materials, 12 BMP files of every flavour the reference decodes
     "png_gallery": lambda: png_gallery(),                     # 26 tris, 13 materials, 13 PNG files: interlaced, 1 / 2 / 4-bit, colour keys

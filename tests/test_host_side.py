@@ -222,6 +222,42 @@ def test_tga_corner_cases_bit_identical_to_reference_and_round_trip(tmp_path):
         assert got is not None and got.shape == expect.shape and np.array_equal(got, expect), enc
 
 
+def test_gif_bit_identical_to_reference_and_round_trip(tmp_path):
+    """The 7 files of the gif_gallery scene decode to the reference's bytes: always RGBA, the first image on the logical
+    screen, background and transparent pixels with alpha 0, interlaced rows back in place, local colour tables, an LZW
+    stream long enough to fill the code table.  And what was written comes back."""
+    g = load_golden("gif_gallery_128x96")
+    hs = host_scene("gif_gallery")
+    a = hs.arrays()
+    assert np.array_equal(a["group_texture_dims"], g["group_texture_dims"])
+    assert np.array_equal(_sums(a["group_texture_bytes"]), g["sum_group_texture_bytes"])
+    dims = a["group_texture_dims"].reshape(-1, 5, 3)
+    assert (dims[:, :, 0] > 0).sum() == 7 and set(np.unique(dims[:, :, 2])) == {0, 4}
+    from par_raytracer_amd import scenes
+    lib = capi.host_lib()
+    rng = np.random.default_rng(5)
+    img = (rng.integers(0, 6, size=(23, 31, 3)) * 45 + 10).astype(np.uint8)
+    img[5:12, 4:20] = img[0, 0]
+    key = (img == img[0, 0]).all(axis=2)
+    for enc in ("gif", "gif_i", "gif_t", "gif_local_i_t"):
+        path = str(tmp_path / ("t_%s.gif" % enc))
+        scenes.write_texture(path, img, enc)
+        got = _load_texture(lib, path)
+        assert got is not None and got.shape == (23, 31, 4), enc
+        if "t" in enc.split("_", 1)[-1] and enc != "gif_i":
+            assert np.array_equal(got[:, :, :3][~key], img[~key]) and np.all(got[:, :, 3][~key] == 255) and np.all(got[:, :, 3][key] == 0), enc
+        else:
+            assert np.array_equal(got[:, :, :3], img) and np.all(got[:, :, 3] == 255), enc
+    path = str(tmp_path / "canvas.gif")
+    scenes.write_texture(path, img, "gif_canvas")
+    got = _load_texture(lib, path)
+    assert got is not None and got.shape == (28, 38, 4)
+    assert np.array_equal(got[2:25, 3:34, :3], img) and np.all(got[2:25, 3:34, 3] == 255)
+    outside = np.ones((28, 38), dtype=bool)
+    outside[2:25, 3:34] = False
+    assert np.all(got[:, :, 3][outside] == 0)
+
+
 def test_bmp_flavours_round_trip(tmp_path):
     """What was written comes back: exactly for palettes, 24- and 32-bit; within the 5-bit quantisation (top bits repeated
     into the low ones) for 16-bit 5-5-5; a 32-bit file whose alpha bytes are all 0 comes back opaque."""
