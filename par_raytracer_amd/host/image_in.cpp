@@ -15,9 +15,10 @@
 //          BGR(A) -> RGB(A), bottom-up files flipped; channels and alpha handling as in the reference's decoder;
 //   * PNM  binary P5 (grey) / P6 (RGB), maxval <= 255;
 //   * GIF  the first image on the logical screen, always RGBA (background and transparent pixels: alpha 0), interlaced
-//          or not, global or local colour table.
+//          or not, global or local colour table;
+//   * PSD  the flattened RGB composite, 8 / 16 bits, raw or PackBits, always RGBA, colours un-blended from white.
 //   * JPEG baseline and progressive (image_jpeg.cpp): grey -> 1 channel, colour -> 3, every sampling layout, restart intervals.
-// Anything else (arithmetic-coded JPEG, run-length / 1-bit BMP, PSD, HDR, PIC ...) is reported and the texture slot
+// Anything else (arithmetic-coded JPEG, run-length / 1-bit BMP, HDR, PIC ...) is reported and the texture slot
 // stays empty, which is how the reference treats a file its decoder rejects (obj_parser.cpp:201-204).
 // tests/test_host_side.py compares the decoded bytes with the reference's on generated files of every kind.
 #include <zlib.h>
@@ -650,6 +651,86 @@ bool DecodeGif(const std::vector<u8> & d, Image * out) {
     }
 }
 
+// ---- PSD ------------------------------------------------------------------------------------------------
+// The reference decoder's reading of a Photoshop file: the flattened composite at the end of the file, RGB mode, 8 or 16
+// bits (high byte kept), raw or PackBits rows; ALWAYS four channels - missing colour channels are 0, a missing alpha is 255 -
+// and where 0 < alpha < 255 the colours are un-blended from the white matte in float: c / a' + 255 (1 - 1 / a'), a' = a / 255.
+u32 Be16(const u8 * p) { return ((u32)p[0] << 8) | (u32)p[1]; }
+
+bool DecodePsd(const std::vector<u8> & d, Image * out) {
+    if (d.size() < 26 + 12 + 2 || Be32(&d[0]) != 0x38425053u) return Fail("not a PSD");
+    if (Be16(&d[4]) != 1) return Fail("unsupported PSD version");
+    const u32 channels = Be16(&d[12]);
+    if (channels > 16) return Fail("unsupported number of PSD channels");
+    const u32 h = Be32(&d[14]), w = Be32(&d[18]), depth = Be16(&d[22]), mode = Be16(&d[24]);
+    if (depth != 8 && depth != 16) return Fail("PSD bit depth is not 8 or 16");
+    if (mode != 3) return Fail("PSD is not in RGB colour mode");
+    if (!w || !h || (unsigned long long)w * h > (1ull << 28)) return Fail("bad PSD size");
+    size_t pos = 26;
+    for (int section = 0; section < 3; ++section) {              // colour mode data, image resources, layers and masks
+        if (pos + 4 > d.size()) return Fail("PSD truncated");
+        const u32 len = Be32(&d[pos]);
+        pos += 4;
+        if ((size_t)len > d.size() - pos) return Fail("PSD truncated");
+        pos += len;
+    }
+    if (pos + 2 > d.size()) return Fail("PSD truncated");
+    const u32 compression = Be16(&d[pos]);
+    pos += 2;
+    if (compression > 1) return Fail("unknown PSD compression");
+    if (compression == 1 && depth == 16) return Fail("run-length coded 16-bit PSD is not supported");
+    const size_t n = (size_t)w * h;
+    if (n > ((size_t)d.size() + 64) * 130) return Fail("PSD header promises more pixels than the file can hold");
+    std::vector<u8> px(n * 4);
+    if (compression) {
+        const size_t table = (size_t)h * channels * 2;           // the per-row byte counts are not needed
+        if (table > d.size() - pos) return Fail("PSD truncated");
+        pos += table;
+    }
+    for (u32 c = 0; c < 4; ++c) {
+        u8 * p = px.data() + c;
+        if (c >= channels) {
+            for (size_t i = 0; i < n; ++i, p += 4) *p = c == 3 ? 255 : 0;
+        } else if (compression) {                                // PackBits over the whole channel
+            size_t count = 0;
+            while (count < n) {
+                if (pos >= d.size()) return Fail("bad PSD run-length data");
+                u32 len = d[pos++];
+                if (len == 128) continue;
+                if (len < 128) {
+                    ++len;
+                    if (len > n - count || (size_t)len > d.size() - pos) return Fail("bad PSD run-length data");
+                    for (u32 k = 0; k < len; ++k, p += 4) *p = d[pos++];
+                } else {
+                    len = 257 - len;
+                    if (len > n - count || pos >= d.size()) return Fail("bad PSD run-length data");
+                    const u8 v = d[pos++];
+                    for (u32 k = 0; k < len; ++k, p += 4) *p = v;
+                }
+                count += len;
+            }
+        } else {
+            const size_t bytes = depth == 16 ? 2 : 1;
+            if (n * bytes > d.size() - pos) return Fail("PSD pixel data truncated");
+            for (size_t i = 0; i < n; ++i, p += 4, pos += bytes) *p = d[pos];      // 16 bit: the high byte comes first
+        }
+    }
+    if (channels >= 4) {
+        for (size_t i = 0; i < n; ++i) {
+            u8 * q = &px[4 * i];
+            if (q[3] != 0 && q[3] != 255) {
+                const float a = q[3] / 255.0f;
+                const float ra = 1.0f / a;
+                const float inv_a = 255.0f * (1 - ra);
+                for (int k = 0; k < 3; ++k) q[k] = (u8)(int)(q[k] * ra + inv_a);
+            }
+        }
+    }
+    out->w = w; out->h = h; out->channels = 4;
+    out->px.swap(px);
+    return true;
+}
+
 // ---- PNM ------------------------------------------------------------------------------------------------
 bool PnmNumber(const std::vector<u8> & d, size_t * pos, u32 * value) {
     for (;;) {
@@ -692,6 +773,7 @@ Texture * LoadTexture(const char * filename) {
         if (d.size() >= 8 && d[0] == 0x89 && d[1] == 'P') ok = DecodePng(d, &img);
         else if (d.size() >= 2 && d[0] == 'B' && d[1] == 'M') ok = DecodeBmp(d, &img);
         else if (d.size() >= 6 && d[0] == 'G' && d[1] == 'I' && d[2] == 'F' && d[3] == '8') ok = DecodeGif(d, &img);
+        else if (d.size() >= 4 && d[0] == '8' && d[1] == 'B' && d[2] == 'P' && d[3] == 'S') ok = DecodePsd(d, &img);
         else if (d.size() >= 2 && d[0] == 'P' && (d[1] == '5' || d[1] == '6')) ok = DecodePnm(d, &img);
         else if (d.size() >= 3 && d[0] == 0xFF && d[1] == 0xD8) {
             const char * err = prt_jpeg::Decode(d, &img.w, &img.h, &img.channels, &img.px);

@@ -465,6 +465,46 @@ def write_gif(path: str, img: np.ndarray, interlace: bool = False, transparent: 
         f.write(bytes(out))
 
 
+def write_psd(path: str, img: np.ndarray, rle: bool = False, sixteen_bit: bool = False) -> None:
+    """Photoshop file with only the flattened composite: RGB mode, img [h, w, 3 or 4], planar channels, raw or PackBits
+    rows; `sixteen_bit` stores every sample as (v, 255 - v)."""
+    import struct
+    a = np.asarray(img, dtype=np.uint8)
+    h, w, c = a.shape
+    out = bytearray(b"8BPS" + struct.pack(">H6xHIIHH", 1, c, h, w, 16 if sixteen_bit else 8, 3))
+    out += struct.pack(">I", 0)                                         # colour mode data
+    out += struct.pack(">I", 12) + b"8BIM\x03\xed\x00\x00\x00\x00\x00\x00"   # one (empty) image resource
+    out += struct.pack(">I", 0)                                         # layers and masks
+    out += struct.pack(">H", 1 if rle else 0)
+    if not rle:
+        for k in range(c):
+            plane = a[:, :, k]
+            out += (np.stack([plane, 255 - plane], axis=-1).tobytes() if sixteen_bit else plane.tobytes())
+    else:
+        assert not sixteen_bit
+        rows = []
+        for k in range(c):
+            for y in range(h):
+                row, packed, i = a[y, :, k], bytearray(), 0
+                while i < w:
+                    run = 1
+                    while i + run < w and run < 128 and row[i + run] == row[i]:
+                        run += 1
+                    if run >= 3:
+                        packed += bytes([257 - run, int(row[i])])
+                        i += run
+                    else:
+                        j = i
+                        while j < w and j - i < 128 and not (j + 2 < w and row[j] == row[j + 1] == row[j + 2]):
+                            j += 1
+                        packed += bytes([j - i - 1]) + row[i:j].tobytes()
+                        i = j
+                rows.append(bytes(packed))
+        out += b"".join(struct.pack(">H", len(r)) for r in rows) + b"".join(rows)
+    with open(path, "wb") as f:
+        f.write(bytes(out))
+
+
 def write_pnm(path: str, img: np.ndarray) -> None:
     """Binary PGM (grey) / PPM (RGB) with a comment line in the header."""
     a = np.asarray(img, dtype=np.uint8)
@@ -938,6 +978,9 @@ def write_texture(path: str, img: np.ndarray, encoding: str) -> None:
         "bmp32": lambda: write_bmp(path, img, "32"),
         "bmp32_v4": lambda: write_bmp(path, img, "32_v4"),
         "pnm": lambda: write_pnm(path, img),
+        "psd": lambda: write_psd(path, img),
+        "psd_rle": lambda: write_psd(path, img, rle=True),
+        "psd16": lambda: write_psd(path, img, sixteen_bit=True),
         "gif": lambda: write_gif(path, img),
         "gif_i": lambda: write_gif(path, img, interlace=True),
         "gif_t": lambda: write_gif(path, img, transparent=True),
@@ -1594,6 +1637,52 @@ def gif_gallery() -> ObjScene:
         camera_position=(0.0, 1.7, 4.4), camera_facing=(0.0, -0.12, -1.0), fov=62.0)
 
 
+def psd_gallery() -> ObjScene:
+    """Photoshop composites as diffuse maps: RGB raw, RGB PackBits, 16-bit, and RGBA (raw and PackBits) with every alpha
+    value, so that the decoder's float un-blending from the white matte is exercised over its whole range."""
+    rng = np.random.default_rng(20241009)
+    pos, nrm, uv = [], [], []
+    groups = []
+
+    def add(name, tris, material):
+        groups.append(ObjGroup(name, _faces_same_index(np.array(tris)), material))
+
+    add("floor", _quad(pos, nrm, uv, [(-4, 0, 3), (4, 0, 3), (4, 0, -3), (-4, 0, -3)], (0, 1, 0),
+                       [(0, 0), (2, 0), (2, 1.5), (0, 1.5)]), "floor")
+
+    def colour(h, w):
+        yy, xx = np.mgrid[0:h, 0:w]
+        img = np.stack([40 + 200 * ((xx // 4 + yy // 3) % 2), 128 + 100 * np.sin(yy * 0.6), 30 + 6 * xx], axis=2) + rng.integers(-25, 26, size=(h, w, 3))
+        img = img.clip(0, 255).astype(np.uint8)
+        img[h // 2:h // 2 + 3] = img[h // 2, 0]                         # flat rows: runs for PackBits
+        return img
+
+    def with_alpha(img):
+        h, w, _ = img.shape
+        a = (np.arange(h * w).reshape(h, w) * 7 % 256).astype(np.uint8)  # every alpha value
+        a[:2] = 255
+        a[2:4] = 0
+        return np.concatenate([img, a[:, :, None]], axis=2)
+
+    layouts = [("rgb", colour(21, 30), "psd"), ("rgb_rle", colour(26, 19), "psd_rle"), ("rgb16", colour(14, 23), "psd16"),
+               ("rgba", with_alpha(colour(24, 32)), "psd"), ("rgba_rle", with_alpha(colour(20, 27)), "psd_rle")]
+    textures = {"floor_kd.psd": (colour(40, 64), "psd_rle")}
+    materials = [MtlMaterial("floor", Ns=20.0, Ka=(0.6, 0.6, 0.6), Kd=(0.9, 0.9, 0.9), Ks=(0.2, 0.2, 0.2), map_Kd="floor_kd.psd")]
+    for k, (name, img, enc) in enumerate(layouts):
+        col, row = k % 3, k // 3
+        x0, y0 = -3.3 + col * 2.3, 0.15 + row * 1.45
+        z = -1.5 - 0.25 * row
+        add("panel_" + name, _quad(pos, nrm, uv, [(x0, y0, z), (x0 + 2.0, y0, z), (x0 + 2.0, y0 + 1.25, z), (x0, y0 + 1.25, z)], (0, 0, 1),
+                                   [(0, 0), (1, 0), (1, 1), (0, 1)]), name)
+        textures[name + ".psd"] = (img, enc)
+        materials.append(MtlMaterial(name, Ns=25.0, d=1.0, Ka=(0.7, 0.7, 0.7), Kd=(1.0, 1.0, 1.0), Ks=(0.15, 0.15, 0.15), map_Kd=name + ".psd"))
+    return ObjScene(
+        name="psd_gallery",
+        positions=np.array(pos, dtype=F32), texcoords=np.array(uv, dtype=F32), normals=np.array(nrm, dtype=F32),
+        groups=groups, materials=materials, textures=textures,
+        camera_position=(0.0, 1.7, 4.4), camera_facing=(0.0, -0.12, -1.0), fov=62.0)
+
+
 # ----------------------------------------------------------------------------------------
 # registry: name -> (factory, render defaults)
 # ----------------------------------------------------------------------------------------
@@ -1618,6 +1707,7 @@ SCENES = {
     "terrain_192": lambda: terrain(192, 8, size=192.0),       # 73,728 tris in 64 groups
     "many_materials": lambda: many_materials(),               # 1,282 tris, 42 materials (LDS table fallback), translucent clusters
     "textured_gallery": lambda: textured_gallery(),           # 192 tris, 7 materials, 14 texture files (row N1)
+    "psd_gallery": lambda: psd_gallery(),                     # 12 tris, 6 materials, 6 PSD composites: raw / PackBits, 16-bit, every alpha value
     "gif_gallery": lambda: gif_gallery(),                     # 14 tris, 7 materials, 7 GIF files: interlaced, transparent, local tables, offset images
     "tga_gallery": lambda: tga_gallery(),                     # 16 tris, 8 materials, 8 TGA files: 5-5-5 pixels, grey + alpha, colour maps
     "bmp_gallery": lambda: bmp_gallery(),                     # 24 tris, 12 materials, 12 BMP files of every flavour the reference decodes

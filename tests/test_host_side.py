@@ -258,6 +258,30 @@ def test_gif_bit_identical_to_reference_and_round_trip(tmp_path):
     assert np.all(got[:, :, 3][outside] == 0)
 
 
+def test_psd_bit_identical_to_reference_and_round_trip(tmp_path):
+    """The 6 composites of the psd_gallery scene (raw / PackBits, 16-bit, RGBA with every alpha value) decode to the
+    reference's bytes - always four channels, colours un-blended from the white matte in float - and opaque / fully
+    transparent pixels come back as written."""
+    g = load_golden("psd_gallery_128x96")
+    hs = host_scene("psd_gallery")
+    a = hs.arrays()
+    assert np.array_equal(a["group_texture_dims"], g["group_texture_dims"])
+    assert np.array_equal(_sums(a["group_texture_bytes"]), g["sum_group_texture_bytes"])
+    from par_raytracer_amd import scenes
+    lib = capi.host_lib()
+    rng = np.random.default_rng(5)
+    rgb = rng.integers(0, 256, size=(9, 13, 3), dtype=np.uint8)
+    rgb[3:6, 2:11] = rgb[3, 2]
+    rgba = np.concatenate([rgb, np.where(rng.integers(0, 2, size=(9, 13, 1)) > 0, 255, 0).astype(np.uint8)], axis=2)
+    for enc, img in (("psd", rgb), ("psd_rle", rgb), ("psd16", rgb), ("psd", rgba), ("psd_rle", rgba)):
+        path = str(tmp_path / ("t_%s.psd" % enc))
+        scenes.write_texture(path, img, enc)
+        got = _load_texture(lib, path)
+        assert got is not None and got.shape == (9, 13, 4) and np.array_equal(got[:, :, :img.shape[2]], img), enc
+        if img.shape[2] == 3:
+            assert np.all(got[:, :, 3] == 255)
+
+
 def test_bmp_flavours_round_trip(tmp_path):
     """What was written comes back: exactly for palettes, 24- and 32-bit; within the 5-bit quantisation (top bits repeated
     into the low ones) for 16-bit 5-5-5; a 32-bit file whose alpha bytes are all 0 comes back opaque."""
