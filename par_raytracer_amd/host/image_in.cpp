@@ -16,14 +16,16 @@
 //   * PNM  binary P5 (grey) / P6 (RGB), maxval <= 255;
 //   * GIF  the first image on the logical screen, always RGBA (background and transparent pixels: alpha 0), interlaced
 //          or not, global or local colour table;
-//   * PSD  the flattened RGB composite, 8 / 16 bits, raw or PackBits, always RGBA, colours un-blended from white.
+//   * PSD  the flattened RGB composite, 8 / 16 bits, raw or PackBits, always RGBA, colours un-blended from white;
+//   * HDR  Radiance RGBE (flat or run-length scanlines), tone-mapped to 8 bits with the reference decoder's gamma 2.2.
 //   * JPEG baseline and progressive (image_jpeg.cpp): grey -> 1 channel, colour -> 3, every sampling layout, restart intervals.
-// Anything else (arithmetic-coded JPEG, run-length / 1-bit BMP, HDR, PIC ...) is reported and the texture slot
+// Anything else (arithmetic-coded JPEG, run-length / 1-bit BMP, Softimage PIC ...) is reported and the texture slot
 // stays empty, which is how the reference treats a file its decoder rejects (obj_parser.cpp:201-204).
 // tests/test_host_side.py compares the decoded bytes with the reference's on generated files of every kind.
 #include <zlib.h>
 
 #include <cctype>
+#include <cmath>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -731,6 +733,106 @@ bool DecodePsd(const std::vector<u8> & d, Image * out) {
     return true;
 }
 
+// ---- Radiance HDR ------------------------------------------------------------------------------------
+// The reference loads .hdr files through its decoder's 8-bit entry point: RGBE pixels become floats (mantissa x
+// 2^(exponent - 136), exponent 0 = black) and are then tone-mapped the library's way - pow(v, 1 / 2.2) in double, x 255 +
+// 0.5 in float, clamped, truncated - to three channels.  Header: "#?RADIANCE" or "#?RGBE", a FORMAT=32-bit_rle_rgbe
+// line, a blank line, "-Y h +X w".  Scanlines are new-style run-length coded (2, 2, width) for 8 <= width < 32768, flat
+// RGBE otherwise; a scanline that does not start with (2, 2, < 128) switches the WHOLE image to flat pixels, re-read from
+// pixel 1 of row 0 (the library's control flow, kept).
+bool HdrLine(const std::vector<u8> & d, size_t * pos, std::string * line) {
+    line->clear();
+    if (*pos >= d.size()) return false;
+    while (*pos < d.size() && d[*pos] != '\n') {
+        if (line->size() < 1022) line->push_back((char)d[*pos]);
+        ++*pos;
+    }
+    if (*pos < d.size()) ++*pos;                                 // the newline
+    return true;
+}
+
+void HdrPixel(const u8 * rgbe, u8 * o) {
+    float v[3] = { 0.0f, 0.0f, 0.0f };
+    if (rgbe[3] != 0) {
+        const float f1 = (float)ldexp(1.0f, (int)rgbe[3] - (int)(128 + 8));
+        for (int k = 0; k < 3; ++k) v[k] = rgbe[k] * f1;
+    }
+    for (int k = 0; k < 3; ++k) {
+        float z = (float)pow((double)(v[k] * 1.0f), (double)(1.0f / 2.2f)) * 255 + 0.5f;
+        if (z < 0) z = 0;
+        if (z > 255) z = 255;
+        o[k] = (u8)(int)z;
+    }
+}
+
+bool DecodeHdr(const std::vector<u8> & d, Image * out) {
+    size_t pos = 0;
+    std::string line;
+    if (!HdrLine(d, &pos, &line) || (line != "#?RADIANCE" && line != "#?RGBE")) return Fail("not a Radiance HDR file");
+    bool valid = false;
+    for (;;) {
+        if (!HdrLine(d, &pos, &line)) return Fail("HDR header truncated");
+        if (line.empty()) break;
+        if (line == "FORMAT=32-bit_rle_rgbe") valid = true;
+    }
+    if (!valid) return Fail("unsupported HDR format");
+    if (!HdrLine(d, &pos, &line)) return Fail("HDR header truncated");
+    if (line.compare(0, 3, "-Y ") != 0) return Fail("unsupported HDR data layout");
+    char * end = nullptr;
+    const long height = strtol(line.c_str() + 3, &end, 10);
+    while (*end == ' ') ++end;
+    if (strncmp(end, "+X ", 3) != 0) return Fail("unsupported HDR data layout");
+    const long width = strtol(end + 3, nullptr, 10);
+    if (width <= 0 || height <= 0 || (unsigned long long)width * (unsigned long long)height > (1ull << 28)) return Fail("bad HDR size");
+    const size_t w = (size_t)width, h = (size_t)height;
+    if (w * h > ((size_t)d.size() + 64) * 130) return Fail("HDR header promises more pixels than the file can hold");
+    std::vector<u8> px(w * h * 3);
+    auto get = [&]() -> u8 { return pos < d.size() ? d[pos++] : (u8)0; };
+    auto flat_from = [&](size_t first) {                          // flat RGBE pixels for pixel `first` .. the end, in reading order
+        for (size_t i = first; i < w * h; ++i) {
+            u8 rgbe[4] = { get(), get(), get(), get() };
+            HdrPixel(rgbe, &px[i * 3]);
+        }
+    };
+    if (w < 8 || w >= 32768) {
+        flat_from(0);
+    } else {
+        std::vector<u8> scan(w * 4);
+        for (size_t j = 0; j < h; ++j) {
+            const u8 c1 = get(), c2 = get(), hi = get();
+            if (c1 != 2 || c2 != 2 || (hi & 0x80)) {              // not run-length coded: these four bytes are pixel 0
+                u8 rgbe[4] = { c1, c2, hi, get() };
+                HdrPixel(rgbe, &px[0]);
+                flat_from(1);
+                break;
+            }
+            const size_t len = ((size_t)hi << 8) | get();
+            if (len != w) return Fail("invalid HDR scanline length");
+            for (int k = 0; k < 4; ++k) {
+                size_t i = 0;
+                while (i < w) {
+                    if (pos >= d.size()) return Fail("HDR run-length data truncated");
+                    u32 count = get();
+                    if (count > 128) {
+                        const u8 value = get();
+                        count -= 128;
+                        if (count > w - i) return Fail("bad run-length data in HDR");
+                        for (u32 z = 0; z < count; ++z) scan[i++ * 4 + k] = value;
+                    } else {
+                        if (count > w - i) return Fail("bad run-length data in HDR");
+                        if (count == 0) return Fail("bad run-length data in HDR");      // (the library would spin here)
+                        for (u32 z = 0; z < count; ++z) scan[i++ * 4 + k] = get();
+                    }
+                }
+            }
+            for (size_t i = 0; i < w; ++i) HdrPixel(&scan[i * 4], &px[(j * w + i) * 3]);
+        }
+    }
+    out->w = (u32)w; out->h = (u32)h; out->channels = 3;
+    out->px.swap(px);
+    return true;
+}
+
 // ---- PNM ------------------------------------------------------------------------------------------------
 bool PnmNumber(const std::vector<u8> & d, size_t * pos, u32 * value) {
     for (;;) {
@@ -774,6 +876,7 @@ Texture * LoadTexture(const char * filename) {
         else if (d.size() >= 2 && d[0] == 'B' && d[1] == 'M') ok = DecodeBmp(d, &img);
         else if (d.size() >= 6 && d[0] == 'G' && d[1] == 'I' && d[2] == 'F' && d[3] == '8') ok = DecodeGif(d, &img);
         else if (d.size() >= 4 && d[0] == '8' && d[1] == 'B' && d[2] == 'P' && d[3] == 'S') ok = DecodePsd(d, &img);
+        else if ((d.size() >= 11 && !memcmp(d.data(), "#?RADIANCE\n", 11)) || (d.size() >= 7 && !memcmp(d.data(), "#?RGBE\n", 7))) ok = DecodeHdr(d, &img);
         else if (d.size() >= 2 && d[0] == 'P' && (d[1] == '5' || d[1] == '6')) ok = DecodePnm(d, &img);
         else if (d.size() >= 3 && d[0] == 0xFF && d[1] == 0xD8) {
             const char * err = prt_jpeg::Decode(d, &img.w, &img.h, &img.channels, &img.px);

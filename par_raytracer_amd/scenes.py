@@ -505,6 +505,47 @@ def write_psd(path: str, img: np.ndarray, rle: bool = False, sixteen_bit: bool =
         f.write(bytes(out))
 
 
+def write_hdr(path: str, img: np.ndarray, rle: bool = True, magic: str = "#?RADIANCE") -> None:
+    """Radiance RGBE picture.  img: [h, w, 3] floats (radiance) or uint8 (mapped to a few decades of radiance).  `rle`:
+    new-style run-length scanlines (only legal for 8 <= w < 32768), else flat RGBE pixels."""
+    a = np.asarray(img)
+    if a.dtype == np.uint8:
+        a = (a.astype(np.float64) / 255.0) ** 2.2 * 4.0 + (a.astype(np.float64) % 7 == 0) * 1e-4
+    a = a.astype(np.float64)
+    h, w, _ = a.shape
+    m = a.max(axis=2)
+    mant, expo = np.frexp(np.maximum(m, 1e-38))
+    scale = np.where(m < 1e-32, 0.0, mant * 256.0 / np.maximum(m, 1e-38))
+    rgbe = np.zeros((h, w, 4), dtype=np.uint8)
+    rgbe[:, :, :3] = np.clip(a * scale[:, :, None], 0, 255).astype(np.uint8)
+    rgbe[:, :, 3] = np.where(m < 1e-32, 0, expo + 128).astype(np.uint8)
+    rgbe[m < 1e-32] = 0
+    out = bytearray((magic + "\n# made by par_raytracer_amd.scenes\nFORMAT=32-bit_rle_rgbe\nEXPOSURE=1.0\n\n-Y %d +X %d\n" % (h, w)).encode())
+    if not rle:
+        out += rgbe.tobytes()
+    else:
+        assert 8 <= w < 32768
+        for y in range(h):
+            out += bytes([2, 2, w >> 8, w & 255])
+            for k in range(4):
+                row, i = rgbe[y, :, k], 0
+                while i < w:
+                    run = 1
+                    while i + run < w and run < 127 and row[i + run] == row[i]:
+                        run += 1
+                    if run >= 3:
+                        out += bytes([128 + run, int(row[i])])
+                        i += run
+                    else:
+                        j = i
+                        while j < w and j - i < 128 and not (j + 2 < w and row[j] == row[j + 1] == row[j + 2]):
+                            j += 1
+                        out += bytes([j - i]) + row[i:j].tobytes()
+                        i = j
+    with open(path, "wb") as f:
+        f.write(bytes(out))
+
+
 def write_pnm(path: str, img: np.ndarray) -> None:
     """Binary PGM (grey) / PPM (RGB) with a comment line in the header."""
     a = np.asarray(img, dtype=np.uint8)
@@ -978,6 +1019,8 @@ def write_texture(path: str, img: np.ndarray, encoding: str) -> None:
         "bmp32": lambda: write_bmp(path, img, "32"),
         "bmp32_v4": lambda: write_bmp(path, img, "32_v4"),
         "pnm": lambda: write_pnm(path, img),
+        "hdr": lambda: write_hdr(path, img),
+        "hdr_flat": lambda: write_hdr(path, img, rle=False, magic="#?RGBE"),
         "psd": lambda: write_psd(path, img),
         "psd_rle": lambda: write_psd(path, img, rle=True),
         "psd16": lambda: write_psd(path, img, sixteen_bit=True),
@@ -1683,6 +1726,47 @@ def psd_gallery() -> ObjScene:
         camera_position=(0.0, 1.7, 4.4), camera_facing=(0.0, -0.12, -1.0), fov=62.0)
 
 
+def hdr_gallery() -> ObjScene:
+    """Radiance .hdr files as diffuse maps, tone-mapped to 8 bits the way the reference's decoder does it: run-length
+    scanlines, flat pixels in a wide file (the old format), a file narrower than 8 pixels (always flat), pixels with a zero
+    exponent, radiances over several decades."""
+    rng = np.random.default_rng(20241010)
+    pos, nrm, uv = [], [], []
+    groups = []
+
+    def add(name, tris, material):
+        groups.append(ObjGroup(name, _faces_same_index(np.array(tris)), material))
+
+    add("floor", _quad(pos, nrm, uv, [(-4, 0, 3), (4, 0, 3), (4, 0, -3), (-4, 0, -3)], (0, 1, 0),
+                       [(0, 0), (2, 0), (2, 1.5), (0, 1.5)]), "floor")
+
+    def radiance(h, w, decades):
+        yy, xx = np.mgrid[0:h, 0:w]
+        base = np.stack([0.5 + 0.5 * np.sin(xx * 0.5) * np.cos(yy * 0.4), 0.5 + 0.5 * np.cos(yy * 0.7), (xx + yy) / float(w + h)], axis=2)
+        img = base * 10.0 ** rng.uniform(-decades, 0.5, size=(h, w, 1))
+        img[h // 2] = img[h // 2, 0]                                     # a flat row: runs
+        img[1, 1:4] = 0.0                                               # zero exponent
+        return img
+
+    layouts = [("rle", radiance(22, 31, 3), "hdr"), ("flat_wide", radiance(17, 24, 2), "hdr_flat"), ("narrow", radiance(29, 6, 2), "hdr_flat"),
+               ("bytes", rng.integers(0, 256, size=(20, 26, 3), dtype=np.uint8), "hdr")]
+    textures = {"floor_kd.hdr": (radiance(40, 64, 1), "hdr")}
+    materials = [MtlMaterial("floor", Ns=20.0, Ka=(0.6, 0.6, 0.6), Kd=(0.9, 0.9, 0.9), Ks=(0.2, 0.2, 0.2), map_Kd="floor_kd.hdr")]
+    for k, (name, img, enc) in enumerate(layouts):
+        col, row = k % 2, k // 2
+        x0, y0 = -3.2 + col * 3.3, 0.15 + row * 1.45
+        z = -1.5 - 0.25 * row
+        add("panel_" + name, _quad(pos, nrm, uv, [(x0, y0, z), (x0 + 3.0, y0, z), (x0 + 3.0, y0 + 1.25, z), (x0, y0 + 1.25, z)], (0, 0, 1),
+                                   [(0, 0), (1, 0), (1, 1), (0, 1)]), name)
+        textures[name + ".hdr"] = (img, enc)
+        materials.append(MtlMaterial(name, Ns=25.0, d=1.0, Ka=(0.7, 0.7, 0.7), Kd=(1.0, 1.0, 1.0), Ks=(0.15, 0.15, 0.15), map_Kd=name + ".hdr"))
+    return ObjScene(
+        name="hdr_gallery",
+        positions=np.array(pos, dtype=F32), texcoords=np.array(uv, dtype=F32), normals=np.array(nrm, dtype=F32),
+        groups=groups, materials=materials, textures=textures,
+        camera_position=(0.0, 1.7, 4.4), camera_facing=(0.0, -0.12, -1.0), fov=62.0)
+
+
 # ----------------------------------------------------------------------------------------
 # registry: name -> (factory, render defaults)
 # ----------------------------------------------------------------------------------------
@@ -1707,6 +1791,7 @@ SCENES = {
     "terrain_192": lambda: terrain(192, 8, size=192.0),       # 73,728 tris in 64 groups
     "many_materials": lambda: many_materials(),               # 1,282 tris, 42 materials (LDS table fallback), translucent clusters
     "textured_gallery": lambda: textured_gallery(),           # 192 tris, 7 materials, 14 texture files (row N1)
+    "hdr_gallery": lambda: hdr_gallery(),                     # 10 tris, 5 materials, 5 Radiance files: run-length, flat, narrow
     "psd_gallery": lambda: psd_gallery(),                     # 12 tris, 6 materials, 6 PSD composites: raw / PackBits, 16-bit, every alpha value
     "gif_gallery": lambda: gif_gallery(),                     # 14 tris, 7 materials, 7 GIF files: interlaced, transparent, local tables, offset images
     "tga_gallery": lambda: tga_gallery(),                     # 16 tris, 8 materials, 8 TGA files: 5-5-5 pixels, grey + alpha, colour maps

@@ -282,6 +282,29 @@ def test_psd_bit_identical_to_reference_and_round_trip(tmp_path):
             assert np.all(got[:, :, 3] == 255)
 
 
+def test_hdr_bit_identical_to_reference(tmp_path):
+    """The 5 Radiance files of the hdr_gallery scene (run-length scanlines, flat pixels in a wide file, a file narrower
+    than 8 pixels, zero exponents, several decades of radiance) come back as the reference's decoder tone-maps them:
+    three channels, pow(v, 1 / 2.2) x 255 + 0.5 truncated.  A written picture comes back within the RGBE mantissa's
+    precision of the analytic tone map."""
+    g = load_golden("hdr_gallery_128x96")
+    hs = host_scene("hdr_gallery")
+    a = hs.arrays()
+    assert np.array_equal(a["group_texture_dims"], g["group_texture_dims"])
+    assert np.array_equal(_sums(a["group_texture_bytes"]), g["sum_group_texture_bytes"])
+    from par_raytracer_amd import scenes
+    lib = capi.host_lib()
+    yy, xx = np.mgrid[0:12, 0:20]
+    rad = np.stack([0.02 + xx / 10.0, 0.5 + 0.4 * np.sin(yy * 0.9), np.full(xx.shape, 0.25)], axis=2)
+    want = (np.clip(rad, 0, None) ** (1 / 2.2) * 255 + 0.5).clip(0, 255)
+    for enc in ("hdr", "hdr_flat"):
+        path = str(tmp_path / ("t_%s.hdr" % enc))
+        scenes.write_texture(path, rad, enc)
+        got = _load_texture(lib, path)
+        assert got is not None and got.shape == (12, 20, 3), enc
+        assert np.abs(got.astype(np.float64) - want).max() <= 5.0, enc         # the 8-bit shared-exponent mantissa truncates
+
+
 def test_bmp_flavours_round_trip(tmp_path):
     """What was written comes back: exactly for palettes, 24- and 32-bit; within the 5-bit quantisation (top bits repeated
     into the low ones) for 16-bit 5-5-5; a 32-bit file whose alpha bytes are all 0 comes back opaque."""
