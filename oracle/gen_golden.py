@@ -64,6 +64,8 @@ FIXTURES = {
     "psd_gallery_128x96": dict(scene="psd_gallery", width=128, height=96, spp=4, lattice=1),
     # Radiance .hdr through the 8-bit entry point: RGBE -> float -> the decoder's gamma-2.2 tone map
     "hdr_gallery_128x96": dict(scene="hdr_gallery", width=128, height=96, spp=4, lattice=1),
+    # Softimage PIC: raw / pure / mixed run-length packets, separate alpha packet, 16-bit run counts
+    "pic_gallery_128x96": dict(scene="pic_gallery", width=128, height=96, spp=4, lattice=1),
     # row N4: the reference's adaptive loop (main.cpp:245-258), one RNG stream per pixel; spp = min_samples
     "cornell_adaptive_4_16": dict(scene="cornell_box", width=96, height=72, spp=4, max_spp=16, lattice=1),
     "gallery_adaptive_10_50": dict(scene="textured_gallery", width=64, height=48, spp=10, max_spp=50, lattice=1),      # reference defaults

@@ -17,9 +17,10 @@
 //   * GIF  the first image on the logical screen, always RGBA (background and transparent pixels: alpha 0), interlaced
 //          or not, global or local colour table;
 //   * PSD  the flattened RGB composite, 8 / 16 bits, raw or PackBits, always RGBA, colours un-blended from white;
-//   * HDR  Radiance RGBE (flat or run-length scanlines), tone-mapped to 8 bits with the reference decoder's gamma 2.2.
+//   * HDR  Radiance RGBE (flat or run-length scanlines), tone-mapped to 8 bits with the reference decoder's gamma 2.2;
+//   * PIC  Softimage: chained channel packets, raw / pure / mixed run-length, 3 or 4 channels.
 //   * JPEG baseline and progressive (image_jpeg.cpp): grey -> 1 channel, colour -> 3, every sampling layout, restart intervals.
-// Anything else (arithmetic-coded JPEG, run-length / 1-bit BMP, Softimage PIC ...) is reported and the texture slot
+// Anything else (arithmetic-coded JPEG, run-length / 1-bit BMP ...) is reported and the texture slot
 // stays empty, which is how the reference treats a file its decoder rejects (obj_parser.cpp:201-204).
 // tests/test_host_side.py compares the decoded bytes with the reference's on generated files of every kind.
 #include <zlib.h>
@@ -833,6 +834,106 @@ bool DecodeHdr(const std::vector<u8> & d, Image * out) {
     return true;
 }
 
+// ---- Softimage PIC -------------------------------------------------------------------------------------
+// Header: magic 53 80 F6 34, "PICT" at byte 88, width and height at 92 (big endian); then a chain of channel packets
+// (8 bits each; channel mask 0x80 R, 0x40 G, 0x20 B, 0x10 A) and, per scanline and packet, the data: raw, pure
+// run-length (count, value) or mixed run-length (count >= 128: a run of count - 127, or of a 16-bit count after 128;
+// else count + 1 raw values).  Channels no packet writes stay 255.  4 channels if a packet carries alpha, else 3.
+bool DecodePic(const std::vector<u8> & d, Image * out) {
+    if (d.size() < 104 || d[0] != 0x53 || d[1] != 0x80 || d[2] != 0xF6 || d[3] != 0x34 || memcmp(&d[88], "PICT", 4) != 0) return Fail("not a PIC");
+    const u32 w = Be16(&d[92]), h = Be16(&d[94]);
+    if (!w || !h) return Fail("empty PIC");
+    size_t pos = 104;                                            // after ratio, fields, pad
+    struct Packet { u8 size, type, channel; } packets[10];
+    int n_packets = 0, act = 0;
+    for (;;) {
+        if (n_packets == 10) return Fail("too many PIC packets");
+        if (pos + 4 > d.size()) return Fail("PIC file too short (reading packets)");
+        const u8 chained = d[pos];
+        Packet & p = packets[n_packets++];
+        p.size = d[pos + 1]; p.type = d[pos + 2]; p.channel = d[pos + 3];
+        pos += 4;
+        act |= p.channel;
+        if (pos >= d.size()) return Fail("PIC file too short (reading packets)");
+        if (p.size != 8) return Fail("PIC packet is not 8 bits per channel");
+        if (!chained) break;
+    }
+    if ((size_t)w * h > ((size_t)d.size() + 64) * 70000) return Fail("PIC header promises more pixels than the file can hold");
+    std::vector<u8> px((size_t)w * h * 4, 0xFF);
+    auto readval = [&](int channel, u8 * dest) -> bool {
+        for (int i = 0, mask = 0x80; i < 4; ++i, mask >>= 1)
+            if (channel & mask) {
+                if (pos >= d.size()) return false;
+                dest[i] = d[pos++];
+            }
+        return true;
+    };
+    auto copyval = [](int channel, u8 * dest, const u8 * src) {
+        for (int i = 0, mask = 0x80; i < 4; ++i, mask >>= 1)
+            if (channel & mask) dest[i] = src[i];
+    };
+    for (u32 y = 0; y < h; ++y)
+        for (int k = 0; k < n_packets; ++k) {
+            const Packet & p = packets[k];
+            u8 * dest = &px[(size_t)y * w * 4];
+            if (p.type == 0) {
+                for (u32 x = 0; x < w; ++x, dest += 4)
+                    if (!readval(p.channel, dest)) return Fail("PIC file too short");
+            } else if (p.type == 1) {
+                int left = (int)w;
+                while (left > 0) {
+                    if (pos >= d.size()) return Fail("PIC file too short (pure read count)");
+                    int count = d[pos++];
+                    if (pos >= d.size()) return Fail("PIC file too short (pure read count)");
+                    if (count > left) count = left;
+                    u8 value[4] = { 0, 0, 0, 0 };
+                    if (!readval(p.channel, value)) return Fail("PIC file too short");
+                    for (int i = 0; i < count; ++i, dest += 4) copyval(p.channel, dest, value);
+                    left -= count;
+                    if (count == 0) return Fail("bad PIC run");       // (the library would spin on a zero count)
+                }
+            } else if (p.type == 2) {
+                int left = (int)w;
+                while (left > 0) {
+                    if (pos >= d.size()) return Fail("PIC file too short (mixed read count)");
+                    int count = d[pos++];
+                    if (pos >= d.size()) return Fail("PIC file too short (mixed read count)");
+                    if (count >= 128) {
+                        if (count == 128) {
+                            if (pos + 2 > d.size()) return Fail("PIC file too short (mixed read count)");
+                            count = (int)Be16(&d[pos]);
+                            pos += 2;
+                        } else {
+                            count -= 127;
+                        }
+                        if (count > left) return Fail("PIC scanline overrun");
+                        u8 value[4] = { 0, 0, 0, 0 };
+                        if (!readval(p.channel, value)) return Fail("PIC file too short");
+                        for (int i = 0; i < count; ++i, dest += 4) copyval(p.channel, dest, value);
+                        if (count == 0) return Fail("bad PIC run");
+                    } else {
+                        ++count;
+                        if (count > left) return Fail("PIC scanline overrun");
+                        for (int i = 0; i < count; ++i, dest += 4)
+                            if (!readval(p.channel, dest)) return Fail("PIC file too short");
+                    }
+                    left -= count;
+                }
+            } else {
+                return Fail("PIC packet has a bad compression type");
+            }
+        }
+    const u32 ch = (act & 0x10) ? 4 : 3;
+    out->w = w; out->h = h; out->channels = ch;
+    if (ch == 4) {
+        out->px.swap(px);
+    } else {
+        out->px.resize((size_t)w * h * 3);
+        for (size_t i = 0; i < (size_t)w * h; ++i) memcpy(&out->px[i * 3], &px[i * 4], 3);
+    }
+    return true;
+}
+
 // ---- PNM ------------------------------------------------------------------------------------------------
 bool PnmNumber(const std::vector<u8> & d, size_t * pos, u32 * value) {
     for (;;) {
@@ -876,6 +977,7 @@ Texture * LoadTexture(const char * filename) {
         else if (d.size() >= 2 && d[0] == 'B' && d[1] == 'M') ok = DecodeBmp(d, &img);
         else if (d.size() >= 6 && d[0] == 'G' && d[1] == 'I' && d[2] == 'F' && d[3] == '8') ok = DecodeGif(d, &img);
         else if (d.size() >= 4 && d[0] == '8' && d[1] == 'B' && d[2] == 'P' && d[3] == 'S') ok = DecodePsd(d, &img);
+        else if (d.size() >= 92 && d[0] == 0x53 && d[1] == 0x80 && d[2] == 0xF6 && d[3] == 0x34 && !memcmp(&d[88], "PICT", 4)) ok = DecodePic(d, &img);
         else if ((d.size() >= 11 && !memcmp(d.data(), "#?RADIANCE\n", 11)) || (d.size() >= 7 && !memcmp(d.data(), "#?RGBE\n", 7))) ok = DecodeHdr(d, &img);
         else if (d.size() >= 2 && d[0] == 'P' && (d[1] == '5' || d[1] == '6')) ok = DecodePnm(d, &img);
         else if (d.size() >= 3 && d[0] == 0xFF && d[1] == 0xD8) {

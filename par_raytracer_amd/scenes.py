@@ -546,6 +546,51 @@ def write_hdr(path: str, img: np.ndarray, rle: bool = True, magic: str = "#?RADI
         f.write(bytes(out))
 
 
+def write_pic(path: str, img: np.ndarray, kind: str = "mixed") -> None:
+    """Softimage PIC, 8 bits per channel.  img [h, w, 3 or 4]; one packet for R, G, B (and, with 4 channels, a second one
+    for alpha).  kind: "raw", "pure" (count, value pairs) or "mixed" (runs and literal stretches; one long run uses the
+    16-bit count form)."""
+    import struct
+    a = np.asarray(img, dtype=np.uint8)
+    h, w, c = a.shape
+    ptype = {"raw": 0, "pure": 1, "mixed": 2}[kind]
+    out = bytearray(b"\x53\x80\xF6\x34" + struct.pack(">f", 3.71) + b"par_raytracer_amd".ljust(80, b"\0") + b"PICT")
+    out += struct.pack(">HHfHH", w, h, 1.0, 3, 0)
+    out += bytes([1 if c == 4 else 0, 8, ptype, 0xE0])
+    if c == 4:
+        out += bytes([0, 8, ptype, 0x10])
+
+    def encode(row):                                                    # row: [w, n] values of one packet
+        n = row.shape[1]
+        if ptype == 0:
+            return row.tobytes()
+        body, i = bytearray(), 0
+        while i < w:
+            run = 1
+            while i + run < w and run < (255 if ptype == 1 else 60000) and np.array_equal(row[i + run], row[i]):
+                run += 1
+            if ptype == 1:
+                body += bytes([run]) + row[i].tobytes()
+                i += run
+            elif run >= 2:
+                body += (bytes([run + 127]) if run <= 128 else bytes([128]) + struct.pack(">H", run)) + row[i].tobytes()
+                i += run
+            else:
+                j = i + 1
+                while j < w and j - i < 128 and not (j + 1 < w and np.array_equal(row[j], row[j + 1])):
+                    j += 1
+                body += bytes([j - i - 1]) + row[i:j].tobytes()
+                i = j
+        return bytes(body)
+
+    for y in range(h):
+        out += encode(a[y, :, :3])
+        if c == 4:
+            out += encode(a[y, :, 3:4])
+    with open(path, "wb") as f:
+        f.write(bytes(out))
+
+
 def write_pnm(path: str, img: np.ndarray) -> None:
     """Binary PGM (grey) / PPM (RGB) with a comment line in the header."""
     a = np.asarray(img, dtype=np.uint8)
@@ -1019,6 +1064,9 @@ def write_texture(path: str, img: np.ndarray, encoding: str) -> None:
         "bmp32": lambda: write_bmp(path, img, "32"),
         "bmp32_v4": lambda: write_bmp(path, img, "32_v4"),
         "pnm": lambda: write_pnm(path, img),
+        "pic": lambda: write_pic(path, img),
+        "pic_raw": lambda: write_pic(path, img, "raw"),
+        "pic_pure": lambda: write_pic(path, img, "pure"),
         "hdr": lambda: write_hdr(path, img),
         "hdr_flat": lambda: write_hdr(path, img, rle=False, magic="#?RGBE"),
         "psd": lambda: write_psd(path, img),
@@ -1767,6 +1815,47 @@ def hdr_gallery() -> ObjScene:
         camera_position=(0.0, 1.7, 4.4), camera_facing=(0.0, -0.12, -1.0), fov=62.0)
 
 
+def pic_gallery() -> ObjScene:
+    """Softimage PIC diffuse maps: raw, pure run-length and mixed run-length packets, RGB and RGB + a separate alpha packet,
+    a scanline-long run that needs the 16-bit count."""
+    rng = np.random.default_rng(20241011)
+    pos, nrm, uv = [], [], []
+    groups = []
+
+    def add(name, tris, material):
+        groups.append(ObjGroup(name, _faces_same_index(np.array(tris)), material))
+
+    add("floor", _quad(pos, nrm, uv, [(-4, 0, 3), (4, 0, 3), (4, 0, -3), (-4, 0, -3)], (0, 1, 0),
+                       [(0, 0), (2, 0), (2, 1.5), (0, 1.5)]), "floor")
+
+    def colour(h, w, alpha=False):
+        yy, xx = np.mgrid[0:h, 0:w]
+        img = np.stack([40 + 200 * ((xx // 5 + yy // 3) % 2), 128 + 100 * np.sin(yy * 0.6), 30 + (6 * xx) % 200], axis=2) + rng.integers(-20, 21, size=(h, w, 3)) * (xx[:, :, None] % 9 < 4)
+        img = img.clip(0, 255).astype(np.uint8)
+        img[h // 2] = img[h // 2, 0]
+        if alpha:
+            img = np.concatenate([img, (60 + (xx // 4 * 37 + yy * 5) % 190).astype(np.uint8)[:, :, None]], axis=2)
+        return img
+
+    layouts = [("mixed", colour(21, 30), "pic"), ("raw", colour(16, 19), "pic_raw"), ("pure", colour(18, 27), "pic_pure"),
+               ("mixed_a", colour(24, 33, True), "pic"), ("pure_a", colour(14, 22, True), "pic_pure"), ("long", colour(9, 300), "pic")]
+    textures = {"floor_kd.pic": (colour(40, 64), "pic")}
+    materials = [MtlMaterial("floor", Ns=20.0, Ka=(0.6, 0.6, 0.6), Kd=(0.9, 0.9, 0.9), Ks=(0.2, 0.2, 0.2), map_Kd="floor_kd.pic")]
+    for k, (name, img, enc) in enumerate(layouts):
+        col, row = k % 3, k // 3
+        x0, y0 = -3.3 + col * 2.3, 0.15 + row * 1.45
+        z = -1.5 - 0.25 * row
+        add("panel_" + name, _quad(pos, nrm, uv, [(x0, y0, z), (x0 + 2.0, y0, z), (x0 + 2.0, y0 + 1.25, z), (x0, y0 + 1.25, z)], (0, 0, 1),
+                                   [(0, 0), (1, 0), (1, 1), (0, 1)]), name)
+        textures[name + ".pic"] = (img, enc)
+        materials.append(MtlMaterial(name, Ns=25.0, d=1.0, Ka=(0.7, 0.7, 0.7), Kd=(1.0, 1.0, 1.0), Ks=(0.15, 0.15, 0.15), map_Kd=name + ".pic"))
+    return ObjScene(
+        name="pic_gallery",
+        positions=np.array(pos, dtype=F32), texcoords=np.array(uv, dtype=F32), normals=np.array(nrm, dtype=F32),
+        groups=groups, materials=materials, textures=textures,
+        camera_position=(0.0, 1.7, 4.4), camera_facing=(0.0, -0.12, -1.0), fov=62.0)
+
+
 # ----------------------------------------------------------------------------------------
 # registry: name -> (factory, render defaults)
 # ----------------------------------------------------------------------------------------
@@ -1791,6 +1880,7 @@ SCENES = {
     "terrain_192": lambda: terrain(192, 8, size=192.0),       # 73,728 tris in 64 groups
     "many_materials": lambda: many_materials(),               # 1,282 tris, 42 materials (LDS table fallback), translucent clusters
     "textured_gallery": lambda: textured_gallery(),           # 192 tris, 7 materials, 14 texture files (row N1)
+    "pic_gallery": lambda: pic_gallery(),                     # 14 tris, 7 materials, 7 Softimage files: raw / pure / mixed run-length, alpha packets
     "hdr_gallery": lambda: hdr_gallery(),                     # 10 tris, 5 materials, 5 Radiance files: run-length, flat, narrow
     "psd_gallery": lambda: psd_gallery(),                     # 12 tris, 6 materials, 6 PSD composites: raw / PackBits, 16-bit, every alpha value
     "gif_gallery": lambda: gif_gallery(),                     # 14 tris, 7 materials, 7 GIF files: interlaced, transparent, local tables, offset images

@@ -305,6 +305,29 @@ def test_hdr_bit_identical_to_reference(tmp_path):
         assert np.abs(got.astype(np.float64) - want).max() <= 5.0, enc         # the 8-bit shared-exponent mantissa truncates
 
 
+def test_pic_bit_identical_to_reference_and_round_trip(tmp_path):
+    """The 7 Softimage files of the pic_gallery scene (raw, pure and mixed run-length packets, a separate alpha packet, a
+    300-pixel run with a 16-bit count) decode to the reference's bytes and channel counts; what was written comes back."""
+    g = load_golden("pic_gallery_128x96")
+    hs = host_scene("pic_gallery")
+    a = hs.arrays()
+    assert np.array_equal(a["group_texture_dims"], g["group_texture_dims"])
+    assert np.array_equal(_sums(a["group_texture_bytes"]), g["sum_group_texture_bytes"])
+    from par_raytracer_amd import scenes
+    lib = capi.host_lib()
+    rng = np.random.default_rng(5)
+    rgb = rng.integers(0, 256, size=(9, 300, 3), dtype=np.uint8)
+    rgb[3:6, 2:290] = rgb[3, 2]
+    rgba = np.concatenate([rgb, rng.integers(0, 256, size=(9, 300, 1), dtype=np.uint8)], axis=2)
+    rgba[4, :, 3] = 77
+    for enc in ("pic", "pic_raw", "pic_pure"):
+        for img in (rgb, rgba):
+            path = str(tmp_path / ("t_%s_%d.pic" % (enc, img.shape[2])))
+            scenes.write_texture(path, img, enc)
+            got = _load_texture(lib, path)
+            assert got is not None and got.shape == img.shape and np.array_equal(got, img), (enc, img.shape)
+
+
 def test_bmp_flavours_round_trip(tmp_path):
     """What was written comes back: exactly for palettes, 24- and 32-bit; within the 5-bit quantisation (top bits repeated
     into the low ones) for 16-bit 5-5-5; a 32-bit file whose alpha bytes are all 0 comes back opaque."""

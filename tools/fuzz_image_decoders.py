@@ -29,6 +29,8 @@ for enc, im in (("psd", img3), ("psd_rle", img3 // 64 * 64), ("psd16", img3), ("
     p = os.path.join(d, "s%d.img" % len(seeds)); scenes.write_texture(p, im, enc); seeds.append(open(p, "rb").read())
 for enc, im in (("hdr", img3), ("hdr_flat", img3), ("hdr_flat", img3[:, :5])):
     p = os.path.join(d, "s%d.img" % len(seeds)); scenes.write_texture(p, im, enc); seeds.append(open(p, "rb").read())
+for enc, im in (("pic", img3 // 64 * 64), ("pic_raw", img3), ("pic_pure", img3 // 64 * 64), ("pic", img4 // 64 * 64), ("pic_pure", img4)):
+    p = os.path.join(d, "s%d.img" % len(seeds)); scenes.write_texture(p, im, enc); seeds.append(open(p, "rb").read())
 n_ok = n_fail = 0
 for it in range(int(os.environ.get("PRT_FUZZ_ITERATIONS", "12000"))):
     b = bytearray(seeds[it % len(seeds)])
