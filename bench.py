@@ -64,6 +64,52 @@ def log(msg):
         print("[bench] " + msg, file=sys.stderr, flush=True)
 
 
+def launch_ranks(n):
+    """Start one child process per rank (what `python -m torch.distributed.run --nproc-per-node n` would do), wait for
+    all of them, return 0 only if every rank exited 0.  Rank 0's stdout (the JSON line) is this process's stdout.  The
+    reference's equivalent is `mpirun -n N` around main.cpp:311-347 (partition + MPI_Gather)."""
+    import signal
+    import socket
+    import subprocess
+
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n),
+                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+        env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    live = set(range(n))
+    kill_at = None
+    try:
+        while live:
+            for r in sorted(live):
+                code = procs[r].poll()
+                if code is None:
+                    continue
+                live.discard(r)
+                if code != 0 and rc == 0:
+                    rc = code if code > 0 else 1
+                    print("[bench] rank %d exited with code %d: stopping the other ranks" % (r, code), file=sys.stderr, flush=True)
+                    for o in live:
+                        procs[o].send_signal(signal.SIGTERM)           # exact PIDs we started
+                    kill_at = time.time() + 20.0
+            if kill_at is not None and time.time() > kill_at:
+                for o in live:
+                    procs[o].kill()
+                kill_at = None
+            time.sleep(0.05)
+    except KeyboardInterrupt:
+        for o in live:
+            procs[o].kill()
+        rc = 130
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -83,13 +129,15 @@ def main():
                          "contention), 2 on several (a 1/8-frame shard gains 13 %%)")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` by itself: this process becomes the launcher.  It has not imported torch or touched HIP
+        # and never will; the ranks are its children (no exec of a process that has initialised the GPU).
+        raise SystemExit(launch_ranks(args.gpus))
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs one rank per GPU: launch with python -m torch.distributed.run "
-                             "--nnodes=1 --nproc-per-node %d bench.py --gpus %d ..." % (args.gpus, args.gpus, args.gpus))
         raise SystemExit("WORLD_SIZE=%d but --gpus %d" % (world, args.gpus))
 
     import torch
@@ -247,6 +295,11 @@ def main():
         rays_total = float(rays_local)
     ms_per_step = elapsed * 1e3 / args.steps
     value = rays_total / elapsed / 1e6
+    ranks_seen = 1
+    if world > 1:
+        one = torch.ones(1, dtype=torch.int32, device=cdev)
+        dist.all_reduce(one, op=dist.ReduceOp.SUM)                 # every rank of the group took part in the collective path
+        ranks_seen = int(one.item())
 
     # ---- roofline of the dominant kernel: one extra, untimed render with visit counting (identical pixels)
     pcount = api.default_params(spp, SEED, bounce_depth=depth, pipeline=args.pipeline | capi.FLAG_COUNT_VISITS)
@@ -336,6 +389,7 @@ def main():
             "metric": "Mrays/s at 1920x1080x8spp, 1M-tri OBJ" if args.workload == "C4" else "Mrays/s (%s)" % args.workload,
             "value": round(value, 3), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "ranks_seen": ranks_seen,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": descr, "seed": SEED, "triangles": int(info.triangle_count), "width": width, "height": height,
                        "spp": spp, "bounce_depth": depth, "rays_per_frame": int(rays_total / args.steps),

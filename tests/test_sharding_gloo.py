@@ -85,3 +85,33 @@ def test_python_sharding_matches_the_c_abi():
         idx = sharding.row_index(h, br, n)
         real = idx[idx < h]
         assert sorted(real.tolist()) == list(range(h))      # every image row exactly once
+
+
+def test_bench_launches_its_own_ranks_and_reports_their_failure():
+    """`python bench.py --gpus 2` with no launcher around it starts its ranks as child processes.  Without a GPU every
+    rank stops with the "needs a GPU" message, and the launcher must hand that failure on as a non-zero exit code."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["HIP_VISIBLE_DEVICES"] = ""        # also on a GPU box: this test is about the launcher, not the render
+    env["ROCR_VISIBLE_DEVICES"] = ""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "1",
+                        "--workload", "tiny"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    err = p.stderr.decode()
+    assert p.returncode != 0, err[-2000:]
+    assert err.count("needs a GPU") >= 1, err[-2000:]
+    assert "exited with code" in err
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_on_one_gpu_rehearsal():
+    """The N > 1 path end to end as the driver starts it (`python bench.py --gpus 2`, no torchrun): two ranks share GPU 0,
+    gloo stands in for RCCL.  The assembled frame must be bit-identical to the single-GPU render."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--share-device",
+                        "--steps", "3", "--warmup", "1", "--workload", "tiny"], env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=900)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    line = [l for l in p.stdout.decode().splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["ranks_seen"] == 2
+    assert out["multi_gpu_check"]["bit_identical_to_single_gpu"] is True
