@@ -41,6 +41,9 @@ void prt_host_default_params(uint32_t spp, uint64_t seed, prt_params * out);
  * scan-line blocks and assembles the full frame on the host.  rgba_out: width*height*4 floats. */
 int prt_host_render(const prt_host_scene * scene, const prt_camera * cam, const prt_params * params,
                     uint32_t width, uint32_t height, int n_gpus, float * rgba_out, prt_counters * counters);
+/* Message of the last prt_host_render / Render() failure (a copy private to the calling thread).  The uploaded contexts
+ * are cached between calls per scene and dropped by prt_host_free_scene; calls from several threads are serialised. */
+const char * prt_host_render_error(void);
 
 /* WriteFramebufferImage (main.cpp:101-131): log-average-luma tone map, RGBA8 pack, PNG. */
 int prt_host_write_image(const float * rgba, uint32_t width, uint32_t height, const char * filename);

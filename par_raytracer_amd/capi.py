@@ -97,7 +97,7 @@ PRT_SYMBOLS = ["prt_create", "prt_destroy", "prt_last_error", "prt_abi_version",
                "prt_render_device", "prt_shard_rows", "prt_render_shard_device", "prt_render_shard", "prt_render_pixel_list", "prt_get_scene_info", "prt_debug_check_bvh", "prt_debug_check_bvh_lbvh", "prt_debug_device_kat"]
 PRT_HOST_SYMBOLS = ["prt_host_load_obj", "prt_host_free_scene", "prt_host_scene_desc", "prt_host_scene_hierarchy_seconds",
                     "prt_host_scene_parse_seconds", "prt_host_last_error", "prt_host_make_camera",
-                    "prt_host_default_params", "prt_host_render", "prt_host_write_image", "prt_host_tonemap",
+                    "prt_host_default_params", "prt_host_render", "prt_host_render_error", "prt_host_write_image", "prt_host_tonemap",
                     "prt_host_load_texture", "prt_host_free_texture"]
 
 
@@ -170,6 +170,7 @@ def host_lib() -> C.CDLL:
         lib.prt_host_default_params.argtypes = [C.c_uint32, C.c_uint64, C.POINTER(PrtParams)]
         lib.prt_host_render.argtypes = [C.c_void_p, C.POINTER(PrtCamera), C.POINTER(PrtParams), C.c_uint32, C.c_uint32,
                                         C.c_int, C.c_void_p, C.POINTER(PrtCounters)]
+        lib.prt_host_render_error.restype = C.c_char_p
         lib.prt_host_write_image.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_char_p]
         lib.prt_host_tonemap.restype = C.c_float
         lib.prt_host_tonemap.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]

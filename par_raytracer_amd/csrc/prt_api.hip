@@ -87,7 +87,7 @@ struct prt_ctx {
     bool any_translucent = false;
     bool textured = false;                // any material has a texture map: the TEX kernel variants run
     // PRT_PIPELINE_DEFAULT: which pipeline won the try-out for a (scene, pixel set, sampling) configuration
-    struct TuneEntry { uint64_t key[4]; unsigned int pipeline; };
+    struct TuneEntry { uint64_t key[6]; unsigned int pipeline; };
     std::vector<TuneEntry> tuned;
     uint64_t scene_epoch = 0;
     DevBuf<DevTexture> textures;
@@ -121,7 +121,8 @@ struct prt_ctx {
     DevBuf<unsigned int> pool_fin;        // adaptive mode: per-wave lists of pixels to finalise
     DevBuf<PoolArgs> pool_args;           // k_pool's arguments (read per phase from memory, kernels_pool.h)
     DevBuf<float4> adapt_f4;              // adaptive mode: scratch [max_spp][n] + running sums [n] + final colours [n]
-    int cu_count = 0;
+    int cu_count = 0;                     // compute units this context may fill (all of the device's minus PRT_RESERVE_CUS)
+    int reserved_cus = 0;
     unsigned int stack_bound = 0;
     DevBuf<int> stack_spill;
 };
@@ -552,10 +553,12 @@ int launch_pool(prt_ctx * ctx, bool count, const DevCamera & cam, DevParams P, u
     A.multi_light = multi_light;
     HIP_TRY(ctx, ctx->pool_args.ensure(1));
     hipLaunchKernelGGL(k_pool_store_args, dim3(1), dim3(64), 0, ctx->stream, A, ctx->pool_args.p);
+    HIP_TRY(ctx, hipGetLastError());
     if (count)
         hipLaunchKernelGGL((k_pool<BLOCK, WAVES, LDSTAB, RING, true, TEX, ADAPT, RINGMEM>), dim3(grid), dim3(BLOCK), lds, ctx->stream, ctx->pool_args.p, ctx->counters.p);
     else
         hipLaunchKernelGGL((k_pool<BLOCK, WAVES, LDSTAB, RING, false, TEX, ADAPT, RINGMEM>), dim3(grid), dim3(BLOCK), lds, ctx->stream, ctx->pool_args.p, ctx->counters.p);
+    HIP_TRY(ctx, hipGetLastError());       // a template variant that cannot launch (LDS, registers) is reported here, by name of its cause
     return 0;
 }
 
@@ -678,8 +681,9 @@ int render_pixels(prt_ctx * ctx, const prt_camera * cam_in, const prt_params * p
             e.key[0] = ctx->scene_epoch;
             e.key[1] = (uint64_t)px.n_pixels | (uint64_t)params->spp << 32;
             e.key[2] = (uint64_t)width | (uint64_t)height << 32;
-            e.key[3] = (uint64_t)params->bounce_depth | (uint64_t)params->reflection_samples << 8 | (uint64_t)params->spec_samples << 20 |
-                       (uint64_t)px.nranks << 32 | (uint64_t)px.block_rows << 44 | (uint64_t)(px.d_pixel_list ? 1 : 0) << 56;
+            e.key[3] = (uint64_t)params->bounce_depth | (uint64_t)params->reflection_samples << 32;      // full-width fields: no aliasing
+            e.key[4] = (uint64_t)params->spec_samples | (uint64_t)px.nranks << 32;
+            e.key[5] = (uint64_t)px.block_rows | (uint64_t)(px.d_pixel_list ? 1 : 0) << 32;
             for (const prt_ctx::TuneEntry & t : ctx->tuned)
                 if (!memcmp(t.key, e.key, sizeof(e.key))) pipeline = t.pipeline;
             if (pipeline == PRT_PIPELINE_DEFAULT) {
@@ -703,10 +707,9 @@ int render_pixels(prt_ctx * ctx, const prt_camera * cam_in, const prt_params * p
                 if (ctx->tuned.size() >= 64) ctx->tuned.erase(ctx->tuned.begin());
                 ctx->tuned.push_back(e);
                 if (getenv("PRT_DEBUG_UTIL")) fprintf(stderr, "[prt] default pipeline try-out: pool %.3f ms, wavefront %.3f ms\n", ms[0], ms[1]);
-                if (whole) {
-                    if (counters) *counters = c;                           // the frame in d_out is the last (wavefront) run
-                    return 0;
-                }
+                // the call itself is then served by the winner like every later one, so that the counters (pipeline, kernel
+                // times) describe the pipeline this configuration will keep
+                (void)whole;
                 pipeline = e.pipeline;
             }
         }
@@ -931,10 +934,29 @@ prt_ctx * prt_create(int device_id) {
     }
     memset(&ctx->scene, 0, sizeof(ctx->scene));
     memset(&ctx->info, 0, sizeof(ctx->info));
-    e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    // PRT_RESERVE_CUS=k (multi-GPU callers): the context's streams are created with a CU mask that leaves the last k compute
+    // units to others - the RCCL gather of the previous frame must not wait for a wave slot while this context's persistent
+    // kernels hold every one of theirs (bench.py sets it for N > 1 with frames in flight).  The persistent grids are sized
+    // for the CUs that are left.
+    std::vector<uint32_t> cu_mask;
+    {
+        const char * rs = getenv("PRT_RESERVE_CUS");
+        const int reserve = rs ? atoi(rs) : 0;
+        if (reserve > 0 && reserve < ctx->cu_count) {
+            cu_mask.assign((size_t)(ctx->cu_count + 31) / 32, 0u);
+            for (int cu = 0; cu < ctx->cu_count - reserve; ++cu) cu_mask[(size_t)cu >> 5] |= 1u << (cu & 31);
+            ctx->cu_count -= reserve;
+            ctx->reserved_cus = reserve;
+        }
+    }
+    auto make_stream = [&](hipStream_t * st) -> hipError_t {
+        if (!cu_mask.empty()) return hipExtStreamCreateWithCUMask(st, (uint32_t)cu_mask.size(), cu_mask.data());
+        return hipStreamCreateWithFlags(st, hipStreamNonBlocking);
+    };
+    e = make_stream(&ctx->stream);
     for (int i = 0; i < 4 && e == hipSuccess; ++i) e = hipEventCreate(&ctx->ev[i]);
     ctx->chain[0].stream = ctx->stream;
-    for (int c = 1; c < PRT_MAX_CHAINS && e == hipSuccess; ++c) e = hipStreamCreateWithFlags(&ctx->chain[c].stream, hipStreamNonBlocking);
+    for (int c = 1; c < PRT_MAX_CHAINS && e == hipSuccess; ++c) e = make_stream(&ctx->chain[c].stream);
     for (int c = 0; c < PRT_MAX_CHAINS && e == hipSuccess; ++c) {
         prt_ctx::ChainWs & w = ctx->chain[c];
         e = hipEventCreate(&w.ev_t0);
@@ -945,7 +967,7 @@ prt_ctx * prt_create(int device_id) {
     }
     if (e != hipSuccess) {
         g_create_error = std::string("prt_create: stream/event creation: ") + hipGetErrorString(e);
-        delete ctx;
+        prt_destroy(ctx);                  // releases whatever was created before the failure (every handle starts out null)
         return nullptr;
     }
     return ctx;

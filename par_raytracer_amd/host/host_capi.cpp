@@ -9,12 +9,15 @@
 #include "scene_flatten.h"
 
 float TonemapFramebuffer(const Framebuffer * fb, u8 * rgba8);   // image_out.cpp
+u64 NewRenderSceneId();                                          // render_host.cpp
+void ForgetRenderScene(u64 scene_id);
 
 struct prt_host_scene {
     Mesh * mesh;
     BoundingHierarchy hierarchy;
     Scene scene;
     FlatScene flat;
+    u64 id;                         // key of Render's context cache; never reused, unlike this object's address
     double parse_seconds;
     double hierarchy_seconds;
 };
@@ -48,6 +51,7 @@ prt_host_scene * prt_host_load_obj(const char * dir, const char * obj_name, int 
     double t1 = Now();
     CalculateTangents(mesh);
     prt_host_scene * hs = new prt_host_scene;
+    hs->id = NewRenderSceneId();
     hs->mesh = mesh;
     hs->parse_seconds = t1 - t0;
     double t2 = Now();
@@ -72,11 +76,13 @@ prt_host_scene * prt_host_load_obj(const char * dir, const char * obj_name, int 
 
 void prt_host_free_scene(prt_host_scene * hs) {
     if (!hs) return;
+    ForgetRenderScene(hs->id);      // drop the device copies: the next scene may well be allocated at this address
     delete hs->mesh;
     delete hs;
 }
 
 const prt_scene_desc * prt_host_scene_desc(const prt_host_scene * hs) { return hs ? &hs->flat.desc : NULL; }
+u64 prt_host_scene_id(const prt_host_scene * hs) { return hs ? hs->id : 0; }
 double prt_host_scene_hierarchy_seconds(const prt_host_scene * hs) { return hs ? hs->hierarchy_seconds : 0.0; }
 double prt_host_scene_parse_seconds(const prt_host_scene * hs) { return hs ? hs->parse_seconds : 0.0; }
 

@@ -55,6 +55,11 @@ int main(int argc, char ** argv) {
     fprintf(stderr, "[Render, sync] :: %.2f s (first call: includes upload + BVH build)\n", t4 - t3);
 
     const RenderReport & r = gLastRenderReport;
+    if (r.status != 0) {
+        // no image of a failed render: tone-mapping a zero frame would print one warning per pixel and write a black PNG
+        fprintf(stderr, "render failed (%d): no image written\n", r.status);
+        return 2;
+    }
     u32 total_pixel_count = gParams.image_width * gParams.image_height;
     printf("GPUs %u\n", r.gpu_count);
     printf("Rays cast:          %llu\n", (unsigned long long)r.counters.ray_count);

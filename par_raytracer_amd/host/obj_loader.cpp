@@ -66,12 +66,14 @@ char * CopyToken(const char * p) {
 char * SlurpFile(const std::string & path) {
     FILE * fp = fopen(path.c_str(), "rb");
     if (!fp) return NULL;
-    fseek(fp, 0, SEEK_END);
-    long n = ftell(fp);
-    fseek(fp, 0, SEEK_SET);
+    // a directory, FIFO or other unseekable path makes fseek / ftell fail (ftell = -1): not a file we can read
+    long n = -1;
+    if (fseek(fp, 0, SEEK_END) == 0) n = ftell(fp);
+    if (n < 0 || (unsigned long)n > (1ul << 40) || fseek(fp, 0, SEEK_SET) != 0) { fclose(fp); return NULL; }
     char * bytes = (char *)calloc(1, (size_t)n + 1);
+    if (!bytes) { fclose(fp); return NULL; }
     size_t got = fread(bytes, 1, (size_t)n, fp);
-    bytes[got] = '\0';
+    bytes[got <= (size_t)n ? got : (size_t)n] = '\0';
     fclose(fp);
     return bytes;
 }

@@ -174,5 +174,6 @@ struct RenderReport {
     double render_ms;
     double trace_kernel_ms;
     u32 gpu_count;
+    int status;                     // 0 = the frame was rendered; negative = the HIP path failed (the frame is zero-filled)
 };
 extern RenderReport gLastRenderReport;

@@ -9,6 +9,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -24,26 +26,33 @@ namespace {
 
 enum { SHARD_BLOCK_ROWS = 8 };
 
+// The uploaded contexts are kept between calls, keyed by a scene id that is never reused (NOT by the scene's address: a
+// freed scene's address is likely to be handed out again for the next one).  0 = no scene.
 struct ContextCache {
-    const void * key = NULL;
+    u64 key = 0;
     std::vector<prt_ctx *> ctxs;
     void Clear() {
         for (size_t i = 0; i < ctxs.size(); ++i) prt_destroy(ctxs[i]);
         ctxs.clear();
-        key = NULL;
+        key = 0;
     }
     ~ContextCache() { Clear(); }
 };
 ContextCache gCache;
 std::string gRenderError;
+std::mutex gRenderMutex;                 // guards gCache and gRenderError: concurrent callers render one after the other
+std::atomic<u64> gNextSceneId(1);
 
-int RenderFlat(const void * cache_key, const prt_scene_desc * desc, const prt_camera * cam, const prt_params * params,
+int RenderFlat(u64 cache_key, const prt_scene_desc * desc, const prt_camera * cam, const prt_params * params,
                u32 width, u32 height, int n_gpus, float * rgba_out, prt_counters * total) {
+    std::lock_guard<std::mutex> lock(gRenderMutex);
     if (n_gpus < 1) n_gpus = 1;
-    if (gCache.key != cache_key || (int)gCache.ctxs.size() != n_gpus) {
+    if (cache_key == 0 || gCache.key != cache_key || (int)gCache.ctxs.size() != n_gpus) {
         gCache.Clear();
+        // PRT_HOST_SHARE_DEVICE=1: every "GPU" of the call is device 0 (rehearsal of the n_gpus > 1 path on a one-GPU box)
+        const char * share = getenv("PRT_HOST_SHARE_DEVICE");
         for (int g = 0; g < n_gpus; ++g) {
-            prt_ctx * ctx = prt_create(g);
+            prt_ctx * ctx = prt_create(share && atoi(share) ? 0 : g);
             if (!ctx) { gRenderError = prt_last_error(NULL); gCache.Clear(); return -1; }
             gCache.ctxs.push_back(ctx);
             if (prt_upload_scene(ctx, desc) != 0) { gRenderError = prt_last_error(ctx); gCache.Clear(); return -2; }
@@ -96,28 +105,35 @@ int RenderFlat(const void * cache_key, const prt_scene_desc * desc, const prt_ca
 
 }  // namespace
 
+u64 NewRenderSceneId() { return gNextSceneId.fetch_add(1); }
+
+void ForgetRenderScene(u64 scene_id) {
+    std::lock_guard<std::mutex> lock(gRenderMutex);
+    if (scene_id != 0 && gCache.key == scene_id) gCache.Clear();
+}
+
 Framebuffer Render(Camera * cam, Scene * scene, u32 width, u32 height) {
     Framebuffer result;
     result.width = width;
     result.height = height;
     result.pixels = (Vector4 *)calloc(sizeof(Vector4), (size_t)width * height);
 
-    static FlatScene flat;
-    static const Scene * flat_for = NULL;
-    if (flat_for != scene) {
-        FlattenScene(scene, &flat);
-        flat_for = scene;
-    }
+    // Like the reference's Render, which is called once per process, every call takes the scene as it is NOW: flatten and
+    // upload again under a fresh id (callers that render many frames of one scene use prt_host_render, which caches).
+    FlatScene flat;
+    FlattenScene(scene, &flat);
     prt_camera pc = ToPrtCamera(cam);
     prt_params pp = ToPrtParams(&gParams);
     prt_counters ctr;
     memset(&ctr, 0, sizeof(ctr));
-    int rc = RenderFlat(scene, &flat.desc, &pc, &pp, width, height, (int)gRenderGpuCount, (float *)result.pixels, &ctr);
+    int rc = RenderFlat(NewRenderSceneId(), &flat.desc, &pc, &pp, width, height, (int)gRenderGpuCount, (float *)result.pixels, &ctr);
     if (rc != 0) {
-        // The reference has no error path here (asserts print and continue, brt.h:41); we report and return the
-        // zero-filled frame rather than abort.
+        // The reference has no error path here (asserts print and continue, brt.h:41); we report, return the zero-filled
+        // frame rather than abort, and leave the code in gLastRenderReport.status for the caller (prt_main exits non-zero).
+        std::lock_guard<std::mutex> lock(gRenderMutex);
         fprintf(stderr, "Render: HIP path failed (%d): %s\n", rc, gRenderError.c_str());
     }
+    gLastRenderReport.status = rc;
     gLastRenderReport.counters.ray_count = ctr.ray_count;
     gLastRenderReport.counters.sphere_check_count = ctr.node_visits;
     gLastRenderReport.counters.mesh_check_count = ctr.tri_tests;
@@ -130,11 +146,18 @@ Framebuffer Render(Camera * cam, Scene * scene, u32 width, u32 height) {
 
 // from host_capi.cpp's opaque scene
 const prt_scene_desc * prt_host_scene_desc(const prt_host_scene * hs);
+extern "C" u64 prt_host_scene_id(const prt_host_scene * hs);
 
 extern "C" int prt_host_render(const prt_host_scene * scene, const prt_camera * cam, const prt_params * params, uint32_t width,
                                uint32_t height, int n_gpus, float * rgba_out, prt_counters * counters) {
     if (!scene || !cam || !params || !rgba_out) return -1;
-    return RenderFlat(scene, prt_host_scene_desc(scene), cam, params, width, height, n_gpus, rgba_out, counters);
+    return RenderFlat(prt_host_scene_id(scene), prt_host_scene_desc(scene), cam, params, width, height, n_gpus, rgba_out, counters);
 }
 
-extern "C" const char * prt_host_render_error(void) { return gRenderError.c_str(); }
+extern "C" const char * prt_host_render_error(void) {
+    // a copy per calling thread: the shared string may be rewritten by another thread's render
+    static thread_local std::string copy;
+    std::lock_guard<std::mutex> lock(gRenderMutex);
+    copy = gRenderError;
+    return copy.c_str();
+}

@@ -184,3 +184,44 @@ def test_more_ranks_than_row_blocks(gpu_renderer_factory):
         rays += c.ray_count
         rows_seen += rows
     assert rows_seen == h and rays == cf.ray_count
+
+
+def test_host_render_forgets_a_freed_scene_and_runs_on_two_contexts(monkeypatch):
+    """prt_host_render (the C++ Render() behind the C entry point, main.cpp:301-358) keeps its uploaded contexts between
+    calls.  A scene that is freed and replaced by another one - quite possibly at the same address - must not be served from
+    that cache; and the n_gpus > 1 path (interleaved row blocks on several contexts, scattered on the host) must give the
+    single-context frame bit for bit.  Both "GPUs" are device 0 here (PRT_HOST_SHARE_DEVICE)."""
+    from par_raytracer_amd import api, capi
+    monkeypatch.setenv("PRT_HOST_SHARE_DEVICE", "1")
+    lib = capi.host_lib()
+    w, h = 96, 54
+    p = api.default_params(2, 4321)
+
+    def host_render(hs, cam, n_gpus):
+        out = np.zeros((h * w, 4), dtype=np.float32)
+        ctr = capi.PrtCounters()
+        rc = lib.prt_host_render(hs.handle, C.byref(cam), C.byref(p), w, h, n_gpus, out.ctypes.data, C.byref(ctr))
+        assert rc == 0, lib.prt_host_render_error().decode()
+        return out, ctr
+
+    def direct(hs, cam):
+        r = api.Renderer(0)
+        r.upload(hs)
+        out, ctr = r.render(cam, p, w, h)
+        r.close()
+        return out, ctr
+
+    frames = []
+    for name in ("cornell_box", "terrain_64", "cornell_box"):
+        s, d = scene_dir(name)
+        hs = api.HostScene(d, "scene.obj", 0, s.camera_position)        # a fresh host scene each time, freed below
+        cam = api.make_camera(s.fov, w, h, s.camera_position, s.camera_facing)
+        want, wc = direct(hs, cam)
+        for n_gpus in (1, 2):
+            got, gc = host_render(hs, cam, n_gpus)
+            assert gc.ray_count == wc.ray_count, (name, n_gpus)
+            assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (name, n_gpus)
+        frames.append(want)
+        hs.close()
+    assert not np.array_equal(frames[0], frames[1])
+    assert np.array_equal(frames[0], frames[2])
