@@ -33,8 +33,8 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 # name -> dict(scene, width, height, spp, lattice, depth, light_mode, rs, ss, seed)
 FIXTURES = {
     # BASELINE configs (C1 full frame; C2 full small frame + lattice of the 512^2 frame; C3-C5 sparse lattices)
-    "c1_sphere_plane_256": dict(scene="sphere_plane", width=256, height=256, spp=1, lattice=1),
-    "c2_cornell_128": dict(scene="cornell_box", width=128, height=128, spp=4, lattice=1),
+    "c1_sphere_plane_256": dict(scene="sphere_plane", width=256, height=256, spp=1, lattice=1, png=True),
+    "c2_cornell_128": dict(scene="cornell_box", width=128, height=128, spp=4, lattice=1, png=True),
     "c2_cornell_512_l4": dict(scene="cornell_box", width=512, height=512, spp=4, lattice=4),
     "c3_icosphere_1080p_l24": dict(scene="icosphere_l6", width=1920, height=1080, spp=8, lattice=24),
     "c4_terrain1m_1080p_l40": dict(scene="terrain_1m", width=1920, height=1080, spp=8, lattice=40),
@@ -46,7 +46,7 @@ FIXTURES = {
     "terrain192_d2": dict(scene="terrain_192", width=160, height=90, spp=4, lattice=1),
     "many_materials_two_lights": dict(scene="many_materials", width=96, height=72, spp=2, lattice=1, depth=3, light_mode=1),
     # row N1: texture / alpha / bump path (14 texture files in 9 encodings; alpha holes, translucency, bump frames)
-    "gallery_160x120": dict(scene="textured_gallery", width=160, height=120, spp=4, lattice=1),
+    "gallery_160x120": dict(scene="textured_gallery", width=160, height=120, spp=4, lattice=1, png=True),
     "gallery_two_lights_d4": dict(scene="textured_gallery", width=96, height=72, spp=2, lattice=1, depth=4, light_mode=1, rs=2, ss=2),
     # JPEG textures: 12 baseline files of every sampling layout (grey, 4:4:4 ... 4:1:1, restart intervals, one scan per
     # component, RGB ids) as diffuse / bump / alpha maps; pins the decoder's IDCT, upsampling and colour arithmetic
@@ -89,7 +89,7 @@ def generate(name: str, cfg: dict, scene_cache: dict) -> None:
                             s.camera_facing, s.fov, bounce_depth=cfg.get("depth", 2),
                             reflection_samples=cfg.get("rs", 1), spec_samples=cfg.get("ss", 1),
                             lattice=cfg["lattice"], light_mode=cfg.get("light_mode", 0), dump_scene=want_dump,
-                            timeout=6 * 3600, adaptive_max=cfg.get("max_spp", 0))
+                            timeout=6 * 3600, adaptive_max=cfg.get("max_spp", 0), write_png=bool(cfg.get("png")))
     st = ref["stats"]
     out = dict(
         scene=scene_name, width=cfg["width"], height=cfg["height"], spp=cfg["spp"], lattice=cfg["lattice"],
@@ -103,6 +103,11 @@ def generate(name: str, cfg: dict, scene_cache: dict) -> None:
         reference_render_seconds=st["render_seconds"], reference_hierarchy_seconds=st["hierarchy_seconds"],
     )
     assert np.all(ref["pixels"][:, :, 3] == 1.0)
+    if ref.get("png"):
+        # the output path (main.cpp:78-131): bytes of the PNG the reference's own WriteFramebufferImage wrote for this frame,
+        # and the float LogAverageLuma returned
+        out["rgba8"] = orc.decode_png_rgba8(ref["png"])
+        out["scene_luma_bits"] = np.uint32(st["scene_luma_bits"])
     if want_dump:
         sc = ref["scene"]
         out["spheres"] = np.frombuffer(sc["spheres"], dtype=np.float32).reshape(-1, 4).copy()
@@ -127,6 +132,39 @@ def generate(name: str, cfg: dict, scene_cache: dict) -> None:
         st["render_seconds"], time.time() - t0), flush=True)
 
 
+# Scenes whose prt_scene_desc - FlattenReferenceScene (include/prt_flatten_ref.h) run inside ref_harness over the REFERENCE's
+# own scene graph - is stored whole: tests/golden/desc_<scene>.npz.  The CPU tests compare it byte for byte with the host
+# mirror's flattening; the GPU tests upload it through prt_upload_scene (the level-1 drop-in: the reference's loader, graph
+# and decoded textures feeding the HIP path) and match the frame fixture named here.
+DESC_FIXTURES = {
+    "cornell_box": "c2_cornell_128",
+    "textured_gallery": "gallery_160x120",
+    "terrain_64": "terrain64_d3",
+}
+
+
+def generate_desc(scene_name: str, scene_cache: dict) -> None:
+    if scene_name not in scene_cache:
+        d = tempfile.mkdtemp(prefix="prt_golden_%s_" % scene_name)
+        s = scenes.make_scene(scene_name)
+        scenes.write_obj(s, d, "scene.obj")
+        scene_cache[scene_name] = (s, d)
+    s, d = scene_cache[scene_name]
+    ref = orc.run_reference(d, "scene.obj", 16, 16, 1, 1234, s.camera_position, s.camera_facing, s.fov, render=False,
+                            dump_desc=True)
+    raw = ref["desc"]
+    f32 = ("positions", "normals", "texcoords", "tangents")
+    u32 = ("idx_positions", "idx_texcoords", "idx_normals", "texture_dims")
+    out = {}
+    for k, v in raw.items():
+        dt = np.float32 if k in f32 else np.uint32 if k in u32 else np.int32 if k == "sphere_group" else np.uint8
+        out[k] = np.frombuffer(v, dtype=dt).copy()
+    np.savez_compressed(os.path.join(GOLDEN, "desc_%s.npz" % scene_name), **out)
+    print("desc_%s.npz: %d triangles, %d groups, %d materials, %d textures (%d texel bytes)" % (
+        scene_name, out["idx_positions"].size // 3, out["groups"].size // 12, out["materials"].size // 80,
+        out["texture_dims"].size // 3, out["texture_bytes"].size))
+
+
 def generate_kat(scene_cache: dict) -> None:
     s = scenes.make_scene("sphere_plane")
     d = tempfile.mkdtemp(prefix="prt_golden_kat_")
@@ -149,10 +187,12 @@ def main():
     if not orc.have_reference():
         raise SystemExit("oracle/_ref/ref_harness missing: run `make -C oracle ref` in the build container")
     cache = {}
-    names = args.only if args.only else ["kat"] + list(FIXTURES)
+    names = args.only if args.only else ["kat"] + list(FIXTURES) + ["desc_" + k for k in DESC_FIXTURES]
     for n in names:
         if n == "kat":
             generate_kat(cache)
+        elif n.startswith("desc_"):
+            generate_desc(n[5:], cache)
         else:
             generate(n, FIXTURES[n], cache)
 

@@ -97,8 +97,10 @@ def run_reference(directory: str, obj_name: str, width: int, height: int, spp: i
                   camera_position: Sequence[float], camera_facing: Sequence[float], fov: float = 60.0,
                   bounce_depth: int = 2, reflection_samples: int = 1, spec_samples: int = 1, lattice: int = 1,
                   light_mode: int = 0, render: bool = True, dump_scene: bool = False, kat: bool = False,
-                  timeout: float = 3600.0, adaptive_max: int = 0) -> dict:
-    """Run the compiled, unmodified reference through ref_harness.  Returns {'pixels', 'stats', 'scene', 'kat'}."""
+                  timeout: float = 3600.0, adaptive_max: int = 0, dump_desc: bool = False, write_png: bool = False) -> dict:
+    """Run the compiled, unmodified reference through ref_harness.  Returns {'pixels', 'stats', 'scene', 'kat', 'desc',
+    'png'}: 'desc' = the arrays of FlattenReferenceScene over the reference's scene graph, 'png' = the bytes of the file
+    the reference's own WriteFramebufferImage wrote for the rendered frame (lattice 1 only)."""
     if not have_reference():
         raise RuntimeError("oracle/_ref/ref_harness is not built (needs /root/reference; `make -C oracle ref`)")
     with tempfile.TemporaryDirectory() as tmp:
@@ -117,12 +119,21 @@ def run_reference(directory: str, obj_name: str, width: int, height: int, spp: i
             cmd += ["--dump-scene", os.path.join(tmp, "scene.bin")]
         if kat:
             cmd += ["--kat", os.path.join(tmp, "kat.bin")]
+        if dump_desc:
+            cmd += ["--dump-desc", os.path.join(tmp, "desc.bin")]
+        if write_png and render and lattice == 1:
+            cmd += ["--write-png", os.path.join(tmp, "out.png")]
         proc = subprocess.run(cmd, cwd=tmp, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout)
         if proc.returncode != 0:
             raise RuntimeError("ref_harness failed (%d): %s" % (proc.returncode, proc.stderr.decode()[-2000:]))
         with open(os.path.join(tmp, "stats.json")) as f:
             stats = json.load(f)
-        res = {"stats": stats, "pixels": None, "scene": None, "kat": None}
+        res = {"stats": stats, "pixels": None, "scene": None, "kat": None, "desc": None, "png": None}
+        if dump_desc:
+            res["desc"] = read_sections(os.path.join(tmp, "desc.bin"))
+        if write_png and render and lattice == 1:
+            with open(os.path.join(tmp, "out.png"), "rb") as f:
+                res["png"] = f.read()
         if render:
             lw, lh = stats["lattice_width"], stats["lattice_height"]
             res["pixels"] = np.fromfile(os.path.join(tmp, "out.f32"), dtype=np.float32).reshape(lh, lw, 4)
@@ -131,3 +142,51 @@ def run_reference(directory: str, obj_name: str, width: int, height: int, spp: i
         if kat:
             res["kat"] = read_sections(os.path.join(tmp, "kat.bin"))
         return res
+
+
+def decode_png_rgba8(data: bytes) -> np.ndarray:
+    """Minimal PNG reader for what stbi_write_png(..., comp = 4, ...) writes (8-bit RGBA, not interlaced): [h, w, 4] u8.
+    Test infrastructure: lets the golden fixtures hold the bytes of the reference's own output file without going
+    through this repository's image decoders."""
+    import struct
+    import zlib
+    assert data[:8] == b"\x89PNG\r\n\x1a\n"
+    off, idat, w, h = 8, b"", 0, 0
+    while off < len(data):
+        n, kind = struct.unpack(">I4s", data[off:off + 8])
+        body = data[off + 8:off + 8 + n]
+        off += 12 + n
+        if kind == b"IHDR":
+            w, h, depth, ctype, _, _, interlace = struct.unpack(">IIBBBBB", body)
+            assert (depth, ctype, interlace) == (8, 6, 0), "not an 8-bit RGBA non-interlaced PNG"
+        elif kind == b"IDAT":
+            idat += body
+        elif kind == b"IEND":
+            break
+    raw = np.frombuffer(zlib.decompress(idat), dtype=np.uint8).reshape(h, 1 + 4 * w)
+    out = np.zeros((h, 4 * w), dtype=np.uint8)
+    prev = np.zeros(4 * w, dtype=np.int32)
+    for y in range(h):
+        f, line = int(raw[y, 0]), raw[y, 1:].astype(np.int32)
+        cur = np.zeros(4 * w, dtype=np.int32)
+        if f == 0:
+            cur = line
+        elif f == 2:
+            cur = (line + prev) & 255
+        else:
+            for i in range(4 * w):
+                a = cur[i - 4] if i >= 4 else 0
+                b = prev[i]
+                c = prev[i - 4] if i >= 4 else 0
+                if f == 1:
+                    pred = a
+                elif f == 3:
+                    pred = (a + b) >> 1
+                else:
+                    p0 = a + b - c
+                    pa, pb, pc = abs(p0 - a), abs(p0 - b), abs(p0 - c)
+                    pred = a if (pa <= pb and pa <= pc) else (b if pb <= pc else c)
+                cur[i] = (line[i] + pred) & 255
+        out[y] = cur.astype(np.uint8)
+        prev = cur
+    return out.reshape(h, w, 4)

@@ -13,7 +13,11 @@
 //   * per-(pixel,sample) reseed Random_Seed(&job.rng, prt_sample_key(seed, pixel, sample)) so pixels
 //     are independent of the rank count and of each other;
 //   * an optional sparse pixel lattice, raw f32 output, scene / sphere-tree dumps and per-function
-//     known-answer vectors for the CPU restatement's unit tests.
+//     known-answer vectors for the CPU restatement's unit tests;
+//   * --dump-desc: FlattenReferenceScene (include/prt_flatten_ref.h) run over the reference's own Scene graph, every
+//     array of the resulting prt_scene_desc written out - what a maintainer's RenderTask would hand to prt_upload_scene;
+//   * --write-png: the reference's own WriteFramebufferImage (LogAverageLuma + Color_Pack + stbi_write_png,
+//     main.cpp:78-131) on the rendered frame, and LogAverageLuma's value in the stats - pins the output path.
 //
 // Build: see oracle/Makefile (flags follow the reference's build.sh:6).
 
@@ -22,6 +26,8 @@
 #undef main
 
 #include "../include/prt_key.h"
+// the level-1 drop-in's flattening, compiled here against the reference's REAL scene types
+#include "../include/prt_flatten_ref.h"
 
 #include <string>
 #include <time.h>
@@ -32,6 +38,12 @@ double NowSeconds() {
     timespec ts;
     clock_gettime(CLOCK_MONOTONIC, &ts);
     return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+u32 FloatBits(float f) {
+    u32 u;
+    memcpy(&u, &f, 4);
+    return u;
 }
 
 struct Section {
@@ -60,6 +72,8 @@ struct HarnessArgs {
     const char * dump_scene = NULL;
     const char * kat = NULL;
     const char * stats = NULL;
+    const char * dump_desc = NULL;
+    const char * write_png = NULL;
 };
 
 HarnessArgs ParseHarnessArgs(int argc, char ** argv) {
@@ -77,6 +91,8 @@ HarnessArgs ParseHarnessArgs(int argc, char ** argv) {
         else if (s == "--dump-scene" && has_val) a.dump_scene = argv[++i];
         else if (s == "--kat" && has_val) a.kat = argv[++i];
         else if (s == "--stats" && has_val) a.stats = argv[++i];
+        else if (s == "--dump-desc" && has_val) a.dump_desc = argv[++i];
+        else if (s == "--write-png" && has_val) a.write_png = argv[++i];
     }
     return a;
 }
@@ -324,6 +340,36 @@ void DumpScene(const char * path, Mesh * mesh, BoundingHierarchy * h, Scene * sc
     fclose(fp);
 }
 
+// Every array of the prt_scene_desc FlattenReferenceScene builds from the reference's scene graph.
+void DumpDesc(const char * path, Scene * scene) {
+    RefFlatScene flat;
+    FlattenReferenceScene(scene, &flat);
+    FILE * fp = fopen(path, "wb");
+    Section out = { fp };
+    out.PutVec("positions", flat.positions);
+    out.PutVec("normals", flat.normals);
+    out.PutVec("texcoords", flat.texcoords);
+    out.PutVec("tangents", flat.tangents);
+    out.PutVec("idx_positions", flat.idx_positions);
+    out.PutVec("idx_texcoords", flat.idx_texcoords);
+    out.PutVec("idx_normals", flat.idx_normals);
+    out.PutVec("groups", flat.groups);               // prt_group records, 12 bytes
+    out.PutVec("materials", flat.materials);         // prt_material records, 80 bytes
+    out.PutVec("lights", flat.lights);               // prt_light records, 48 bytes
+    out.PutVec("spheres", flat.spheres);             // prt_bsphere records, 24 bytes
+    out.PutVec("sphere_group", flat.sphere_group);
+    std::vector<u32> dims;
+    std::vector<u8> texels;
+    for (size_t i = 0; i < flat.textures.size(); ++i) {
+        const prt_texture & t = flat.textures[i];
+        dims.push_back(t.size_x); dims.push_back(t.size_y); dims.push_back(t.channels);
+        texels.insert(texels.end(), t.texels, t.texels + (size_t)t.size_x * t.size_y * t.channels);
+    }
+    out.PutVec("texture_dims", dims);
+    out.PutVec("texture_bytes", texels);
+    fclose(fp);
+}
+
 }  // namespace
 
 int main(int argc, char ** argv) {
@@ -377,12 +423,14 @@ int main(int argc, char ** argv) {
     }
 
     if (args.dump_scene) DumpScene(args.dump_scene, mesh, &hierarchy, &scene);
+    if (args.dump_desc) DumpDesc(args.dump_desc, &scene);
     if (args.kat) WriteKnownAnswers(args.kat, &cam);
 
     u32 w = gParams.image_width, h = gParams.image_height;
     u32 lw = (w + args.lattice - 1) / args.lattice, lh = (h + args.lattice - 1) / args.lattice;
     DebugCounters debug = {};
     double render_s = 0.0;
+    float scene_luma = 0.0f;
     if (args.out) {
         RenderSharedData shared;
         shared.cam = &cam;
@@ -426,17 +474,26 @@ int main(int argc, char ** argv) {
         FILE * fp = fopen(args.out, "wb");
         fwrite(&pixels[0], sizeof(Vector4), pixels.size(), fp);
         fclose(fp);
+        if (args.write_png && args.lattice == 1) {
+            // the reference's output path on this frame, untouched: main.cpp:101-131 (and :78-99, color.h:105-111)
+            Framebuffer fb;
+            fb.pixels = &pixels[0];
+            fb.width = w;
+            fb.height = h;
+            scene_luma = LogAverageLuma(&fb);
+            WriteFramebufferImage(&fb, (char *)args.write_png);
+        }
     }
 
     FILE * sf = args.stats ? fopen(args.stats, "w") : stdout;
     fprintf(sf, "{\"triangles\": %u, \"groups\": %u, \"spheres\": %u, \"width\": %u, \"height\": %u, \"lattice\": %u, "
                 "\"lattice_width\": %u, \"lattice_height\": %u, \"spp\": %u, \"seed\": %llu, \"bounce_depth\": %u, "
                 "\"ray_count\": %llu, \"sphere_check_count\": %llu, \"mesh_check_count\": %llu, "
-                "\"render_seconds\": %.6f, \"hierarchy_seconds\": %.6f}\n",
+                "\"render_seconds\": %.6f, \"hierarchy_seconds\": %.6f, \"scene_luma_bits\": %u}\n",
             total_tris, (u32)mesh->groups.size(), (u32)hierarchy.spheres.size(), w, h, args.lattice, lw, lh, args.spp,
             (unsigned long long)args.seed, gParams.bounce_depth,
             (unsigned long long)debug.ray_count, (unsigned long long)debug.sphere_check_count,
-            (unsigned long long)debug.mesh_check_count, render_s, t_build);
+            (unsigned long long)debug.mesh_check_count, render_s, t_build, FloatBits(scene_luma));
     if (args.stats) fclose(sf);
 
     MPI_Finalize();

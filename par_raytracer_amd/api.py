@@ -97,6 +97,89 @@ class HostScene:
             pass
 
 
+# ---- prt_scene_desc <-> flat arrays (the level-1 drop-in's data: what FlattenReferenceScene hands to prt_upload_scene) ---
+
+DESC_F32 = ("positions", "normals", "texcoords", "tangents")
+DESC_U32 = ("idx_positions", "idx_texcoords", "idx_normals", "texture_dims")
+
+
+def desc_arrays(desc_ptr) -> dict:
+    """Every array a prt_scene_desc points to, as flat numpy copies: float / index arrays as such, the record arrays
+    (prt_group 12 B, prt_material 80 B, prt_light 48 B, prt_bsphere 24 B) as raw bytes, textures as (size_x, size_y,
+    channels) triples + the concatenated texel bytes - the layout of oracle/ref_harness --dump-desc."""
+    d = desc_ptr.contents
+    f = capi.np_from_ptr
+
+    def raw(ptr, count, size):
+        return f(C.cast(ptr, C.POINTER(C.c_uint8)), count * size, np.uint8) if count else np.zeros(0, dtype=np.uint8)
+
+    out = {
+        "positions": f(d.positions, d.position_count * 3, np.float32),
+        "normals": f(d.normals, d.normal_count * 3, np.float32),
+        "texcoords": f(d.texcoords, d.texcoord_count * 2, np.float32),
+        "tangents": f(d.tangents, d.normal_count * 3, np.float32) if d.tangents else np.zeros(0, dtype=np.float32),
+        "idx_positions": f(d.idx_positions, d.index_count, np.uint32),
+        "idx_texcoords": f(d.idx_texcoords, d.index_count, np.uint32),
+        "idx_normals": f(d.idx_normals, d.index_count, np.uint32),
+        "groups": raw(d.groups, d.group_count, C.sizeof(capi.PrtGroup)),
+        "materials": raw(d.materials, d.material_count, C.sizeof(capi.PrtMaterial)),
+        "lights": raw(d.lights, d.light_count, C.sizeof(capi.PrtLight)),
+        "spheres": raw(d.spheres, d.sphere_count, C.sizeof(capi.PrtBSphere)),
+        "sphere_group": f(d.sphere_group, d.sphere_count, np.int32) if d.sphere_count else np.zeros(0, dtype=np.int32),
+    }
+    dims, blobs = [], []
+    for i in range(d.texture_count):
+        t = d.textures[i]
+        dims += [t.size_x, t.size_y, t.channels]
+        blobs.append(np.ctypeslib.as_array(t.texels, shape=(t.size_x * t.size_y * t.channels,)).copy())
+    out["texture_dims"] = np.array(dims, dtype=np.uint32)
+    out["texture_bytes"] = np.concatenate(blobs) if blobs else np.zeros(0, dtype=np.uint8)
+    return out
+
+
+class FlatDesc:
+    """A prt_scene_desc built from the arrays of desc_arrays() / a tests/golden/desc_*.npz fixture.  Keeps the arrays
+    alive; `.desc` is what Renderer.upload() and the oracle take."""
+
+    def __init__(self, arrays: dict):
+        a = {k: np.ascontiguousarray(np.asarray(v)) for k, v in arrays.items()}
+        self._keep = a
+        d = capi.PrtSceneDesc()
+
+        def ptr(key, ctype):
+            arr = a[key]
+            return arr.ctypes.data_as(C.POINTER(ctype)) if arr.size else C.cast(None, C.POINTER(ctype))
+
+        d.positions = ptr("positions", C.c_float); d.position_count = a["positions"].size // 3
+        d.normals = ptr("normals", C.c_float); d.normal_count = a["normals"].size // 3
+        d.texcoords = ptr("texcoords", C.c_float); d.texcoord_count = a["texcoords"].size // 2
+        d.tangents = ptr("tangents", C.c_float)
+        d.idx_positions = ptr("idx_positions", C.c_uint32)
+        d.idx_texcoords = ptr("idx_texcoords", C.c_uint32)
+        d.idx_normals = ptr("idx_normals", C.c_uint32)
+        d.index_count = a["idx_positions"].size
+        d.groups = ptr("groups", capi.PrtGroup); d.group_count = a["groups"].size // C.sizeof(capi.PrtGroup)
+        d.materials = ptr("materials", capi.PrtMaterial); d.material_count = a["materials"].size // C.sizeof(capi.PrtMaterial)
+        d.lights = ptr("lights", capi.PrtLight); d.light_count = a["lights"].size // C.sizeof(capi.PrtLight)
+        d.spheres = ptr("spheres", capi.PrtBSphere); d.sphere_count = a["spheres"].size // C.sizeof(capi.PrtBSphere)
+        d.sphere_group = ptr("sphere_group", C.c_int32)
+        dims = a["texture_dims"].reshape(-1, 3)
+        self._tex = (capi.PrtTexture * max(1, len(dims)))()
+        off = 0
+        base = a["texture_bytes"].ctypes.data
+        for i, (sx, sy, ch) in enumerate(dims):
+            self._tex[i].size_x, self._tex[i].size_y, self._tex[i].channels = int(sx), int(sy), int(ch)
+            self._tex[i].texels = C.cast(base + off, C.POINTER(C.c_uint8))
+            off += int(sx) * int(sy) * int(ch)
+        d.textures = C.cast(self._tex, C.POINTER(capi.PrtTexture)) if len(dims) else C.cast(None, C.POINTER(capi.PrtTexture))
+        d.texture_count = len(dims)
+        self._desc = d
+
+    @property
+    def desc(self):
+        return C.pointer(self._desc)
+
+
 def make_camera(fov: float, width: int, height: int, position: Sequence[float], facing: Sequence[float]) -> PrtCamera:
     cam = PrtCamera()
     p = (C.c_float * 3)(*[float(v) for v in position])
@@ -139,7 +222,7 @@ class Renderer:
             raise RuntimeError("%s failed (%d): %s" % (what, rc, self._lib.prt_last_error(self._ctx).decode()))
 
     def upload(self, scene) -> PrtSceneInfo:
-        desc = scene.desc if isinstance(scene, HostScene) else scene
+        desc = scene.desc if isinstance(scene, (HostScene, FlatDesc)) else scene
         self._check(self._lib.prt_upload_scene(self._ctx, desc), "prt_upload_scene")
         return self.scene_info()
 

@@ -151,129 +151,6 @@ void PopulateSceneObjects(Scene * scene, BoundingHierarchy * h, Mesh * mesh, u32
 
 // -------------------------------------------------------------------------------------------------
 
-// Texture slot -> index into FlatScene::textures (one entry per distinct Texture object), -1 = none.
-static s32 TextureSlot(const Texture * t, std::map<const Texture *, s32> * index, std::vector<prt_texture> * out) {
-    if (!t) return -1;
-    std::map<const Texture *, s32>::iterator it = index->find(t);
-    if (it != index->end()) return it->second;
-    prt_texture pt;
-    pt.size_x = t->size_x; pt.size_y = t->size_y; pt.channels = t->channels; pt.texels = t->texels;
-    s32 slot = (s32)out->size();
-    out->push_back(pt);
-    (*index)[t] = slot;
-    return slot;
-}
-
-static prt_material ToPrtMaterial(const Material * m, std::map<const Texture *, s32> * tex_index, std::vector<prt_texture> * textures) {
-    prt_material o;
-    memset(&o, 0, sizeof(o));
-    o.specular_intensity = m->specular_intensity;
-    o.index_of_refraction = m->index_of_refraction;
-    o.alpha = m->alpha;
-    const Vector4 * src[3] = { &m->ambient_color, &m->diffuse_color, &m->specular_color };
-    float * dst[3] = { o.ambient_color, o.diffuse_color, o.specular_color };
-    for (int k = 0; k < 3; ++k) { dst[k][0] = src[k]->x; dst[k][1] = src[k]->y; dst[k][2] = src[k]->z; dst[k][3] = src[k]->w; }
-    o.ambient_texture = TextureSlot(m->ambient_texture, tex_index, textures);
-    o.diffuse_texture = TextureSlot(m->diffuse_texture, tex_index, textures);
-    o.specular_texture = TextureSlot(m->specular_texture, tex_index, textures);
-    o.alpha_texture = TextureSlot(m->alpha_texture, tex_index, textures);
-    o.bump_texture = TextureSlot(m->bump_texture, tex_index, textures);
-    return o;
-}
-
-void FlattenScene(const Scene * scene, FlatScene * out) {
-    const BoundingHierarchy * h = scene->hierarchy;
-    const Mesh * mesh = h->mesh;
-    *out = FlatScene();
-
-    out->positions.resize(mesh->positions.size() * 3);
-    for (size_t i = 0; i < mesh->positions.size(); ++i) {
-        out->positions[3 * i] = mesh->positions[i].x; out->positions[3 * i + 1] = mesh->positions[i].y; out->positions[3 * i + 2] = mesh->positions[i].z;
-    }
-    out->normals.resize(mesh->normals.size() * 3);
-    for (size_t i = 0; i < mesh->normals.size(); ++i) {
-        out->normals[3 * i] = mesh->normals[i].x; out->normals[3 * i + 1] = mesh->normals[i].y; out->normals[3 * i + 2] = mesh->normals[i].z;
-    }
-    out->texcoords.resize(mesh->texcoords.size() * 2);
-    for (size_t i = 0; i < mesh->texcoords.size(); ++i) {
-        out->texcoords[2 * i] = mesh->texcoords[i].x; out->texcoords[2 * i + 1] = mesh->texcoords[i].y;
-    }
-    if (mesh->tangents.size() == mesh->normals.size()) {
-        out->tangents.resize(mesh->tangents.size() * 3);
-        for (size_t i = 0; i < mesh->tangents.size(); ++i) {
-            out->tangents[3 * i] = mesh->tangents[i].x; out->tangents[3 * i + 1] = mesh->tangents[i].y; out->tangents[3 * i + 2] = mesh->tangents[i].z;
-        }
-    }
-
-    // materials: 0 = scene default, then every distinct material the object list references, in the
-    // order groups appear in the mesh.
-    std::map<const Material *, s32> mat_index;
-    std::map<const Texture *, s32> tex_index;
-    out->materials.push_back(ToPrtMaterial(scene->default_mat, &tex_index, &out->textures));
-    mat_index[scene->default_mat] = 0;
-
-    std::map<const MeshGroup *, s32> group_index;
-    for (size_t g = 0; g < mesh->groups.size(); ++g) {
-        const MeshGroup * mg = &mesh->groups[g];
-        const Material * m = mg->material ? mg->material : scene->default_mat;
-        if (!mat_index.count(m)) {
-            mat_index[m] = (s32)out->materials.size();
-            out->materials.push_back(ToPrtMaterial(m, &tex_index, &out->textures));
-        }
-        prt_group pg;
-        pg.first_index = (u32)out->idx_positions.size();
-        pg.index_count = (u32)mg->idx_positions.size();
-        pg.material = mat_index[m];
-        out->groups.push_back(pg);
-        group_index[mg] = (s32)g;
-        out->idx_positions.insert(out->idx_positions.end(), mg->idx_positions.begin(), mg->idx_positions.end());
-        out->idx_texcoords.insert(out->idx_texcoords.end(), mg->idx_texcoords.begin(), mg->idx_texcoords.end());
-        out->idx_normals.insert(out->idx_normals.end(), mg->idx_normals.begin(), mg->idx_normals.end());
-    }
-
-    for (u32 i = 0; i < scene->light_count; ++i) {
-        const LightSource * l = &scene->lights[i];
-        prt_light pl;
-        memset(&pl, 0, sizeof(pl));
-        pl.type = (l->type == Light_Point) ? PRT_LIGHT_POINT : PRT_LIGHT_DIRECTIONAL;
-        pl.color[0] = l->color.x; pl.color[1] = l->color.y; pl.color[2] = l->color.z; pl.color[3] = l->color.w;
-        pl.position[0] = l->position.x; pl.position[1] = l->position.y; pl.position[2] = l->position.z;
-        pl.facing[0] = l->facing.x; pl.facing[1] = l->facing.y; pl.facing[2] = l->facing.z;
-        pl.falloff = l->falloff;
-        out->lights.push_back(pl);
-    }
-
-    for (size_t i = 0; i < h->spheres.size(); ++i) {
-        prt_bsphere s;
-        s.center[0] = h->spheres[i].s.center.x; s.center[1] = h->spheres[i].s.center.y; s.center[2] = h->spheres[i].s.center.z;
-        s.radius = h->spheres[i].s.radius;
-        s.c0 = h->spheres[i].c0;
-        s.c1 = h->spheres[i].c1;
-        out->spheres.push_back(s);
-        const MeshGroup * mg = h->mesh_groups[i];
-        out->sphere_group.push_back(mg ? group_index[mg] : -1);
-    }
-
-    prt_scene_desc & d = out->desc;
-    memset(&d, 0, sizeof(d));
-    d.positions = out->positions.data();   d.position_count = (u32)mesh->positions.size();
-    d.normals = out->normals.data();       d.normal_count = (u32)mesh->normals.size();
-    d.texcoords = out->texcoords.data();   d.texcoord_count = (u32)mesh->texcoords.size();
-    d.tangents = out->tangents.empty() ? NULL : out->tangents.data();
-    d.idx_positions = out->idx_positions.data();
-    d.idx_texcoords = out->idx_texcoords.data();
-    d.idx_normals = out->idx_normals.data();
-    d.index_count = (u32)out->idx_positions.size();
-    d.groups = out->groups.data();         d.group_count = (u32)out->groups.size();
-    d.materials = out->materials.data();   d.material_count = (u32)out->materials.size();
-    d.textures = out->textures.empty() ? NULL : out->textures.data();
-    d.texture_count = (u32)out->textures.size();
-    d.lights = out->lights.data();         d.light_count = (u32)out->lights.size();
-    d.spheres = out->spheres.data();
-    d.sphere_group = out->sphere_group.data();
-    d.sphere_count = (u32)out->spheres.size();
-}
-
 prt_camera ToPrtCamera(const Camera * cam) {
     prt_camera c;
     c.tan_a2 = cam->tan_a2; c.aspect = cam->aspect; c.inv_width = cam->inv_width; c.inv_height = cam->inv_height;

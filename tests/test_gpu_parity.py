@@ -425,3 +425,28 @@ def test_stack_overflow_falls_back_to_the_slow_stack(gpu_renderer_factory, pipel
     monkeypatch.delenv("PRT_STACK_CAP")
     assert np.array_equal(ref.view(np.uint32), got.view(np.uint32))
     assert c_ref.ray_count == c_got.ray_count == int(g["ray_count"])
+
+
+@pytest.mark.parametrize("pipeline", ["wavefront", "pool"])
+@pytest.mark.parametrize("scene,frame", [("cornell_box", "c2_cornell_128"), ("textured_gallery", "gallery_160x120"),
+                                         ("terrain_64", "terrain64_d3")])
+def test_level1_dropin_reference_flattened_scene(scene, frame, pipeline):
+    """The level-1 drop-in: a scene parsed, decoded and linked by the REFERENCE and flattened
+    inside it by include/prt_flatten_ref.h (tests/golden/desc_<scene>.npz holds the resulting prt_scene_desc arrays,
+    texels included) goes through prt_upload_scene / prt_render and must give the reference's own frame.  Nothing of this
+    repository's loader, decoders or host mirror is involved."""
+    from par_raytracer_amd import api
+    d = load_golden("desc_" + scene)
+    g = load_golden(frame)
+    fd = api.FlatDesc({k: d[k] for k in d.files})
+    r = api.Renderer(0)
+    try:
+        info = r.upload(fd)
+        assert info.triangle_count == int(g["triangles"])
+        cam, p = camera_and_params(g, PIPELINES[pipeline])
+        img, ctr = r.render_lattice(cam, p, int(g["width"]), int(g["height"]), int(g["lattice"]))
+    finally:
+        r.close()
+    diff = np.abs(img[:, :, :3] - g["rgb"])
+    assert ctr.ray_count == int(g["ray_count"]), "ray_count %d != reference %d" % (ctr.ray_count, int(g["ray_count"]))
+    assert diff.max() <= TOL, "max|dRGB| = %g" % diff.max()

@@ -603,27 +603,57 @@ def _decode_png(path):
     return w, h, depth, ctype, np.frombuffer(b"".join(rows), dtype=np.uint8).reshape(h, w, 4)
 
 
-def test_tonemap_and_png_roundtrip(tmp_path):
-    g = load_golden("c2_cornell_128")
+@pytest.mark.parametrize("fixture", ["c1_sphere_plane_256", "c2_cornell_128", "gallery_160x120"])
+def test_output_path_is_the_references_byte_for_byte(fixture, tmp_path):
+    """LogAverageLuma + the tone-map loop + Color_Pack (main.cpp:78-127, color.h:105-111) and the PNG behind them.  The
+    fixture holds what the REFERENCE's own WriteFramebufferImage made of its own frame: the float LogAverageLuma returned
+    (bit pattern) and the RGBA8 pixels of the PNG file it wrote.  prt_host_tonemap must return that float and those bytes
+    exactly - the log sum is sequential in row-major order and the pack truncates, so nothing here has a tolerance - and
+    the file prt_host_write_image writes must decode to the same pixels."""
+    g = load_golden(fixture)
+    if "rgba8" not in g:
+        pytest.skip("fixture without the reference's output bytes")
     rgb = g["rgb"]
     h, w = rgb.shape[:2]
     rgba = np.concatenate([rgb, np.ones((h, w, 1), dtype=np.float32)], axis=2).astype(np.float32)
     lib = capi.host_lib()
     out8 = np.zeros((h, w, 4), dtype=np.uint8)
     luma = lib.prt_host_tonemap(rgba.ctypes.data_as(C.c_void_p), w, h, out8.ctypes.data_as(C.c_void_p))
-    # numpy restatement of main.cpp:78-127 in float32, sequential log sum
-    l = (np.float32(0.2126) * rgb[:, :, 0] + np.float32(0.7152) * rgb[:, :, 1]) + np.float32(0.0722) * rgb[:, :, 2]
-    acc = np.float32(0.0)
-    for v in np.log(np.float32(0.01) + l.reshape(-1)).astype(np.float32):
-        acc = np.float32(acc + v)
-    expect_luma = np.exp(acc / np.float32(w * h))
-    assert abs(luma - expect_luma) <= 2e-6 * expect_luma
+    assert np.float32(luma).view(np.uint32) == np.uint32(g["scene_luma_bits"]), "LogAverageLuma differs from the reference's"
+    assert np.array_equal(out8, g["rgba8"]), "%d bytes differ from the reference's PNG" % int((out8 != g["rgba8"]).sum())
     assert np.all(out8[:, :, 3] == 255) and out8[:, :, :3].max() > 40
     path = str(tmp_path / "o.png")
     assert lib.prt_host_write_image(rgba.ctypes.data_as(C.c_void_p), w, h, path.encode()) == 0
     pw, ph, depth, ctype, px = _decode_png(path)
     assert (pw, ph, depth, ctype) == (w, h, 8, 6)
-    assert np.array_equal(px, out8)
+    assert np.array_equal(px, g["rgba8"])
+
+
+# ---- level-1 drop-in: FlattenReferenceScene over the reference's own scene graph --------------------------------------
+
+@pytest.mark.parametrize("scene", ["cornell_box", "textured_gallery", "terrain_64"])
+def test_flattened_reference_scene_equals_the_host_mirrors(scene):
+    """tests/golden/desc_<scene>.npz is include/prt_flatten_ref.h run INSIDE the reference (oracle/ref_harness --dump-desc:
+    its OBJ / MTL / texture loaders, its Scene -> SceneObject -> MeshGroup graph, its sphere tree).  Every array must be
+    byte for byte what this repository's loader + host mirror hand to prt_upload_scene for the same files."""
+    from par_raytracer_amd import api
+    g = load_golden("desc_" + scene)
+    mine = api.desc_arrays(host_scene(scene, 0).desc)
+    assert sorted(mine) == sorted(g.files)
+    for k in g.files:
+        want, got = g[k], mine[k]
+        assert want.dtype == got.dtype and want.shape == got.shape, k
+        assert np.array_equal(want.view(np.uint8), got.view(np.uint8)), "%s: %d differing bytes" % (k, int((want.view(np.uint8) != got.view(np.uint8)).sum()))
+    # and the arrays make a scene the CPU restatement renders to the reference's own pixels
+    fd = api.FlatDesc({k: g[k] for k in g.files})
+    frame = {"cornell_box": "c2_cornell_128", "textured_gallery": "gallery_160x120", "terrain_64": "terrain64_d3"}[scene]
+    gf = load_golden(frame)
+    from conftest import camera_and_params
+    import oracle_py as orc
+    cam, p = camera_and_params(gf)
+    img, ctr = orc.render(fd.desc, cam, p, int(gf["width"]), int(gf["height"]), 1, 4)
+    assert ctr.ray_count == int(gf["ray_count"])
+    assert np.array_equal(img[:, :, :3].view(np.uint32), gf["rgb"].view(np.uint32))
 
 
 # ---- driver binary ------------------------------------------------------------------------------------------------
