@@ -45,6 +45,9 @@ FIXTURES = {
     "terrain64_d3": dict(scene="terrain_64", width=80, height=60, spp=2, lattice=1, depth=3),
     "terrain192_d2": dict(scene="terrain_192", width=160, height=90, spp=4, lattice=1),
     "many_materials_two_lights": dict(scene="many_materials", width=96, height=72, spp=2, lattice=1, depth=3, light_mode=1),
+    # near-coincident hits: the reference's visit order decides (raytracer.cpp:104, 149, 208-209, 220)
+    "coincident_192x144_d3": dict(scene="coincident", width=192, height=144, spp=4, lattice=1, depth=3, png=True),
+    "coincident_two_lights": dict(scene="coincident", width=96, height=72, spp=2, lattice=1, depth=2, light_mode=2),
     # row N1: texture / alpha / bump path (14 texture files in 9 encodings; alpha holes, translucency, bump frames)
     "gallery_160x120": dict(scene="textured_gallery", width=160, height=120, spp=4, lattice=1, png=True),
     "gallery_two_lights_d4": dict(scene="textured_gallery", width=96, height=72, spp=2, lattice=1, depth=4, light_mode=1, rs=2, ss=2),

@@ -1472,6 +1472,91 @@ def textured_gallery(sphere_segments: int = 20, sphere_rings: int = 10) -> ObjSc
         camera_position=(0.3, 1.4, 4.6), camera_facing=(-0.05, -0.18, -1.0), fov=60.0)
 
 
+def coincident_geometry() -> ObjScene:
+    """Adversarial geometry for the one place where the reference's VISIT ORDER is observable (raytracer.cpp:104, 149,
+    208-209, 220): hits whose t agree to within a few ulp.  Real OBJ scenes have them - decals laid onto walls, faces
+    exported twice, coplanar patches from different groups - and the reference resolves them by a sequential filter
+    (`t > best * d` early reject, then strict `<`) in sphere-tree order, which any other traversal order has to replay.
+
+    A slanted base plane (so that t, d and the barycentrics round differently for every triangulation) carries, each in
+    its own group and material: a coplanar patch triangulated the other way; patches lifted by 1, 2, 3 and 4 ulp of the
+    coordinates; a patch pushed 2 ulp BELOW the base; a patch whose faces appear twice in the group and once more in
+    another group; a finely tessellated coplanar patch (32 x 32 quads: shared edges and vertices hit head-on); a
+    translucent coplanar patch (a different winner changes the ray count, not only the colour).  A second slanted wall
+    catches the bounces."""
+    pos, nrm, uv = [], [], []
+    groups = []
+    n = _normalize(np.array([[0.2, 1.0, 0.35]], dtype=np.float64))[0]
+    u = _normalize(np.array([[1.0, 0.3, 0.1]], dtype=np.float64))[0]
+    u = _normalize((u - n * np.dot(u, n))[None, :])[0]
+    v = np.cross(n, u)
+    origin = np.array([0.3, 0.9, -1.7])
+
+    def P(a, b, lift_ulps=0.0):
+        q = origin + a * u + b * v
+        q32 = q.astype(np.float32)
+        if lift_ulps:
+            # move every coordinate by k ulp (of itself) along the sign of the plane normal's component
+            q32 = (q32.astype(np.float64) + lift_ulps * np.spacing(np.abs(q32)).astype(np.float64) * np.sign(n)).astype(np.float32)
+        return [float(x) for x in q32]
+
+    def patch(name, material, a0, a1, b0, b1, lift=0.0, flip_diag=False, repeat=1, cells=1):
+        tris = []
+        for r in range(repeat):
+            for ia in range(cells):
+                for ib in range(cells):
+                    aa0 = a0 + (a1 - a0) * ia / cells; aa1 = a0 + (a1 - a0) * (ia + 1) / cells
+                    bb0 = b0 + (b1 - b0) * ib / cells; bb1 = b0 + (b1 - b0) * (ib + 1) / cells
+                    base = len(pos)
+                    for (a, b) in ((aa0, bb0), (aa1, bb0), (aa1, bb1), (aa0, bb1)):     # counter-clockwise seen from +n
+                        pos.append(P(a, b, lift)); nrm.append([float(x) for x in n]); uv.append([a, b])
+                    if flip_diag:
+                        tris += [[base + 1, base + 2, base + 3], [base + 1, base + 3, base]]
+                    else:
+                        tris += [[base, base + 1, base + 2], [base, base + 2, base + 3]]
+        groups.append(ObjGroup(name, _faces_same_index(np.array(tris)), material))
+        return tris
+
+    patch("base", "base", -4.0, 4.0, -4.0, 4.0)
+    patch("coplanar_flip", "m_flip", -3.5, -2.0, -3.0, -1.0, flip_diag=True)
+    for k in (1, 2, 3, 4):
+        patch("lift_%dulp" % k, "m_lift%d" % k, -1.8 + 0.9 * (k - 1), -1.0 + 0.9 * (k - 1), -3.0, -1.0, lift=float(k))
+    patch("sunk_2ulp", "m_sunk", 2.0, 3.5, -3.0, -1.0, lift=-2.0)
+    t_double = patch("doubled", "m_double", -3.5, -1.5, -0.5, 1.0, repeat=2)
+    # the same faces once more, through another group with another material (re-using the first copy's vertices)
+    groups.append(ObjGroup("doubled_again", _faces_same_index(np.array(t_double[:2])), "m_double2"))
+    patch("tessellated", "m_tess", -1.0, 1.5, -0.5, 2.0, cells=32)
+    patch("translucent", "m_trans", 2.0, 3.5, -0.5, 1.5)
+    patch("stack_a", "m_lift1", -3.5, -1.5, 1.5, 3.5, lift=1.0)
+    patch("stack_b", "m_lift2", -3.0, -1.0, 2.0, 3.8, lift=1.0, flip_diag=True)
+    patch("stack_c", "m_lift3", -2.5, -0.5, 1.2, 3.0)
+    # a wall facing the base plane and the light, for the bounces
+    wn = _normalize(np.array([[-0.6, 0.25, 0.75]]))[0]
+    wu = _normalize(np.cross(wn, [0.0, 1.0, 0.0])[None, :])[0]
+    wv = np.cross(wu, wn)
+    wo = np.array([3.2, 1.2, -3.2])
+    corners = [wo - 2.5 * wu - 1.2 * wv, wo + 2.5 * wu - 1.2 * wv, wo + 2.5 * wu + 2.4 * wv, wo - 2.5 * wu + 2.4 * wv]
+    if np.dot(np.cross(corners[1] - corners[0], corners[2] - corners[0]), wn) < 0:
+        corners = corners[::-1]
+    groups.append(ObjGroup("wall", _faces_same_index(np.array(_quad(pos, nrm, uv, corners, tuple(wn), [(0, 0), (1, 0), (1, 1), (0, 1)]))), "wall"))
+
+    def mat(name, kd, d=1.0, ks=(0.2, 0.2, 0.2), ns=12.0):
+        return MtlMaterial(name, Ns=ns, Ni=1.5, d=d, Ka=kd, Kd=kd, Ks=ks)
+
+    materials = [
+        mat("base", (0.55, 0.55, 0.55)), mat("m_flip", (0.9, 0.1, 0.1)), mat("m_lift1", (0.1, 0.8, 0.1)), mat("m_lift2", (0.1, 0.1, 0.9)),
+        mat("m_lift3", (0.9, 0.8, 0.1)), mat("m_lift4", (0.8, 0.1, 0.8)), mat("m_sunk", (0.1, 0.8, 0.8)),
+        mat("m_double", (1.0, 0.5, 0.0), ks=(0.8, 0.8, 0.8), ns=40.0), mat("m_double2", (0.0, 0.4, 1.0)),
+        mat("m_tess", (0.9, 0.9, 0.9), ks=(0.5, 0.5, 0.5), ns=25.0), mat("m_trans", (0.9, 0.3, 0.5), d=0.4),
+        mat("wall", (0.7, 0.65, 0.5)),
+    ]
+    return ObjScene(
+        name="coincident_geometry",
+        positions=np.array(pos, dtype=F32), texcoords=np.array(uv, dtype=F32), normals=np.array(nrm, dtype=F32),
+        groups=groups, materials=materials,
+        camera_position=(0.2, 5.2, 4.4), camera_facing=(0.02, -0.78, -0.9), fov=60.0)
+
+
 def jpeg_gallery() -> ObjScene:
     """JPEG textures through the loader and the texture path: thirteen panels in two rows over a floor, one per JPEG layout
     write_jpeg produces - baseline grey, 4:4:4, 4:2:2, 4:4:0, 4:2:0, 4:1:1, 4:2:0 with a restart interval, one scan per
@@ -1879,6 +1964,7 @@ SCENES = {
     "terrain_64": lambda: terrain(64, 4, size=64.0),          # 8,192 tris in 16 groups, CPU-test sized
     "terrain_192": lambda: terrain(192, 8, size=192.0),       # 73,728 tris in 64 groups
     "many_materials": lambda: many_materials(),               # 1,282 tris, 42 materials (LDS table fallback), translucent clusters
+    "coincident": lambda: coincident_geometry(),              # 2,100 tris: coplanar / ulp-offset / doubled faces in different groups (visit-order parity)
     "textured_gallery": lambda: textured_gallery(),           # 192 tris, 7 materials, 14 texture files (row N1)
     "pic_gallery": lambda: pic_gallery(),                     # 14 tris, 7 materials, 7 Softimage files: raw / pure / mixed run-length, alpha packets
     "hdr_gallery": lambda: hdr_gallery(),                     # 10 tris, 5 materials, 5 Radiance files: run-length, flat, narrow

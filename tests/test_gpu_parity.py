@@ -16,7 +16,10 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-4      # north_star: "per-pixel RGB within 1e-4 of the reference"
 
 SMALL = ["c1_sphere_plane_256", "c2_cornell_128", "c2_cornell_512_l4", "cornell_point_light_d5",
-         "icosphere_l3_two_lights", "terrain64_d3", "terrain192_d2", "many_materials_two_lights"]
+         "icosphere_l3_two_lights", "terrain64_d3", "terrain192_d2", "many_materials_two_lights",
+         # coplanar patches of different groups, decals 1-4 ulp off their wall, doubled faces, shared edges hit head-on: the
+         # reference's sequential filter in ITS visit order decides these hits (raytracer.cpp:104, 149, 208-209, 220)
+         "coincident_192x144_d3", "coincident_two_lights"]
 BIG = ["c3_icosphere_1080p_l24", "c4_terrain1m_1080p_l40", "c5_terrain1m_4k_l120"]
 TEXTURED = ["gallery_160x120", "gallery_two_lights_d4", "jpeg_gallery_128x96", "png_gallery_128x96", "bmp_gallery_128x96", "tga_gallery_128x96", "gif_gallery_128x96", "psd_gallery_128x96", "hdr_gallery_128x96", "pic_gallery_128x96"]       # row N1: ambient / diffuse / specular / alpha / bump maps
 ADAPTIVE = ["cornell_adaptive_4_16", "gallery_adaptive_10_50", "terrain64_adaptive_3_12_d4", "c4_terrain1m_adaptive_l60"]   # row N4

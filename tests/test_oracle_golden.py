@@ -16,7 +16,7 @@ from conftest import camera_and_params, host_scene, load_golden, scene_dir
 import oracle_py as orc
 
 FAST = ["c1_sphere_plane_256", "c2_cornell_128", "c2_cornell_512_l4", "cornell_point_light_d5",
-        "icosphere_l3_two_lights", "terrain64_d3", "gallery_160x120", "gallery_two_lights_d4",
+        "icosphere_l3_two_lights", "terrain64_d3", "coincident_192x144_d3", "coincident_two_lights", "gallery_160x120", "gallery_two_lights_d4",
         "cornell_adaptive_4_16", "gallery_adaptive_10_50", "terrain64_adaptive_3_12_d4", "many_materials_two_lights",
         "jpeg_gallery_128x96", "png_gallery_128x96", "bmp_gallery_128x96", "tga_gallery_128x96", "gif_gallery_128x96", "psd_gallery_128x96", "hdr_gallery_128x96", "pic_gallery_128x96"]
 SLOW = ["terrain192_d2", "c3_icosphere_1080p_l24", "c4_terrain1m_1080p_l40", "c4_terrain1m_adaptive_l60"]
@@ -71,6 +71,7 @@ def test_lattice_is_a_subset_of_the_full_frame():
     ("sphere_plane", 48, 48, 2, 2, 2, 2, 1, 7),
     ("terrain_64", 32, 24, 2, 6, 0, 1, 1, 424242),
     ("textured_gallery", 56, 40, 3, 5, 2, 1, 2, 31337),          # textures + point light + deep alpha chains
+    ("coincident", 64, 48, 3, 4, 1, 1, 1, 2025),                 # coplanar / ulp-offset / doubled faces: visit order decides
 ])
 def test_live_against_compiled_reference(scene, w, h, spp, depth, lm, rs, ss, seed):
     from par_raytracer_amd import api
