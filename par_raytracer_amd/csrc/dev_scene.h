@@ -108,9 +108,13 @@ struct DevParams {
     //   otherwise: row-blocks of shard_block_rows rows, block b of this rank = image block b*nranks + rank
     unsigned int first_pixel, shard_block_rows, shard_rank, shard_nranks;
     const unsigned int * pixel_list;   // explicit pixel ids (prt_render_pixel_list) or NULL
-    // traversal stack: LDS entries per lane, then a global spill column per lane (dev_trace.h TravStack)
+    // traversal stack: LDS entries per lane, then a global spill column per lane for the rest of the bound (dev_trace.h
+    // LdsStack; null when the LDS column covers the bound)
     int * stack_spill;
     unsigned int stack_lds_entries, stack_spill_stride;
+    // full-height global stack columns of k_trace_exact's fixed grid (wavefront pipeline)
+    int * exact_stack;
+    unsigned int exact_stack_stride;
     unsigned int local_base;                    // large calls run in passes of bounded workspace (prt_api.hip render_pixels)
     // adaptive sampling (main.cpp:245-258): on when max_spp > spp; k_pool<ADAPT> only
     unsigned int max_spp;
@@ -137,7 +141,41 @@ struct DevCounters {          // device-side accumulators (atomics, one add per 
     // k_pool, COUNT builds: wave-cycles (s_memtime) spent in the top-up / trace / shade phase, in the whole main loop, and
     // (adaptive mode) in the finalise step, which is part of the shade phase
     unsigned long long phase_cycles[5];
+    // pool pipeline: the most entries any pass wanted to put on its park lists ([0] closest-hit rays + finalise steps, [1] shadow
+    // rays); above the lists' capacities the frame is incomplete and render_pixels renders it again with longer lists
+    unsigned long long park_peak[2];
 };
+
+// Per-sample radiance accumulator of the wavefront and pool pipelines: 2^-32 fixed point in 64-bit integers.  A sample's
+// contributions arrive in an order that depends on the pipeline, on the number of lights (the shadow rays of one hit finish
+// in either order), on the slow path (a parked ray lands later) - integer addition does not care, so the sample's radiance
+// is the same bits every time.  A contribution is truncated to a multiple of 2^-32 (exact for floats >= 2^-8; the whole
+// chain stays far inside the 1e-4 tolerance); |sum| < 2^31.
+struct Accum { long long x, y, z, w; };
+
+PRT_D long long accum_fix(float c) {
+    const float m = fabsf(c);
+    const unsigned int hi = (unsigned int)m;                                    // v_cvt_u32_f32: truncates, saturates, NaN -> 0
+    const unsigned int lo = (unsigned int)((m - (float)hi) * 4294967296.0f);    // (float)hi is exact wherever the difference is not 0
+    const long long v = (long long)((unsigned long long)hi << 32 | lo);
+    return c < 0.0f ? -v : v;
+}
+PRT_D float accum_float(long long v) { return (float)((double)v * (1.0 / 4294967296.0)); }
+PRT_D void accum_zero(Accum * a) { a->x = 0; a->y = 0; a->z = 0; a->w = 0; }
+// Additions are atomics without return value, always: the issuing wave does not wait for them (a read-modify-write would
+// park it for a memory round trip at every finished shadow ray), and several shadow rays of one sample may finish at once.
+// They are performed in the L2, past the compute unit's vector L1 - so reads must not be served from that L1 either.
+PRT_D void accum_add(Accum * a, f3 c) {
+    __hip_atomic_fetch_add(reinterpret_cast<unsigned long long *>(&a->x), (unsigned long long)accum_fix(c.x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_add(reinterpret_cast<unsigned long long *>(&a->y), (unsigned long long)accum_fix(c.y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_add(reinterpret_cast<unsigned long long *>(&a->z), (unsigned long long)accum_fix(c.z), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+PRT_D f3 accum_read(const Accum * a) {
+    const long long x = __hip_atomic_load(&a->x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const long long y = __hip_atomic_load(&a->y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const long long z = __hip_atomic_load(&a->z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return mk3(accum_float(x), accum_float(y), accum_float(z));
+}
 
 enum { BVH_LEAF_MAX = 4 };
 

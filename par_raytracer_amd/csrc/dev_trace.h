@@ -10,12 +10,15 @@
 //     2^-16 of the scene + camera extent, >= 100x the rounding of the slab arithmetic and of the triangle
 //     test's acceptance region) by shifting the ray origin per plane side, so a slab test with plain
 //     float rounding can never cull a triangle the reference would accept;
-//   * ties in t are broken by the triangle's rank in the reference's visit order.
-// The early reject `t > best*d` (raytracer.cpp:104) is kept in the same form; like in the reference it
-// can differ by an ulp from the final `t*ood < best` test for two nearly coincident hits, the one place
-// where visit order is observable (SURVEY.md §7.2 "Tie-breaking").
+//   * hits whose t agree to within a few ulp (coplanar patches, decals, doubled faces, shared edges hit head-on) are
+//     where the reference's VISIT ORDER is observable: it runs a sequential filter - early reject `t > best*d`
+//     (raytracer.cpp:104), then strict `<` (:149, :220) - over the triangles in sphere-tree order (:208-209), and the two
+//     tests can disagree by an ulp.  The traversal here finds the exact minimum of t in any order and FLAGS a ray whose
+//     minimum has company within 2^-19 of it; a flagged ray is then decided by resolve_near_ties(): the candidates near
+//     the minimum are enumerated in the reference's visit order (tri_rank) and put through the reference's filter, form
+//     for form.  Scenes without such geometry never take that path.
 //
-// Traversal stack: per-lane LDS column, with a flag-and-retrace fallback on a global column (see LdsStack).
+// Traversal stack: per-lane LDS column that continues in a per-lane global column when it is full (see LdsStack).
 #pragma once
 
 #include "dev_scene.h"
@@ -44,36 +47,69 @@ PRT_D bool first_active_lane() {
 PRT_D float as_f(int v) { return __int_as_float(v); }
 PRT_D int as_i(float v) { return __float_as_int(v); }
 
-// Reference triangle test on pre-differenced data.  Returns true and updates (best_t, v, w) when the
-// reference's IntersectRayTriangle would return true AND IntersectRayMesh would keep it (strict <).
-// `equal_t` reports a bit-equal t so the caller can consult the visit rank.
-PRT_D bool tri_test(f3 o, f3 d, f3 qp, f3 a, f3 ab, f3 ac, f3 n, float best_t, float & out_t, float & out_v, float & out_w,
-                    bool & equal_t) {
-    equal_t = false;
-    float dd = dot3(qp, n);
+// The geometric part of IntersectRayTriangle (raytracer.cpp:82-125) on pre-differenced data: everything except the two
+// comparisons with the caller's best hit.  True when the ray's line meets the front side of the triangle at t >= 0;
+// then t / dd is the hit parameter and v / dd, w / dd the barycentrics (dd > 0).
+PRT_D bool tri_geom(f3 o, f3 qp, f3 a, f3 ab, f3 ac, f3 n, float & t, float & dd, float & v, float & w) {
+    dd = dot3(qp, n);
     if (dd <= 0.0f) return false;
-    f3 ap = o - a;
-    float t = dot3(ap, n);
+    const f3 ap = o - a;
+    t = dot3(ap, n);
     if (t < 0.0f) return false;
-    if (t > best_t * dd) return false;
-    f3 e = cross3(qp, ap);
-    float v = dot3(ac, e);
+    const f3 e = cross3(qp, ap);
+    v = dot3(ac, e);
     if (v < 0.0f || v > dd) return false;
-    float w = -dot3(ab, e);
+    w = -dot3(ab, e);
     if (w < 0.0f || (v + w) > dd) return false;
-    float ood = 1.0f / dd;
-    float th = t * ood;
+    return true;
+}
+
+// The reference's test as IntersectRayMesh applies it (raytracer.cpp:104, 149): true, with the hit in (out_t, out_v,
+// out_w), when IntersectRayTriangle returns true for `best_t` AND the caller keeps it (strict <).  The early reject and
+// the final comparison are different float expressions of the same inequality; for a hit within an ulp or two of best_t
+// they can disagree, which is what makes the reference's result depend on its visit order.  Used by the known-answer
+// tests and by resolve_near_ties(), never by the hot loop.
+PRT_D bool tri_test_ref(f3 o, f3 qp, f3 a, f3 ab, f3 ac, f3 n, float best_t, float & out_t, float & out_v, float & out_w) {
+    float t, dd, v, w;
+    if (!tri_geom(o, qp, a, ab, ac, n, t, dd, v, w)) return false;
+    if (t > best_t * dd) return false;
+    const float ood = 1.0f / dd;
+    const float th = t * ood;
+    if (!(th < best_t)) return false;
+    out_t = th; out_v = v * ood; out_w = w * ood;
+    return true;
+}
+
+// Relaxed early reject and the width of "near": a candidate is only rejected early when it is beyond best * (1 + 2^-17),
+// so no hit below the current best is ever lost to rounding and the traversal's result is the exact minimum of t; `near`
+// is raised for a candidate within 2^-19 (16 ulp) of the current best on either side.  The BVH cannot hide such a
+// candidate: every box is widened by pad = 2^-16 x (largest coordinate), and t < 4 x (largest coordinate).
+#define PRT_TIE_REJECT 1.00000762939453125f      /* 1 + 2^-17 */
+#define PRT_TIE_NEAR   1.0000019073486328125f    /* 1 + 2^-19 */
+
+// Hot-loop triangle test.  Returns true and the hit when the candidate is strictly closer than best_t.
+PRT_D bool tri_test(f3 o, f3 d, f3 qp, f3 a, f3 ab, f3 ac, f3 n, float best_t, float & out_t, float & out_v, float & out_w,
+                    bool & near) {
+    near = false;
+    const float dd = dot3(qp, n);
+    if (dd <= 0.0f) return false;
+    const f3 ap = o - a;
+    const float t = dot3(ap, n);
+    if (t < 0.0f) return false;
+    if (t > (best_t * dd) * PRT_TIE_REJECT) return false;
+    const f3 e = cross3(qp, ap);
+    const float v = dot3(ac, e);
+    if (v < 0.0f || v > dd) return false;
+    const float w = -dot3(ab, e);
+    if (w < 0.0f || (v + w) > dd) return false;
+    const float ood = 1.0f / dd;
+    const float th = t * ood;
+    near = th * PRT_TIE_NEAR >= best_t;             // (th <= best_t * PRT_TIE_REJECT is already known)
     if (th < best_t) {
         out_t = th;
         out_v = v * ood;
         out_w = w * ood;
         return true;
-    }
-    equal_t = (th == best_t);
-    if (equal_t) {
-        out_t = th;
-        out_v = v * ood;
-        out_w = w * ood;
     }
     return false;
 }
@@ -86,17 +122,27 @@ struct TravRay {
     float pnx, pny, pnz;              // (o +- pad) / direction for the plane the ray ENTERS through on each axis
     float pfx, pfy, pfz;              // ... and for the plane it LEAVES through (pad always widens the box)
     HitRec best;
-    unsigned int best_rank;
-    int node, sp, kind;
-    bool overflow;                    // a push was dropped: the result is not trustworthy, re-trace on the slow stack
+    int node, sp, kind;               // kind: TRACE_CLOSEST / TRACE_ANY
 };
 
-// Traversal stacks.  The fast one is this lane's column of a workgroup LDS array (entry e of lane l at
-// col[e*BLOCK + l]: a wave's push/pop of one level is one conflict-free ds_write/ds_read_b32).  Its height
-// bounds occupancy, so it is sized for what rays really use (<= 24 entries; the deepest ever observed on the 1M
-// triangle scene is 16) and not for the worst case (3 pushes per 4-wide level).  A push that does not fit is
-// DROPPED and the ray is flagged; a flagged ray is re-traced from scratch on the slow stack, a per-lane column in
-// global memory that holds the full bound.  The hot loop therefore carries one compare per push and no spill code.
+
+// Bottom-of-stack marker.  A traversal ends when it pops it.  The two rare things a traversal has to report - a candidate
+// within 2^-19 of the best hit (resolve_near_ties() must decide), a push that did not fit the stack - are recorded IN the
+// marker, i.e. in slot 0 of the lane's own stack column, so that they cost the loop no register: the marker that comes back
+// tells the story.  None of the four values is a valid leaf link (their first_tri would be 2^29 - 1; upload caps the
+// triangle count below that).
+enum { TRAV_SENTINEL = (int)0x80000000, TRAV_FLAG_NEAR = 1, TRAV_FLAG_OVERFLOW = 2, TRAV_SENTINEL_LAST = (int)0x80000003 };
+PRT_D bool trav_done(int node) { return node <= TRAV_SENTINEL_LAST; }                              // the marker was popped
+PRT_D bool trav_flagged(int node) { return node <= TRAV_SENTINEL_LAST && node != TRAV_SENTINEL; }
+
+// Traversal stacks.  LdsStack: this lane's column of a workgroup LDS array (entry e of lane l at col[e*BLOCK + l]: a wave's
+// push/pop of one level is one conflict-free ds_write/ds_read_b32).  Its height bounds occupancy, so it is sized for what
+// rays really use (<= 24 entries; the deepest ever observed on the 1M triangle scene is 16) and not for the worst case (3
+// pushes per 4-wide level).  A push that does not fit is DROPPED and the marker gets TRAV_FLAG_OVERFLOW: the result of such
+// a ray is not trustworthy (a found any-hit occluder still is) and the kernel hands the ray to a slow path that traces it
+// again on a stack that holds the whole bound.  The hot loop therefore carries one compare per push and no spill code.
+// LdsSpillStack: the same column, continued in a per-lane global column behind it; never overflows (slow paths only: the
+// extra branch per push and pop costs the fast kernels 5 %).  GlobalStack: a whole column in global memory.
 template <int BLOCK>
 struct LdsStack {
     int * col;
@@ -106,6 +152,28 @@ struct LdsStack {
         return false;
     }
     PRT_D int pop(int sp) const { return col[sp * BLOCK]; }
+    PRT_D void flag(int bit) const { col[0] |= bit; }
+};
+
+template <int BLOCK>
+struct LdsSpillStack {
+    int * col;
+    unsigned int cap;
+    int * spill;                      // WAVE-UNIFORM base of the spill area (null when cap covers the bound): entry cap + k of
+    unsigned int spill_stride;        // the lane with global thread id g at spill[k * spill_stride + g] - no per-lane pointer is kept
+    PRT_D size_t spill_index(int sp) const {
+        return (size_t)((unsigned int)sp - cap) * spill_stride + (blockIdx.x * (unsigned int)BLOCK + threadIdx.x);
+    }
+    PRT_D bool push(int sp, int v) const {
+        if ((unsigned int)sp < cap) col[sp * BLOCK] = v;
+        else spill[spill_index(sp)] = v;
+        return true;
+    }
+    PRT_D int pop(int sp) const {
+        if ((unsigned int)sp < cap) return col[sp * BLOCK];
+        return spill[spill_index(sp)];
+    }
+    PRT_D void flag(int bit) const { col[0] |= bit; }
 };
 
 struct GlobalStack {
@@ -113,9 +181,16 @@ struct GlobalStack {
     size_t stride;
     PRT_D bool push(int sp, int v) const { col[(size_t)sp * stride] = v; return true; }
     PRT_D int pop(int sp) const { return col[(size_t)sp * stride]; }
+    PRT_D void flag(int bit) const { col[0] |= bit; }
 };
 
-enum { TRAV_SENTINEL = (int)0x80000000 };   // bottom-of-stack marker; never a valid leaf link (first_tri < 2^29)
+// After a traversal ended: what its marker says.  0 for a ray that ended on an any-hit occluder (it never pops the marker,
+// and a found occluder is final whatever happened before).
+PRT_D int trav_end_flags(const TravRay & r) { return trav_done(r.node) ? (r.node & 3) : 0; }
+// the hit of a closest-hit ray has company within a few ulp: the reference's visit order decides (resolve_near_ties)
+PRT_D bool trav_wants_resolve(const TravRay & r) { return r.kind == TRACE_CLOSEST && (trav_end_flags(r) & TRAV_FLAG_NEAR) != 0 && r.best.tri >= 0; }
+// fast kernels: the ray cannot be finished here (near tie, or a dropped push): it goes to the slow path
+PRT_D bool trav_needs_slow_path(const TravRay & r) { return (trav_end_flags(r) & TRAV_FLAG_OVERFLOW) != 0 || trav_wants_resolve(r); }
 
 template <class STK>
 PRT_D void trav_init(TravRay & r, f3 o, f3 d, int kind, float pad, const STK & stk) {
@@ -134,11 +209,9 @@ PRT_D void trav_init(TravRay & r, f3 o, f3 d, int kind, float pad, const STK & s
     r.best.t = 3.402823466e+38f;
     r.best.v = r.best.w = 0.0f;
     r.best.tri = -1;
-    r.best_rank = 0xFFFFFFFFu;
     r.kind = kind;
     stk.push(0, TRAV_SENTINEL);
     r.sp = 1;
-    r.overflow = false;
     r.node = 0;
 }
 
@@ -195,9 +268,9 @@ PRT_D void trav_node_step(const DevScene & sc, TravRay & r, const STK & stk, Tra
     cswap(key[1], key[3], link[1], link[3]);
     cswap(key[1], key[2], link[1], link[2]);
     if (key[0] < inf) {
-        if (key[3] < inf) { if (stk.push(r.sp, link[3])) r.sp++; else r.overflow = true; }
-        if (key[2] < inf) { if (stk.push(r.sp, link[2])) r.sp++; else r.overflow = true; }
-        if (key[1] < inf) { if (stk.push(r.sp, link[1])) r.sp++; else r.overflow = true; }
+        if (key[3] < inf) { if (stk.push(r.sp, link[3])) r.sp++; else stk.flag(TRAV_FLAG_OVERFLOW); }
+        if (key[2] < inf) { if (stk.push(r.sp, link[2])) r.sp++; else stk.flag(TRAV_FLAG_OVERFLOW); }
+        if (key[1] < inf) { if (stk.push(r.sp, link[1])) r.sp++; else stk.flag(TRAV_FLAG_OVERFLOW); }
         r.node = link[0];
     } else {
         if (COUNT && r.best.tri >= 0) st.culled++;
@@ -219,24 +292,16 @@ PRT_D bool trav_leaf(const DevScene & sc, TravRay & r, const STK & stk, TraceSta
         const float4 r0 = tp[0], r1 = tp[1], r2 = tp[2];
         if (COUNT) { st.tris++; if (first_active_lane()) st.wtris++; }
         float t, v, w;
-        bool eq;
-        bool hit = tri_test(r.o, r.d, qp, mk3(r0.x, r0.y, r0.z), mk3(r0.w, r1.x, r1.y), mk3(r1.z, r1.w, r2.x),
-                            mk3(r2.y, r2.z, r2.w), r.best.t, t, v, w, eq);
-        if (eq && r.best.tri >= 0 && (int)ti != r.best.tri) {
-            // bit-equal t: the reference keeps whichever it visited first
-            unsigned int rk = sc.tri_rank[ti];
-            if (r.best_rank == 0xFFFFFFFFu) r.best_rank = sc.tri_rank[r.best.tri];
-            hit = rk < r.best_rank;
-            if (hit) r.best_rank = rk;
-        } else if (hit) {
-            r.best_rank = 0xFFFFFFFFu;
-        }
+        bool near;
+        const bool hit = tri_test(r.o, r.d, qp, mk3(r0.x, r0.y, r0.z), mk3(r0.w, r1.x, r1.y), mk3(r1.z, r1.w, r2.x),
+                                  mk3(r2.y, r2.z, r2.w), r.best.t, t, v, w, near);
+        if (near) stk.flag(TRAV_FLAG_NEAR);
         if (hit) {
             r.best.t = t;
             r.best.v = v;
             r.best.w = w;
             r.best.tri = (int)ti;
-            if (r.kind == TRACE_ANY) return true;
+            if (r.kind & TRACE_ANY) return true;
         }
     }
     r.sp--;
@@ -244,30 +309,92 @@ PRT_D bool trav_leaf(const DevScene & sc, TravRay & r, const STK & stk, TraceSta
     return false;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Near ties: the reference's answer for a ray whose closest hit has company within a few ulp.
+//
+// The reference keeps `best` (FLT_MAX at first) and offers it every triangle in ITS visit order - sphere tree depth first,
+// c1 before c0, groups in leaf order, triangles in index order (raytracer.cpp:136, 208-209); a triangle replaces best iff
+// !(t > best * d) and t / d < best (:104, :149, :220).  Far from best both comparisons say the same; within an ulp or two
+// they need not, so which of several near-coincident hits survives depends on the order.  What cannot depend on it:
+// let N be the candidates with t <= bound, where no candidate lies in the "moat" (bound, bound * (1 + 2^-20)].  Then
+//   - every member of N beats any best that is not in N on both comparisons with room to spare, so the first member the
+//     reference meets is accepted whatever came before it;
+//   - from then on best <= bound, and nothing outside N can pass `t / d < best`.
+// Hence the reference's final hit is its own filter run over N alone, in its visit order, from FLT_MAX.  That is what this
+// function does: N's members are fetched one by one in visit order (tri_rank) - each fetch a traversal bounded by `bound`,
+// no storage needed - and put through tri_test_ref.  If the moat turns out to be occupied the bound is widened and the
+// replay starts over.  (Not modelled: the reference also skips a GROUP whose bounding sphere it enters later than best,
+// raytracer.cpp:176-179, with the sphere's own rounding; a hit lies inside its group's sphere, so this only differs for a
+// near-tied hit on the sphere's very surface.)
+template <class STK, bool COUNT>
+PRT_D HitRec resolve_near_ties(const DevScene & sc, f3 o, f3 d, float pad, float min_t, const STK & stk, TraceStats & st) {
+    TravRay r;
+    HitRec result;
+    result.t = 3.402823466e+38f; result.v = result.w = 0.0f; result.tri = -1;
+    const f3 qp = o - (o + d);
+    float bound = min_t * PRT_TIE_NEAR;
+    for (int widen = 0; widen < 8; ++widen) {
+        const float moat = bound * 1.00000095367431640625f;          // 1 + 2^-20
+        bool occupied = false;
+        float best = 3.402823466e+38f;                              // the reference's best_hit.t, replayed
+        result.tri = -1;
+        unsigned int next_rank = 0;                                 // candidates of rank >= next_rank are still to come
+        for (;;) {
+            // the member of N with the smallest rank >= next_rank
+            unsigned int c_rank = 0xFFFFFFFFu;
+            int c_tri = -1;
+            trav_init(r, o, d, TRACE_CLOSEST, pad, stk);
+            r.best.t = moat;                                        // the boxes are culled against the moat's far side
+            for (;;) {
+                while (r.node >= 0) trav_node_step<STK, COUNT>(sc, r, stk, st);
+                if (trav_done(r.node)) break;
+                const unsigned int leaf = (unsigned int)~r.node;
+                const unsigned int first = leaf >> 2, count = (leaf & 3u) + 1u;
+                for (unsigned int i = 0; i < count; ++i) {
+                    const unsigned int ti = first + i;
+                    const float4 * tp = sc.tris + 3 * (size_t)ti;
+                    const float4 r0 = tp[0], r1 = tp[1], r2 = tp[2];
+                    float t, dd, v, w;
+                    if (!tri_geom(o, qp, mk3(r0.x, r0.y, r0.z), mk3(r0.w, r1.x, r1.y), mk3(r1.z, r1.w, r2.x), mk3(r2.y, r2.z, r2.w), t, dd, v, w)) continue;
+                    const float th = t * (1.0f / dd);
+                    if (th > bound) { if (th <= moat) occupied = true; continue; }
+                    const unsigned int rk = sc.tri_rank[ti];
+                    if (rk >= next_rank && rk < c_rank) { c_rank = rk; c_tri = (int)ti; }
+                }
+                r.sp--;
+                r.node = stk.pop(r.sp);
+            }
+            if (c_tri < 0 || occupied) break;
+            const float4 * tp = sc.tris + 3 * (size_t)c_tri;
+            const float4 r0 = tp[0], r1 = tp[1], r2 = tp[2];
+            float t, v, w;
+            if (tri_test_ref(o, qp, mk3(r0.x, r0.y, r0.z), mk3(r0.w, r1.x, r1.y), mk3(r1.z, r1.w, r2.x), mk3(r2.y, r2.z, r2.w), best, t, v, w)) {
+                best = t;
+                result.t = t; result.v = v; result.w = w; result.tri = c_tri;
+            }
+            next_rank = c_rank + 1u;
+        }
+        if (!occupied) break;
+        bound = moat * PRT_TIE_NEAR;                                // take the moat's occupants in and try again
+    }
+    return result;
+}
+
 // Whole-ray traversal, "while-while" (Aila & Laine): every lane first walks internal nodes until it holds
 // a leaf (or runs out of work), and only then does the wave run the triangle code.  With 64 lanes a fused
-// node-or-leaf loop would execute the (4x longer) leaf body in almost every iteration.
+// node-or-leaf loop would execute the (4x longer) leaf body in almost every iteration.  Near ties are decided on the spot:
+// this is the form for the slow paths and the experimental kernels, on a stack that cannot overflow.
 template <class STK, bool COUNT>
-PRT_D HitRec trace_ray_on(const DevScene & sc, f3 o, f3 d, int kind, float pad, const STK & stk, TraceStats & st, bool & overflow) {
+PRT_D HitRec trace_ray(const DevScene & sc, f3 o, f3 d, int kind, float pad, const STK & stk, TraceStats & st) {
     TravRay r;
     trav_init(r, o, d, kind, pad, stk);
     for (;;) {
         while (r.node >= 0) trav_node_step<STK, COUNT>(sc, r, stk, st);
-        if (r.node == TRAV_SENTINEL) break;
-        if (trav_leaf<STK, COUNT>(sc, r, stk, st)) break;
+        if (trav_done(r.node)) break;
+        if (trav_leaf<STK, COUNT>(sc, r, stk, st)) return r.best;           // any-hit ray: found its occluder
     }
-    overflow = r.overflow;
+    if (kind == TRACE_CLOSEST && (r.node & TRAV_FLAG_NEAR) && r.best.tri >= 0) return resolve_near_ties<STK, COUNT>(sc, o, d, pad, r.best.t, stk, st);
     return r.best;
-}
-
-// Fast stack first; the (never observed) overflow case re-traces on the slow stack.
-template <int BLOCK, bool COUNT>
-PRT_D HitRec trace_ray(const DevScene & sc, f3 o, f3 d, int kind, float pad, const LdsStack<BLOCK> & fast, const GlobalStack & slow,
-                       TraceStats & st) {
-    bool overflow;
-    HitRec h = trace_ray_on<LdsStack<BLOCK>, COUNT>(sc, o, d, kind, pad, fast, st, overflow);
-    if (overflow) h = trace_ray_on<GlobalStack, COUNT>(sc, o, d, kind, pad, slow, st, overflow);
-    return h;
 }
 
 }  // namespace prt

@@ -34,9 +34,11 @@ __global__ void k_debug_kat(int kind, const void * in, void * out, unsigned int 
         const f3 o = mk3(p[0], p[1], p[2]), d = mk3(p[3], p[4], p[5]);
         const f3 a = mk3(p[6], p[7], p[8]), ab = mk3(p[9], p[10], p[11]), ac = mk3(p[12], p[13], p[14]), nn = mk3(p[15], p[16], p[17]);
         const f3 qp = o - (o + d);
-        float t, v, w;
-        bool eq;
-        const bool hit = tri_test(o, d, qp, a, ab, ac, nn, p[18], t, v, w, eq);
+        // IntersectRayTriangle itself (raytracer.cpp:82-125): the geometric tests and the early reject against out_hit->t;
+        // whether the caller keeps the hit (strict <) is IntersectRayMesh's business
+        float tn, dd, vn, wn, t = 0.0f, v = 0.0f, w = 0.0f;
+        bool hit = tri_geom(o, qp, a, ab, ac, nn, tn, dd, vn, wn) && !(tn > p[18] * dd);
+        if (hit) { const float ood = 1.0f / dd; t = tn * ood; v = vn * ood; w = wn * ood; }
         float * q = (float *)out + (size_t)i * 11;
         for (int k = 0; k < 11; ++k) q[k] = 0.0f;
         if (hit) {

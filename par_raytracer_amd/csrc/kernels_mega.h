@@ -37,12 +37,11 @@ __global__ __launch_bounds__(BLOCK) void k_render_mega(DevScene sc, DevCamera ca
     extern __shared__ int s_stack[];
     const unsigned int sid = blockIdx.x * BLOCK + threadIdx.x;
     if (sid >= n_samples) return;
-    LdsStack<BLOCK> stack;
+    LdsSpillStack<BLOCK> stack;
     stack.col = s_stack + threadIdx.x;
     stack.cap = P.stack_lds_entries;
-    GlobalStack slow;
-    slow.col = P.stack_spill + sid;
-    slow.stride = P.stack_spill_stride;
+    stack.spill = P.stack_spill;
+    stack.spill_stride = P.stack_spill_stride;
     const unsigned int pixel = pixel_of_local(P, sid / P.spp);
     const unsigned int samp = sid % P.spp;
     u64 * ring = RING ? ring_ws + sid : nullptr;
@@ -62,21 +61,27 @@ __global__ __launch_bounds__(BLOCK) void k_render_mega(DevScene sc, DevCamera ca
     while (sample_advance<RING>(sc, P, S, cur, store, hit, req, shaded, ring, ring_stride)) {
         rays++;                                                     // debug->ray_count++  raytracer.cpp:161
         const f3 ob = req.o + req.d * P.ray_bias;                   // raytracer.cpp:163
-        hit = trace_ray<BLOCK, COUNT>(sc, ob, req.d, req.kind, P.box_pad, stack, slow, st);
+        hit = trace_ray<LdsSpillStack<BLOCK>, COUNT>(sc, ob, req.d, req.kind, P.box_pad, stack, st);
     }
     sample_rgb[sid] = make_float4(S.ret.x, S.ret.y, S.ret.z, 0.0f);
     flush_counters(ctr, rays, shaded, st, COUNT);
 }
 
 // One lane per pixel: sum the spp sample colours in order, divide, w = 1 (main.cpp:235-263).
-__global__ void k_resolve(const float4 * sample_rgb, float4 * out_rgba, unsigned int n_pixels, unsigned int spp) {
+// FIXED: the samples are the fixed-point accumulators of the wavefront / pool pipelines (dev_scene.h Accum), else float4.
+template <bool FIXED>
+PRT_D f3 load_sample_rgb(const void * sample_rgb, size_t i) {
+    if (FIXED) return accum_read(reinterpret_cast<const Accum *>(sample_rgb) + i);
+    const float4 c = reinterpret_cast<const float4 *>(sample_rgb)[i];
+    return mk3(c.x, c.y, c.z);
+}
+
+template <bool FIXED>
+__global__ void k_resolve(const void * sample_rgb, float4 * out_rgba, unsigned int n_pixels, unsigned int spp) {
     const unsigned int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n_pixels) return;
     f3 color = mk3(0.0f, 0.0f, 0.0f);
-    for (unsigned int s = 0; s < spp; ++s) {
-        const float4 c = sample_rgb[(size_t)p * spp + s];
-        color = color + mk3(c.x, c.y, c.z);
-    }
+    for (unsigned int s = 0; s < spp; ++s) color = color + load_sample_rgb<FIXED>(sample_rgb, (size_t)p * spp + s);
     color = color / (float)spp;
     out_rgba[p] = make_float4(color.x, color.y, color.z, 1.0f);
 }
@@ -85,12 +90,12 @@ __global__ void k_resolve(const float4 * sample_rgb, float4 * out_rgba, unsigned
 // every group of SPP lanes then adds its neighbours' values one after the other - the reference's summation order - with
 // wave shuffles.  (k_resolve's per-lane runs of spp x 16 B make every load instruction touch 64 different cache lines:
 // 0.28 ms per 1080p x 8 spp frame; this one: 0.10 ms.)
-template <int SPP>
-__global__ __launch_bounds__(256) void k_resolve_pow2(const float4 * sample_rgb, float4 * out_rgba, unsigned int n_pixels) {
+template <int SPP, bool FIXED>
+__global__ __launch_bounds__(256) void k_resolve_pow2(const void * sample_rgb, float4 * out_rgba, unsigned int n_pixels) {
     const unsigned long long sid = (unsigned long long)blockIdx.x * 256ull + threadIdx.x;
     const unsigned long long n_samples = (unsigned long long)n_pixels * SPP;
-    float4 c = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    if (sid < n_samples) c = sample_rgb[sid];
+    f3 c = mk3(0.0f, 0.0f, 0.0f);
+    if (sid < n_samples) c = load_sample_rgb<FIXED>(sample_rgb, (size_t)sid);
     const int lane = (int)(threadIdx.x & 63u);
     const int leader = lane & ~(SPP - 1);
     f3 color = mk3(0.0f, 0.0f, 0.0f);

@@ -36,12 +36,11 @@ __global__ __launch_bounds__(BLOCK, 4) void k_render_persistent(DevScene sc, Dev
     extern __shared__ int s_stack[];
     const unsigned int slot = blockIdx.x * BLOCK + threadIdx.x;          // persistent lane id
     const unsigned int lane = lane_id();
-    LdsStack<BLOCK> stack;
+    LdsSpillStack<BLOCK> stack;
     stack.col = s_stack + threadIdx.x;
     stack.cap = P.stack_lds_entries;
-    GlobalStack slow;
-    slow.col = P.stack_spill + slot;
-    slow.stride = P.stack_spill_stride;
+    stack.spill = P.stack_spill;
+    stack.spill_stride = P.stack_spill_stride;
     u64 * ring = RING ? ring_ws + slot : nullptr;
     const size_t ring_stride = (size_t)gridDim.x * BLOCK;
 
@@ -118,16 +117,13 @@ __global__ __launch_bounds__(BLOCK, 4) void k_render_persistent(DevScene sc, Dev
             const int walkers = __popcll(__ballot(r.node >= 0));
             const int nmin = node_min < (walkers >> 1) ? node_min : (walkers >> 1);
             while (r.node >= 0) {
-                trav_node_step<LdsStack<BLOCK>, COUNT>(sc, r, stack, st);
+                trav_node_step<LdsSpillStack<BLOCK>, COUNT>(sc, r, stack, st);
                 if (__popcll(__ballot(r.node >= 0)) < nmin) break;
             }
-            bool fin = r.node == TRAV_SENTINEL;
-            if (!fin && r.node < 0) fin = trav_leaf<LdsStack<BLOCK>, COUNT>(sc, r, stack, st);
+            bool fin = trav_done(r.node);
+            if (!fin && r.node < 0) fin = trav_leaf<LdsSpillStack<BLOCK>, COUNT>(sc, r, stack, st);
             if (fin) {
-                if (r.overflow) {
-                    bool again;
-                    r.best = trace_ray_on<GlobalStack, COUNT>(sc, r.o, r.d, r.kind, P.box_pad, slow, st, again);
-                }
+                if (trav_wants_resolve(r)) r.best = resolve_near_ties<LdsSpillStack<BLOCK>, COUNT>(sc, r.o, r.d, P.box_pad, r.best.t, stack, st);
                 hit = r.best;
                 state = LANE_ADVANCE;
                 break;

@@ -32,9 +32,21 @@ struct PoolBuffers {
     float4 * cq;                 // [waves][2][3][cap]   closest-hit lists, double buffered: (o, sample) (d, level | pending << 8) (T, -)
     float4 * hits;               // [waves][cap]         (t, v, w, tri) by list position
     float4 * sq;                 // [waves][3][scap]     shadow list: (o, sample) (radiance, w) (d, -), see WaveBuffers::sq_*
-    unsigned int * head;         // global sample counter
+    unsigned int * head;         // global sample counter (adopting launch: counter into the park list)
     unsigned int cap, scap;      // slots per wave; multiples of 64
     unsigned int topup_min;      // top up when at least this many slots are free
+    // Rays the fast kernel (EXACT = false) cannot finish - the hit has company within a few ulp and the reference's visit order
+    // decides (dev_trace.h resolve_near_ties), or a push did not fit the LDS stack column - are PARKED, list entry and all,
+    // and dropped from the pool.  After the fast kernel: k_pool_parked_shadows traces the parked shadow rays exactly and adds
+    // their radiance; then a second launch of k_pool, the EXACT variant (spill-capable stack, near ties decided in its loop),
+    // adopts the parked closest-hit rays instead of fresh samples and runs their samples to the end.  The slow code thus never
+    // sits in the fast kernel.  Normally nothing is parked and both follow-up launches find empty lists.
+    float4 * park;               // [3][park_cap]  kind 0: (o, sample) (d, level | pending << 8) (T, kind) of a closest-hit ray
+                                 //                kind 2 (ADAPT): (-, pixel) (-) (-, kind): a pixel whose finalise step was deferred
+    float4 * spark;              // [3][spark_cap] (o, sample) (radiance, w as in sq_c) (d, -) of a parked shadow ray
+    unsigned int * park_count;   // [0] closest / finalise entries parked so far, [1] shadow entries
+    unsigned int park_cap, spark_cap;
+    unsigned int adopt;          // EXACT kernels: 1 = top up from the park list, not from the sample counter
     // adaptive mode (k_pool<ADAPT>): the unit in the pool is a PIXEL that runs its samples one after the other
     unsigned int * fin;          // [waves][cap]         pixels whose current sample has no ray left; finalised after the next trace phase
     float4 * scratch;            // [max_spp][n_pixels]  every sample's colour (RenderPixel's scratch_buffer, main.cpp:232)
@@ -79,6 +91,10 @@ struct PoolEmit {
     }
 };
 
+enum { POOL_PARKED_MARK = 0x7FFFFFFE };        // hits[].w of a closest-hit ray that was parked: not shaded here (never a triangle index)
+enum { POOL_PARK_CLOSEST = 0, POOL_PARK_FINALISE = 2 };
+enum { POOL_PARKED_SHADOW_BLOCKS = 64 };         // k_pool_parked_shadows' fixed grid
+
 PRT_D void pool_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }
 
 // Everything the kernel is told, in device memory.  Passed by value these ~130 dwords are loaded into SGPRs at kernel
@@ -120,8 +136,18 @@ PRT_D PoolArgs pool_args(const PoolArgs * args) {
     A.B.accum = as_global(A.B.accum); A.B.rng = as_global(A.B.rng); A.B.rng_aux = as_global(A.B.rng_aux); A.B.ring = as_global(A.B.ring);
     A.B.frames = as_global(A.B.frames);
     A.Q.cq = as_global(A.Q.cq); A.Q.hits = as_global(A.Q.hits); A.Q.sq = as_global(A.Q.sq); A.Q.head = as_global(A.Q.head);
+    A.Q.park = as_global(A.Q.park); A.Q.spark = as_global(A.Q.spark); A.Q.park_count = as_global(A.Q.park_count);
     A.Q.fin = as_global(A.Q.fin); A.Q.scratch = as_global(A.Q.scratch); A.Q.jobsum = as_global(A.Q.jobsum); A.Q.final_rgb = as_global(A.Q.final_rgb);
     return A;
+}
+
+// The fast kernel's stack drops what does not fit its LDS column (and parks the ray); the EXACT kernel's continues in memory.
+template <int BLOCK, bool EXACT> struct PoolStack { typedef LdsStack<BLOCK> type; };
+template <int BLOCK> struct PoolStack<BLOCK, true> { typedef LdsSpillStack<BLOCK> type; };
+template <int BLOCK> PRT_D void pool_stack_spill(LdsStack<BLOCK> &, PoolArgsPtr) {}
+template <int BLOCK> PRT_D void pool_stack_spill(LdsSpillStack<BLOCK> & stack, PoolArgsPtr args) {
+    stack.spill = as_global(args->P.stack_spill);
+    stack.spill_stride = args->P.stack_spill_stride;
 }
 
 // Puts the arguments where k_pool reads them.  A kernel rather than a hipMemcpyAsync: kernel arguments are captured at
@@ -131,7 +157,10 @@ __global__ void k_pool_store_args(PoolArgs a, PoolArgs * dst) {
 }
 
 // grid = resident blocks; dynamic LDS = max(stack_entries, WFRAME_LDS_DWORDS) * BLOCK * 4 (traversal stack columns).
-template <int BLOCK, int WAVES, bool LDSTAB, bool RING, bool COUNT, bool TEX, bool ADAPT, bool RINGMEM>
+// EXACT: the slow variant - stack columns that continue in global memory, near ties decided inside the traversal loop
+// (resolve_near_ties).  It runs as the adopting second launch of a render (PoolBuffers::park); the fast variant parks what
+// it cannot finish.
+template <int BLOCK, int WAVES, bool LDSTAB, bool RING, bool COUNT, bool TEX, bool ADAPT, bool RINGMEM, bool EXACT>
 __global__ __launch_bounds__(BLOCK, WAVES) void k_pool(const PoolArgs * args, DevCounters * ctr) {
     extern __shared__ int s_stack[];
     constexpr int LDS_MATS = 32, LDS_LIGHTS = 4;
@@ -160,9 +189,11 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_pool(const PoolArgs * args, De
     const unsigned int slot_id = blockIdx.x * BLOCK + threadIdx.x;
     const unsigned int lane = lane_id();
     const unsigned int wave = (unsigned int)__builtin_amdgcn_readfirstlane((int)(slot_id >> 6));      // scalar: the list pointers stay in SGPRs
-    LdsStack<BLOCK> stack;
+    typedef typename PoolStack<BLOCK, EXACT>::type Stack;
+    Stack stack;
     stack.col = s_stack + threadIdx.x;
     stack.cap = ((PoolArgsPtr)args)->P.stack_lds_entries;
+    pool_stack_spill(stack, (PoolArgsPtr)args);
 
     unsigned int n_f = 0;                      // wave-uniform (ADAPT): pixels waiting to be finalised
     int cur = 0;
@@ -197,7 +228,56 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_pool(const PoolArgs * args, De
           const WaveBuffers & B = A.B;
           const PoolBuffers & Q = A.Q;
           PRT_POOL_LISTS(A);
-          if (n_c + n_f + Q.topup_min <= cap) {
+          if (EXACT && Q.adopt) {
+            // second launch: the work is the park list.  Only into an EMPTY pool, so that an adopted ray never meets rays of
+            // its own sample's earlier life.
+            if (n_c + n_s + n_f == 0u) {
+                const unsigned int n_parked = *Q.park_count < Q.park_cap ? *Q.park_count : Q.park_cap;
+                // spread thinly: every parked sample still has its remaining bounces to go, one round after the other, and this
+                // launch is the tail of the frame - a few rays per wave on many waves, not all of them on the first wave
+                const unsigned int n_waves = gridDim.x * (BLOCK / 64);
+                unsigned int chunk = (n_parked + n_waves - 1u) / n_waves;
+                chunk = chunk < 1u ? 1u : chunk > cap ? cap : chunk;
+                unsigned int base = 0;
+                if (lane == 0) base = atomicAdd(Q.head, chunk);
+                base = (unsigned int)__builtin_amdgcn_readfirstlane((int)base);
+                if (base >= n_parked) {
+                    fetch_done = true;
+                } else {
+                    unsigned int cnt = n_parked - base;
+                    if (cnt <= chunk) fetch_done = true; else cnt = chunk;
+                    // closest-hit rays go to the list; a deferred finalise step goes to the finalise list (its pixel's parked
+                    // shadow rays have been traced by k_pool_parked_shadows in the meantime)
+                    unsigned int * const fin_list = ADAPT ? Q.fin + (size_t)wave * cap : nullptr;
+                    unsigned int m_c = 0, m_f = 0;
+                    for (unsigned int k0 = 0; k0 < cnt; k0 += 64u) {
+                        const unsigned int k = k0 + lane;
+                        const bool have = k < cnt;
+                        float4 e0 = make_float4(0, 0, 0, 0), e1 = e0, e2 = e0;
+                        if (have) { e0 = Q.park[base + k]; e1 = Q.park[(size_t)Q.park_cap + base + k]; e2 = Q.park[2u * (size_t)Q.park_cap + base + k]; }
+                        const bool is_fin = ADAPT && have && as_i(e2.w) == POOL_PARK_FINALISE;
+                        const bool is_ray = have && !is_fin;
+                        const unsigned long long mr = __ballot(is_ray), mf = __ballot(is_fin);
+                        const unsigned int pr = __builtin_amdgcn_mbcnt_hi((unsigned int)(mr >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)mr, 0u));
+                        const unsigned int pf = __builtin_amdgcn_mbcnt_hi((unsigned int)(mf >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)mf, 0u));
+                        if (is_ray) { co[m_c + pr] = e0; cd[m_c + pr] = e1; ct[m_c + pr] = make_float4(e2.x, e2.y, e2.z, 0.0f); }
+                        if (is_fin) {
+                            const unsigned int j = (unsigned int)as_i(e0.w);
+                            fin_list[m_f + pf] = j;
+                            float4 js = Q.jobsum[j];
+                            js.w = as_f(as_i(js.w) & 0x7FFFFFFF);                  // the deferral mark
+                            Q.jobsum[j] = js;
+                        }
+                        m_c += (unsigned int)__popcll(mr);
+                        m_f += (unsigned int)__popcll(mf);
+                    }
+                    cnt = m_c;
+                    n_f = m_f;
+                    n_c = cnt;
+                    rays -= cnt;                  // these rays were counted when the first launch traced them (raytracer.cpp:161: one TraceRay each)
+                }
+            }
+          } else if (n_c + n_f + Q.topup_min <= cap) {
             const unsigned int want = cap - n_c - n_f;
             unsigned int base = 0;
             if (lane == 0) base = atomicAdd(Q.head, want);
@@ -223,7 +303,7 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_pool(const PoolArgs * args, De
                     }
                     B.rng[sid] = make_ulonglong2(S.rng.chain, S.rng.prev);
                     if (RING) B.rng_aux[sid] = make_ulonglong2(S.rng.seed0, (u64)S.rng.k);
-                    B.accum[sid] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                    accum_zero(B.accum + sid);
                     co[n_c + k] = make_float4(fr.ray_o.x, fr.ray_o.y, fr.ray_o.z, as_f((int)sid));
                     cd[n_c + k] = make_float4(fr.ray_d.x, fr.ray_d.y, fr.ray_d.z, as_f(0));
                     ct[n_c + k] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
@@ -247,14 +327,11 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_pool(const PoolArgs * args, De
             const DevScene & sc = A.sc;
             const DevParams & P = A.P;
             const WaveBuffers & B = A.B;
-            const int keep_min = A.keep_min, node_min = A.node_min, multi_light = A.multi_light;
+            const int keep_min = A.keep_min, node_min = A.node_min;
             PRT_POOL_LISTS(A);
             const DevLight * lights = sc.light_count <= (unsigned int)LDS_LIGHTS ? s_lights : sc.lights;
-            GlobalStack slow;
-            slow.col = P.stack_spill + slot_id;
-            slow.stride = P.stack_spill_stride;
             TravRay r;
-            r.node = TRAV_SENTINEL; r.sp = 0; r.kind = 0; r.overflow = false;
+            r.node = TRAV_SENTINEL; r.sp = 0; r.kind = 0;
             int ray = -1;
             float4 payload = make_float4(0, 0, 0, 0);
             int sample = 0;
@@ -304,33 +381,46 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_pool(const PoolArgs * args, De
                     const int walkers = __popcll(__ballot(r.node >= 0));
                     const int nmin = node_min < (walkers >> 1) ? node_min : (walkers >> 1);
                     while (r.node >= 0) {
-                        trav_node_step<LdsStack<BLOCK>, COUNT>(sc, r, stack, st);
+                        trav_node_step<Stack, COUNT>(sc, r, stack, st);
                         if (__popcll(__ballot(r.node >= 0)) < nmin) break;
                     }
-                    bool fin = r.node == TRAV_SENTINEL;
-                    if (!fin && r.node < 0) fin = trav_leaf<LdsStack<BLOCK>, COUNT>(sc, r, stack, st);
+                    bool fin = trav_done(r.node);
+                    if (!fin && r.node < 0) fin = trav_leaf<Stack, COUNT>(sc, r, stack, st);
                     if (fin) {
-                        if (r.overflow) {
-                            // a push did not fit the LDS column (never observed on real scenes): redo the ray on this
-                            // lane's full-height global column
-                            bool again;
-                            r.best = trace_ray_on<GlobalStack, COUNT>(sc, r.o, r.d, r.kind, P.box_pad, slow, st, again);
-                        }
-                        if ((unsigned int)ray < n_c) {
+                        if (EXACT && trav_wants_resolve(r)) r.best = resolve_near_ties<Stack, COUNT>(sc, r.o, r.d, P.box_pad, r.best.t, stack, st);
+                        if (!EXACT && trav_needs_slow_path(r)) {
+                            // rare: the hit has company within a few ulp and the reference's visit order decides, or a push did
+                            // not fit the LDS column (dev_trace.h).  Not here: the ray is parked for the launches that follow.
+                            if ((unsigned int)ray < n_c) {
+                                const unsigned int slot = atomicAdd(A.Q.park_count, 1u);
+                                if (slot < A.Q.park_cap) {
+                                    const float4 t4 = ct[ray];
+                                    A.Q.park[slot] = co[ray];
+                                    A.Q.park[(size_t)A.Q.park_cap + slot] = cd[ray];
+                                    A.Q.park[2u * (size_t)A.Q.park_cap + slot] = make_float4(t4.x, t4.y, t4.z, as_f(POOL_PARK_CLOSEST));
+                                }
+                                hits[ray] = make_float4(0.0f, 0.0f, 0.0f, as_f(POOL_PARKED_MARK));     // its sample leaves this pool
+                            } else {
+                                const unsigned int slot = atomicAdd(A.Q.park_count + 1, 1u);
+                                if (slot < A.Q.spark_cap) {
+                                    A.Q.spark[slot] = sq_o[(unsigned int)ray - n_c];
+                                    A.Q.spark[(size_t)A.Q.spark_cap + slot] = payload;
+                                    A.Q.spark[2u * (size_t)A.Q.spark_cap + slot] = make_float4(r.d.x, r.d.y, r.d.z, 0.0f);
+                                }
+                                if (ADAPT) {
+                                    // the pixel's sample must not be finalised before this ray's radiance has landed: mark the
+                                    // pixel, the finalise step parks itself when it sees the mark
+                                    float * const w = &A.Q.jobsum[sample].w;
+                                    *w = as_f(as_i(*w) | (int)0x80000000);
+                                }
+                            }
+                        } else if ((unsigned int)ray < n_c) {
                             hits[ray] = make_float4(r.best.t, r.best.v, r.best.w, as_f(r.best.tri));
                         } else {
                             // shadow ray: add the precomputed radiance when unoccluded (k_trace has the commentary)
                             const bool lit = r.best.tri < 0 || (payload.w >= 0.0f && r.best.t * r.best.t <= payload.w);
                             if (lit) {
-                                if (multi_light) {
-                                    atomicAdd(&B.accum[sample].x, payload.x);
-                                    atomicAdd(&B.accum[sample].y, payload.y);
-                                    atomicAdd(&B.accum[sample].z, payload.z);
-                                } else {
-                                    float4 a = B.accum[sample];
-                                    a.x += payload.x; a.y += payload.y; a.z += payload.z;
-                                    B.accum[sample] = a;
-                                }
+                                accum_add(B.accum + sample, mk3(payload.x, payload.y, payload.z));
                             }
                         }
                         ray = -1;
@@ -378,10 +468,26 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_pool(const PoolArgs * args, De
                     f3 ray_o = mk3(0, 0, 0), ray_d = mk3(0, 0, 1);
                     if (live) {
                         j = fin[i];
-                        const float4 a = B.accum[j], st = Q.jobsum[j];
+                    }
+                    bool defer = false;
+                    if (live && !EXACT) {
+                        // a shadow ray of this pixel is parked (see the trace phase): the step waits for the EXACT launch
+                        defer = as_i(Q.jobsum[j].w) < 0;
+                        if (defer) {
+                            const unsigned int slot = atomicAdd(Q.park_count, 1u);
+                            if (slot < Q.park_cap) {
+                                Q.park[slot] = make_float4(0.0f, 0.0f, 0.0f, as_f((int)j));
+                                Q.park[(size_t)Q.park_cap + slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                                Q.park[2u * (size_t)Q.park_cap + slot] = make_float4(0.0f, 0.0f, 0.0f, as_f(POOL_PARK_FINALISE));
+                            }
+                        }
+                    }
+                    if (live && !defer) {
+                        const f3 a = accum_read(B.accum + j);
+                        const float4 st = Q.jobsum[j];
                         unsigned int samp = (unsigned int)as_i(st.w);              // index of the sample that just ended
                         const f3 sum_prev = mk3(st.x, st.y, st.z);
-                        const f3 c = mk3(a.x, a.y, a.z);
+                        const f3 c = a;
                         Q.scratch[(size_t)samp * n_px + j] = make_float4(c.x, c.y, c.z, 0.0f);
                         const f3 sum = sum_prev + c;                                // color += scratch_buffer[samp]
                         bool stop = false;
@@ -405,7 +511,7 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_pool(const PoolArgs * args, De
                             Q.final_rgb[j] = make_float4(out.x, out.y, out.z, 1.0f);
                         } else {
                             Q.jobsum[j] = make_float4(sum.x, sum.y, sum.z, as_f((int)samp));
-                            B.accum[j] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                            accum_zero(B.accum + j);
                             Rng rng;
                             const ulonglong2 rs = B.rng[j], ra = B.rng_aux[j];
                             rng.chain = rs.x; rng.prev = rs.y; rng.seed0 = ra.x; rng.k = (u32)ra.y;
@@ -448,9 +554,10 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_pool(const PoolArgs * args, De
                     T = mk3(rt.x, rt.y, rt.z);
                     hit.t = h.x; hit.v = h.y; hit.w = h.z; hit.tri = as_i(h.w);
                 }
+                const bool parked = !EXACT && live && hit.tri == POOL_PARKED_MARK;      // continues in the EXACT launch
                 unsigned int shaded = 0;
                 // the frame under construction lives in this lane's (idle) traversal stack column
-                shade_entry_lds<RING, TEX, BLOCK, RINGMEM>(sc, P, B, tb, live, s, level, pending, ray_o, ray_d, T, hit, emit, shaded, stack.col);
+                shade_entry_lds<RING, TEX, BLOCK, RINGMEM>(sc, P, B, tb, live && !parked, s, level, pending, ray_o, ray_d, T, hit, emit, shaded, stack.col);
                 shaded_w += (unsigned int)__popcll(__ballot(shaded != 0));
             }
             n_c = emit.m_c;
@@ -495,5 +602,39 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_pool(const PoolArgs * args, De
 }
 
 #undef PRT_POOL_LISTS
+
+// Between the fast k_pool and its adopting EXACT launch: the parked shadow rays, traced exactly (trace_ray on a full-height
+// global stack; a point light's shadow ray, which uses its hit distance, gets its near ties resolved) and their radiance
+// added.  A small fixed grid that reads the list length on the device and normally finds 0.
+template <bool COUNT>
+__global__ __launch_bounds__(256) void k_pool_parked_shadows(const PoolArgs * args, DevCounters * ctr) {
+    const PoolArgs A = pool_args(args);
+    const DevScene & sc = A.sc;
+    const DevParams & P = A.P;
+    const unsigned int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned int n = A.Q.park_count[1] < A.Q.spark_cap ? A.Q.park_count[1] : A.Q.spark_cap;
+    if (gid == 0) {
+        atomicMax(&ctr->park_peak[0], (unsigned long long)A.Q.park_count[0]);
+        atomicMax(&ctr->park_peak[1], (unsigned long long)A.Q.park_count[1]);
+    }
+    TraceStats st;
+    st.nodes = st.tris = st.wnodes = st.wleaves = st.wtris = st.wrefills = st.max_sp = st.culled = 0;
+    GlobalStack slow;
+    slow.col = P.exact_stack + gid;
+    slow.stride = P.exact_stack_stride;
+    for (unsigned int i = gid; i < n; i += gridDim.x * blockDim.x) {
+        const float4 ro = A.Q.spark[i], pay = A.Q.spark[(size_t)A.Q.spark_cap + i], rd = A.Q.spark[2u * (size_t)A.Q.spark_cap + i];
+        const int sample = as_i(ro.w);
+        const f3 d = mk3(rd.x, rd.y, rd.z);
+        const f3 ob = mk3(ro.x, ro.y, ro.z) + d * P.ray_bias;                   // raytracer.cpp:163
+        const HitRec h = trace_ray<GlobalStack, COUNT>(sc, ob, d, pay.w < 0.0f ? TRACE_ANY : TRACE_CLOSEST, P.box_pad, slow, st);
+        const bool lit = h.tri < 0 || (pay.w >= 0.0f && h.t * h.t <= pay.w);
+        if (lit) accum_add(A.B.accum + sample, mk3(pay.x, pay.y, pay.z));
+    }
+    if (COUNT) {
+        atomicAdd(&ctr->node_visits, (unsigned long long)st.nodes);
+        atomicAdd(&ctr->tri_tests, (unsigned long long)st.tris);
+    }
+}
 
 }  // namespace prt

@@ -34,7 +34,7 @@ enum { WF_KIND_CLOSEST = 0, WF_KIND_SHADOW_ANY = 1, WF_KIND_SHADOW_DIST = 2 };
 enum { WF_STAGE_REFL = 0, WF_STAGE_SPEC = 1, WF_STAGE_ALPHA = 2, WF_STAGE_DONE = 3 };
 
 struct WaveBuffers {
-    float4 * accum;              // [N] per-sample radiance (xyz)
+    Accum * accum;               // [N] per-sample radiance (xyz), fixed point (dev_scene.h)
     ulonglong2 * rng;            // [N] (chain, prev)
     ulonglong2 * rng_aux;        // [N] (seed0, k)            RING only
     u64 * ring;                  // [16][N]                   RING only
@@ -48,8 +48,8 @@ struct WaveBuffers {
                                  //               it (raytracer.cpp:393-396); w < 0: directional light number -w - 1, whose
                                  //               direction comes from the light table - no per-ray copy of a constant
     float4 * sq_d;               //               (d.xyz, -)   written and read for point lights only
-    unsigned int * counts;       // [0] next closest count, [1] next shadow count, [2] trace fetch head, [3] overflowed rays
-    unsigned int * overflow;     // ray indices whose traversal dropped a stack push (re-traced by k_trace_overflow)
+    unsigned int * counts;       // [0] next closest count, [1] next shadow count, [2] trace fetch head, [3] rays handed to k_trace_exact
+    unsigned int * overflow;     // ray indices whose hit has a near tie or whose stack overflowed (traced again, exactly, by k_trace_exact)
     unsigned int n_samples;      // samples of THIS chain (all per-sample arrays are indexed 0 .. n_samples)
     unsigned int sample_base;    // global id of its first sample (pixel / key derivation only)
 };
@@ -106,7 +106,7 @@ __global__ __launch_bounds__(256) void k_raygen(DevCamera cam, DevParams P, Wave
     sample_begin<RING>(cam, P, pixel, samp, S, cur, ring, B.n_samples);
     B.rng[sid] = make_ulonglong2(S.rng.chain, S.rng.prev);
     if (RING) B.rng_aux[sid] = make_ulonglong2(S.rng.seed0, (u64)S.rng.k);
-    B.accum[sid] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    accum_zero(B.accum + sid);
     B.rq_o[0][sid] = make_float4(cur.ray_o.x, cur.ray_o.y, cur.ray_o.z, as_f((int)sid));
     B.rq_d[0][sid] = make_float4(cur.ray_d.x, cur.ray_d.y, cur.ray_d.z, as_f(0));
     B.rq_t[0][sid] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
@@ -205,12 +205,13 @@ __global__ __launch_bounds__(BLOCK, 6) void k_trace(DevScene sc, DevParams P, Wa
                 trav_node_step<LdsStack<BLOCK>, COUNT>(sc, r, stack, st);
                 if (__popcll(__ballot(r.node >= 0)) < nmin) break;
             }
-            bool fin = r.node == TRAV_SENTINEL;
+            bool fin = trav_done(r.node);
             if (!fin && r.node < 0) fin = trav_leaf<LdsStack<BLOCK>, COUNT>(sc, r, stack, st);
             if (fin) {
-                if (r.overflow) {
-                    // a push did not fit the LDS column (never observed on real scenes): hand the ray to
-                    // k_trace_overflow, which redoes it on a full-height global stack before k_shade runs
+                if (trav_needs_slow_path(r)) {
+                    // rare: the hit has company within a few ulp and the reference's visit order decides (dev_trace.h), or
+                    // a push did not fit the LDS column (never observed on real scenes): hand the ray to k_trace_exact, which
+                    // traces it again on a full-height stack and replays that order, before k_shade runs
                     B.overflow[atomicAdd(B.counts + 3, 1u)] = (unsigned int)ray;
                 } else if ((unsigned int)ray < n_closest) {
                     B.hits[ray] = make_float4(r.best.t, r.best.v, r.best.w, as_f(r.best.tri));
@@ -219,15 +220,7 @@ __global__ __launch_bounds__(BLOCK, 6) void k_trace(DevScene sc, DevParams P, Wa
                     // (boolean only, raytracer.cpp:385); otherwise the point light's inverted distance test (:396)
                     const bool lit = r.best.tri < 0 || (payload.w >= 0.0f && r.best.t * r.best.t <= payload.w);
                     if (lit) {
-                        if (multi_light) {
-                            atomicAdd(&B.accum[sample].x, payload.x);
-                            atomicAdd(&B.accum[sample].y, payload.y);
-                            atomicAdd(&B.accum[sample].z, payload.z);
-                        } else {
-                            float4 a = B.accum[sample];
-                            a.x += payload.x; a.y += payload.y; a.z += payload.z;
-                            B.accum[sample] = a;
-                        }
+                        accum_add(B.accum + sample, mk3(payload.x, payload.y, payload.z));
                     }
                 }
                 ray = -1;
@@ -249,19 +242,20 @@ __global__ __launch_bounds__(BLOCK, 6) void k_trace(DevScene sc, DevParams P, Wa
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Slow path of k_trace: rays whose LDS stack column overflowed are re-traced from scratch on a per-lane global
-// stack that holds the full worst-case bound.  A small fixed grid launched after every k_trace of a scene whose
-// bound exceeds the LDS column; it reads the list length on the device (no host round trip) and normally finds 0.
+// Slow path of k_trace: rays whose hit has a near tie or whose LDS stack column overflowed are traced again by trace_ray,
+// which replays the reference's visit order over near-tied candidates (dev_trace.h resolve_near_ties), on a per-lane global
+// stack that holds the full worst-case bound.  A small fixed grid launched after every k_trace; it reads the list length on the device (no host round trip)
+// and normally finds 0.
 template <bool COUNT>
-__global__ __launch_bounds__(256) void k_trace_overflow(DevScene sc, DevParams P, WaveBuffers B, int cur, unsigned int n_closest,
+__global__ __launch_bounds__(256) void k_trace_exact(DevScene sc, DevParams P, WaveBuffers B, int cur, unsigned int n_closest,
                                                          int multi_light, DevCounters * ctr) {
     const unsigned int gid = blockIdx.x * blockDim.x + threadIdx.x;
     const unsigned int n_overflow = B.counts[3];
     TraceStats st;
     st.nodes = st.tris = st.wnodes = st.wleaves = st.wtris = st.wrefills = st.max_sp = st.culled = 0;
     GlobalStack slow;
-    slow.col = P.stack_spill + gid;
-    slow.stride = P.stack_spill_stride;
+    slow.col = P.exact_stack + gid;
+    slow.stride = P.exact_stack_stride;
     for (unsigned int i = gid; i < n_overflow; i += gridDim.x * blockDim.x) {
         const unsigned int idx = B.overflow[i];
         float4 ro, rd, payload = make_float4(0, 0, 0, 0);
@@ -287,24 +281,14 @@ __global__ __launch_bounds__(256) void k_trace_overflow(DevScene sc, DevParams P
         const int sample = as_i(ro.w);
         const f3 d = mk3(rd.x, rd.y, rd.z);
         const f3 ob = mk3(ro.x, ro.y, ro.z) + d * P.ray_bias;
-        bool again;
-        const HitRec best = trace_ray_on<GlobalStack, COUNT>(sc, ob, d, kind == WF_KIND_SHADOW_ANY ? TRACE_ANY : TRACE_CLOSEST,
-                                                             P.box_pad, slow, st, again);
+        const HitRec best = trace_ray<GlobalStack, COUNT>(sc, ob, d, kind == WF_KIND_SHADOW_ANY ? TRACE_ANY : TRACE_CLOSEST, P.box_pad, slow, st);
         if (idx < n_closest) {
             B.hits[idx] = make_float4(best.t, best.v, best.w, as_f(best.tri));
         } else {
             const float dist_sq = kind == WF_KIND_SHADOW_ANY ? -1.0f : payload.w;
             const bool lit = best.tri < 0 || (dist_sq >= 0.0f && best.t * best.t <= dist_sq);
             if (lit) {
-                if (multi_light) {
-                    atomicAdd(&B.accum[sample].x, payload.x);
-                    atomicAdd(&B.accum[sample].y, payload.y);
-                    atomicAdd(&B.accum[sample].z, payload.z);
-                } else {
-                    float4 a = B.accum[sample];
-                    a.x += payload.x; a.y += payload.y; a.z += payload.z;
-                    B.accum[sample] = a;
-                }
+                accum_add(B.accum + sample, mk3(payload.x, payload.y, payload.z));
             }
         }
     }
@@ -653,11 +637,7 @@ PRT_D void shade_entry_on(const DevScene & sc, const DevParams & P, const WaveBu
 
     // ---- outputs ------------------------------------------------------------------------------------------
     if (live) {
-        if (add.x != 0.0f || add.y != 0.0f || add.z != 0.0f) {
-            float4 a = B.accum[s];
-            a.x += add.x; a.y += add.y; a.z += add.z;
-            B.accum[s] = a;
-        }
+        if (add.x != 0.0f || add.y != 0.0f || add.z != 0.0f) accum_add(B.accum + s, add);
         B.rng[s] = make_ulonglong2(rng.chain, rng.prev);
         if (RING) B.rng_aux[s] = make_ulonglong2(rng.seed0, (u64)rng.k);
     }

@@ -85,6 +85,7 @@ struct prt_ctx {
     prt_scene_info info;
     float scene_abs_max = 0.0f;
     bool any_translucent = false;
+    bool point_lights = false;            // any point light: its shadow rays use the hit distance (raytracer.cpp:396), so they can be near-tied too
     bool textured = false;                // any material has a texture map: the TEX kernel variants run
     // PRT_PIPELINE_DEFAULT: which pipeline won the try-out for a (scene, pixel set, sampling) configuration
     struct TuneEntry { uint64_t key[6]; unsigned int pipeline; };
@@ -118,6 +119,8 @@ struct prt_ctx {
     } chain[PRT_MAX_CHAINS];
     DevBuf<unsigned int> wf_counts;       // persistent / pool pipelines' sample counter
     DevBuf<float4> pool_f4;               // pool pipeline: the waves' private ray lists
+    DevBuf<float4> pool_park;             // pool pipeline: rays parked for the slow launches (kernels_pool.h PoolBuffers::park)
+    size_t pool_park_cap = 1u << 18, pool_spark_cap = 1u << 18;     // entries; enlarged when a frame needed more (render_pixels)
     DevBuf<unsigned int> pool_fin;        // adaptive mode: per-wave lists of pixels to finalise
     DevBuf<PoolArgs> pool_args;           // k_pool's arguments (read per phase from memory, kernels_pool.h)
     DevBuf<float4> adapt_f4;              // adaptive mode: scratch [max_spp][n] + running sums [n] + final colours [n]
@@ -272,16 +275,18 @@ int chain_setup(prt_ctx * ctx, Chain & c, int index, const DevParams & P, bool r
     HIP_TRY(ctx, w.rng.ensure(ring ? 2 * N : N));
     HIP_TRY(ctx, w.counts.ensure(16));
     HIP_TRY(ctx, w.overflow.ensure(N * (1 + (size_t)n_lights)));
-    if (ctx->stack_bound > P.stack_lds_entries) {
-        HIP_TRY(ctx, w.slow_stack.ensure((size_t)ctx->stack_bound * 64 * 256));     // k_trace_overflow's fixed grid
-        c.P.stack_spill = w.slow_stack.p;
-        c.P.stack_spill_stride = 64 * 256;
+    {
+        // k_trace_exact's fixed grid: full-height stack columns for the rays k_trace hands over (near ties, overflowed columns)
+        const size_t exact_lanes = 64 * 256;
+        HIP_TRY(ctx, w.slow_stack.ensure((size_t)std::max(ctx->stack_bound, 4u) * exact_lanes));
+        c.P.exact_stack = w.slow_stack.p;
+        c.P.exact_stack_stride = (unsigned int)exact_lanes;
     }
     WaveBuffers & B = c.B;
     memset(&B, 0, sizeof(B));
     B.n_samples = n_samples;
     B.sample_base = base;
-    B.accum = ctx->sample_rgb.p + base;
+    B.accum = reinterpret_cast<Accum *>(ctx->sample_rgb.p) + base;
     B.rng = w.rng.p;
     B.rng_aux = ring ? w.rng.p + N : nullptr;
     B.ring = ring ? ctx->ring_ws.p + (size_t)16 * base : nullptr;   // this chain's own [16][n_samples] block of the shared ring workspace
@@ -303,7 +308,7 @@ int chain_setup(prt_ctx * ctx, Chain & c, int index, const DevParams & P, bool r
 struct WaveTuning {
     int per_cu, keep_min, node_min, multi_light, shade_block;
     unsigned int chunk_min;
-    bool may_overflow, ring, count_visits;
+    bool ring, count_visits;
     size_t lds;
 };
 
@@ -331,14 +336,13 @@ int chain_issue_round(prt_ctx * ctx, Chain & c, const WaveTuning & t) {
     HIP_TRY(ctx, hipEventRecord(c.ws->ev_t1, stream));
     if (c.round == 0) HIP_TRY(ctx, hipEventRecord(c.ws->ev_first, stream));
     c.launches++;
-    if (t.may_overflow) {
-        // only scenes whose worst-case stack bound exceeds the LDS column can overflow; the kernel reads the
-        // list length on the device and normally finds it zero
+    {
+        // rays with a near-tied hit; the kernel reads the list length on the device and normally finds it zero
         constexpr unsigned int OVF_BLOCKS = 64;
         if (t.count_visits)
-            hipLaunchKernelGGL(k_trace_overflow<true>, dim3(OVF_BLOCKS), dim3(256), 0, stream, ctx->scene, c.P, B, c.cur, c.n_closest, t.multi_light, ctx->counters.p);
+            hipLaunchKernelGGL(k_trace_exact<true>, dim3(OVF_BLOCKS), dim3(256), 0, stream, ctx->scene, c.P, B, c.cur, c.n_closest, t.multi_light, ctx->counters.p);
         else
-            hipLaunchKernelGGL(k_trace_overflow<false>, dim3(OVF_BLOCKS), dim3(256), 0, stream, ctx->scene, c.P, B, c.cur, c.n_closest, t.multi_light, ctx->counters.p);
+            hipLaunchKernelGGL(k_trace_exact<false>, dim3(OVF_BLOCKS), dim3(256), 0, stream, ctx->scene, c.P, B, c.cur, c.n_closest, t.multi_light, ctx->counters.p);
         HIP_TRY(ctx, hipGetLastError());
     }
     if (c.n_closest) {
@@ -411,7 +415,6 @@ int render_wavefront(prt_ctx * ctx, const DevCamera & cam, const DevParams & P, 
     t.shade_block = n_chains >= 2 ? 256 : 1024;
     if (const char * e = getenv("PRT_SHADE_BLOCK")) t.shade_block = atoi(e) == 256 ? 256 : 1024;
     t.multi_light = ctx->scene.light_count > 1 ? 1 : 0;
-    t.may_overflow = ctx->stack_bound > P.stack_lds_entries;
 
     Chain chain[PRT_MAX_CHAINS];
     int rc = 0;
@@ -471,13 +474,26 @@ int render_wavefront(prt_ctx * ctx, const DevCamera & cam, const DevParams & P, 
 // workspace, without the global queues), plus cap (+ cap * lights shadow) ray slots per resident wave.
 // RINGMEM = false: no sample can make more than 15 RNG draws (and the scene is opaque, untextured, fixed spp): the
 // general-RNG variant runs without its draw ring in memory (dev_rng.h).
+template <int BLOCK, int WAVES, bool LDSTAB, bool RING, bool COUNT, bool TEX, bool ADAPT, bool RINGMEM, bool EXACT>
+int launch_pool_kernel(prt_ctx * ctx, unsigned int grid, size_t lds, const PoolArgs * d_args) {
+    hipLaunchKernelGGL((k_pool<BLOCK, WAVES, LDSTAB, RING, COUNT, TEX, ADAPT, RINGMEM, EXACT>), dim3(grid), dim3(BLOCK), lds, ctx->stream, d_args, ctx->counters.p);
+    HIP_TRY(ctx, hipGetLastError());       // a template variant that cannot launch (LDS, registers) is reported here, by name of its cause
+    return 0;
+}
+
 template <int BLOCK, int WAVES, bool LDSTAB, bool RING, bool TEX, bool ADAPT, bool RINGMEM = true>
 int launch_pool(prt_ctx * ctx, bool count, const DevCamera & cam, DevParams P, unsigned int n_samples, unsigned int stack_entries) {
     // the stack columns double as the shading phase's frame storage (WFRAME_LDS_DWORDS per lane)
     const size_t lds = (size_t)std::max(stack_entries, (unsigned int)WFRAME_LDS_DWORDS) * BLOCK * sizeof(int);
+    // Three launches (kernels_pool.h PoolBuffers::park): the fast kernel, which parks the rays it cannot finish - a hit with
+    // company within a few ulp, a stack column that overflowed -; k_pool_parked_shadows for the parked shadow rays; the EXACT
+    // kernel, adopting the parked closest-hit rays.  Normally nothing is parked and the two follow-ups leave at once.
+    // PRT_POOL_EXACT=1 (tests): the EXACT kernel does the whole render.
+    const bool exact_only = getenv("PRT_POOL_EXACT") != nullptr;
     int per_cu = 0;
-    hipError_t oe = count ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_pool<BLOCK, WAVES, LDSTAB, RING, true, TEX, ADAPT, RINGMEM>, BLOCK, lds)
-                          : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_pool<BLOCK, WAVES, LDSTAB, RING, false, TEX, ADAPT, RINGMEM>, BLOCK, lds);
+    hipError_t oe = exact_only ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_pool<BLOCK, WAVES, LDSTAB, RING, false, TEX, ADAPT, RINGMEM, true>, BLOCK, lds)
+                  : count      ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_pool<BLOCK, WAVES, LDSTAB, RING, true, TEX, ADAPT, RINGMEM, false>, BLOCK, lds)
+                               : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_pool<BLOCK, WAVES, LDSTAB, RING, false, TEX, ADAPT, RINGMEM, false>, BLOCK, lds);
     if (oe != hipSuccess || per_cu < 1) per_cu = 1;
     per_cu = std::min(per_cu, 8);
     if (const char * e = getenv("PRT_POOL_BLOCKS_PER_CU")) per_cu = std::max(1, std::min(per_cu, atoi(e)));
@@ -501,30 +517,48 @@ int launch_pool(prt_ctx * ctx, bool count, const DevCamera & cam, DevParams P, u
     HIP_TRY(ctx, w.f4.ensure((size_t)levels * fr4 * N));
     HIP_TRY(ctx, w.rng.ensure(RING ? 2 * N : N));
     HIP_TRY(ctx, ctx->pool_f4.ensure((size_t)waves * (7u * (size_t)cap + 3u * (size_t)scap)));
+    // [0] sample counter, [1] parked closest-hit / finalise entries, [2] parked shadow rays, [3] the adopting launch's counter
     HIP_TRY(ctx, ctx->wf_counts.ensure(16));
-    HIP_TRY(ctx, hipMemsetAsync(ctx->wf_counts.p, 0, 16, ctx->stream));
-    if (ctx->stack_bound > stack_entries) {
-        const size_t lanes = (size_t)grid * BLOCK;
-        HIP_TRY(ctx, ctx->stack_spill.ensure((size_t)ctx->stack_bound * lanes));
-        P.stack_spill = ctx->stack_spill.p;
-        P.stack_spill_stride = (unsigned int)lanes;
-    }
+    HIP_TRY(ctx, hipMemsetAsync(ctx->wf_counts.p, 0, 16 * sizeof(unsigned int), ctx->stream));
+    // Park lists: sized for what scenes with coincident geometry need in practice, never for the worst case (every sample's
+    // ray parked: 48 bytes x samples x (1 + lights)).  The kernels count what they could not store; render_pixels looks at
+    // the counts after the frame and, if a list was too short, enlarges it and renders the frame again.
+    const size_t park_cap = std::min<size_t>(ctx->pool_park_cap, N + (ADAPT ? N : 0)), spark_cap = std::min<size_t>(ctx->pool_spark_cap, N * n_lights);
+    HIP_TRY(ctx, ctx->pool_park.ensure(3 * (park_cap + spark_cap)));
+    // the EXACT launch's lanes continue their LDS stack columns in memory; k_pool_parked_shadows has full-height columns
+    const unsigned int grid2 = exact_only ? grid : std::max(1u, std::min(grid, (unsigned int)ctx->cu_count));
+    const size_t exact_lanes = (size_t)POOL_PARKED_SHADOW_BLOCKS * 256, spill_lanes = (size_t)grid2 * BLOCK;
+    const size_t spill_entries = ctx->stack_bound > stack_entries ? ctx->stack_bound - stack_entries : 0;
+    const size_t exact_ints = (size_t)std::max(ctx->stack_bound, 4u) * exact_lanes;
+    HIP_TRY(ctx, ctx->stack_spill.ensure(exact_ints + spill_entries * spill_lanes));
+    P.exact_stack = ctx->stack_spill.p;
+    P.exact_stack_stride = (unsigned int)exact_lanes;
+    P.stack_spill = spill_entries ? ctx->stack_spill.p + exact_ints : nullptr;
+    P.stack_spill_stride = (unsigned int)spill_lanes;
+
     WaveBuffers B;
     memset(&B, 0, sizeof(B));
     B.n_samples = n_samples;
     B.sample_base = 0;
-    B.accum = ctx->sample_rgb.p;
+    B.accum = reinterpret_cast<Accum *>(ctx->sample_rgb.p);
     B.rng = w.rng.p;
     B.rng_aux = RING ? w.rng.p + N : nullptr;
     B.ring = RING && RINGMEM ? ctx->ring_ws.p : nullptr;
     B.frames = w.f4.p;
     PoolBuffers Q;
+    memset(&Q, 0, sizeof(Q));
     Q.cq = ctx->pool_f4.p;
     Q.hits = Q.cq + (size_t)waves * 6u * cap;
     Q.sq = Q.hits + (size_t)waves * cap;
     Q.head = ctx->wf_counts.p;
     Q.cap = cap;
     Q.scap = scap;
+    Q.park = ctx->pool_park.p;
+    Q.spark = ctx->pool_park.p + 3 * park_cap;
+    Q.park_count = ctx->wf_counts.p + 1;
+    Q.park_cap = (unsigned int)park_cap;
+    Q.spark_cap = (unsigned int)spark_cap;
+    Q.adopt = 0;
     Q.fin = nullptr; Q.scratch = nullptr; Q.jobsum = nullptr; Q.final_rgb = nullptr;
     if (ADAPT) {
         // n_samples counts PIXELS here: the unit in the pool is a pixel that runs its samples one after the other
@@ -551,29 +585,47 @@ int launch_pool(prt_ctx * ctx, bool count, const DevCamera & cam, DevParams P, u
     A.keep_min = keep_min;
     A.node_min = node_min;
     A.multi_light = multi_light;
-    HIP_TRY(ctx, ctx->pool_args.ensure(1));
+    HIP_TRY(ctx, ctx->pool_args.ensure(2));
     hipLaunchKernelGGL(k_pool_store_args, dim3(1), dim3(64), 0, ctx->stream, A, ctx->pool_args.p);
     HIP_TRY(ctx, hipGetLastError());
-    if (count)
-        hipLaunchKernelGGL((k_pool<BLOCK, WAVES, LDSTAB, RING, true, TEX, ADAPT, RINGMEM>), dim3(grid), dim3(BLOCK), lds, ctx->stream, ctx->pool_args.p, ctx->counters.p);
-    else
-        hipLaunchKernelGGL((k_pool<BLOCK, WAVES, LDSTAB, RING, false, TEX, ADAPT, RINGMEM>), dim3(grid), dim3(BLOCK), lds, ctx->stream, ctx->pool_args.p, ctx->counters.p);
-    HIP_TRY(ctx, hipGetLastError());       // a template variant that cannot launch (LDS, registers) is reported here, by name of its cause
-    return 0;
+    int rc;
+    if (exact_only) {
+        return count ? launch_pool_kernel<BLOCK, WAVES, LDSTAB, RING, true, TEX, ADAPT, RINGMEM, true>(ctx, grid, lds, ctx->pool_args.p)
+                     : launch_pool_kernel<BLOCK, WAVES, LDSTAB, RING, false, TEX, ADAPT, RINGMEM, true>(ctx, grid, lds, ctx->pool_args.p);
+    }
+    rc = count ? launch_pool_kernel<BLOCK, WAVES, LDSTAB, RING, true, TEX, ADAPT, RINGMEM, false>(ctx, grid, lds, ctx->pool_args.p)
+               : launch_pool_kernel<BLOCK, WAVES, LDSTAB, RING, false, TEX, ADAPT, RINGMEM, false>(ctx, grid, lds, ctx->pool_args.p);
+    if (rc) return rc;
+    if (count) hipLaunchKernelGGL(k_pool_parked_shadows<true>, dim3(POOL_PARKED_SHADOW_BLOCKS), dim3(256), 0, ctx->stream, ctx->pool_args.p, ctx->counters.p);
+    else hipLaunchKernelGGL(k_pool_parked_shadows<false>, dim3(POOL_PARKED_SHADOW_BLOCKS), dim3(256), 0, ctx->stream, ctx->pool_args.p, ctx->counters.p);
+    HIP_TRY(ctx, hipGetLastError());
+    // the adopting launch: one block per compute unit; they find the park list empty and leave at once - except in scenes
+    // with coincident geometry, where they finish what the first launch set aside
+    A.Q.adopt = 1;
+    A.Q.head = ctx->wf_counts.p + 3;
+    hipLaunchKernelGGL(k_pool_store_args, dim3(1), dim3(64), 0, ctx->stream, A, ctx->pool_args.p + 1);
+    HIP_TRY(ctx, hipGetLastError());
+    return count ? launch_pool_kernel<BLOCK, WAVES, LDSTAB, RING, true, TEX, ADAPT, RINGMEM, true>(ctx, grid2, lds, ctx->pool_args.p + 1)
+                 : launch_pool_kernel<BLOCK, WAVES, LDSTAB, RING, false, TEX, ADAPT, RINGMEM, true>(ctx, grid2, lds, ctx->pool_args.p + 1);
 }
 
-// sample colours -> pixels: the coalesced kernel for power-of-two spp up to 64, the one-lane-per-pixel kernel otherwise
-void launch_resolve(hipStream_t stream, const float4 * samples, float4 * out, unsigned int n_px, unsigned int spp) {
+template <bool FIXED>
+void launch_resolve_t(hipStream_t stream, const void * samples, float4 * out, unsigned int n_px, unsigned int spp) {
     const unsigned int grid2 = (unsigned int)(((unsigned long long)n_px * spp + 255ull) / 256ull);
     switch (spp) {
-        case 2: hipLaunchKernelGGL(k_resolve_pow2<2>, dim3(grid2), dim3(256), 0, stream, samples, out, n_px); break;
-        case 4: hipLaunchKernelGGL(k_resolve_pow2<4>, dim3(grid2), dim3(256), 0, stream, samples, out, n_px); break;
-        case 8: hipLaunchKernelGGL(k_resolve_pow2<8>, dim3(grid2), dim3(256), 0, stream, samples, out, n_px); break;
-        case 16: hipLaunchKernelGGL(k_resolve_pow2<16>, dim3(grid2), dim3(256), 0, stream, samples, out, n_px); break;
-        case 32: hipLaunchKernelGGL(k_resolve_pow2<32>, dim3(grid2), dim3(256), 0, stream, samples, out, n_px); break;
-        case 64: hipLaunchKernelGGL(k_resolve_pow2<64>, dim3(grid2), dim3(256), 0, stream, samples, out, n_px); break;
-        default: hipLaunchKernelGGL(k_resolve, dim3((n_px + 255) / 256), dim3(256), 0, stream, samples, out, n_px, spp);
+        case 2: hipLaunchKernelGGL((k_resolve_pow2<2, FIXED>), dim3(grid2), dim3(256), 0, stream, samples, out, n_px); break;
+        case 4: hipLaunchKernelGGL((k_resolve_pow2<4, FIXED>), dim3(grid2), dim3(256), 0, stream, samples, out, n_px); break;
+        case 8: hipLaunchKernelGGL((k_resolve_pow2<8, FIXED>), dim3(grid2), dim3(256), 0, stream, samples, out, n_px); break;
+        case 16: hipLaunchKernelGGL((k_resolve_pow2<16, FIXED>), dim3(grid2), dim3(256), 0, stream, samples, out, n_px); break;
+        case 32: hipLaunchKernelGGL((k_resolve_pow2<32, FIXED>), dim3(grid2), dim3(256), 0, stream, samples, out, n_px); break;
+        case 64: hipLaunchKernelGGL((k_resolve_pow2<64, FIXED>), dim3(grid2), dim3(256), 0, stream, samples, out, n_px); break;
+        default: hipLaunchKernelGGL(k_resolve<FIXED>, dim3((n_px + 255) / 256), dim3(256), 0, stream, samples, out, n_px, spp);
     }
+}
+// fixed: the samples are the wavefront / pool pipelines' fixed-point accumulators (dev_scene.h Accum), else float4 colours
+void launch_resolve(hipStream_t stream, const void * samples, bool fixed, float4 * out, unsigned int n_px, unsigned int spp) {
+    if (fixed) launch_resolve_t<true>(stream, samples, out, n_px, spp);
+    else launch_resolve_t<false>(stream, samples, out, n_px, spp);
 }
 
 // GPU radix-tree build + host collapse / quantise.  verts: 9 floats per triangle.
@@ -594,9 +646,13 @@ int build_bvh_lbvh(prt_ctx * ctx, const float * verts, uint32_t n_tris, uint32_t
     return 0;
 }
 
-// Renders the pixel set into d_out (device, float4 per pixel, packed in local pixel order).  Synchronous.
 int render_pixels(prt_ctx * ctx, const prt_camera * cam_in, const prt_params * params, uint32_t width, uint32_t height,
-                  const PixelSet & px, float4 * d_out, prt_counters * counters) {
+                  const PixelSet & px, float4 * d_out, prt_counters * counters);
+
+// Renders the pixel set into d_out (device, float4 per pixel, packed in local pixel order).  Synchronous.
+int render_pixels_once(prt_ctx * ctx, const prt_camera * cam_in, const prt_params * params, uint32_t width, uint32_t height,
+                       const PixelSet & px, float4 * d_out, prt_counters * counters, bool * park_overflow) {
+    *park_overflow = false;
     if (!ctx->has_scene) { ctx->error = "prt_render: no scene uploaded"; return -2; }
     if (!cam_in || !params || !width || !height) { ctx->error = "prt_render: null camera / params or empty image"; return -1; }
     if (params->spp == 0 || params->spp > 65535) { ctx->error = "prt_render: spp must be in 1..65535 (prt_key.h packs the sample in 16 bits)"; return -1; }
@@ -734,7 +790,7 @@ int render_pixels(prt_ctx * ctx, const prt_camera * cam_in, const prt_params * p
     unsigned int pass_pixels = px.n_pixels;
     {
         const unsigned long long lv = std::max(1u, P.bounce_depth), fr4 = ctx->textured ? 7 : ring_eff ? 5 : 4, nl = std::max(1u, ctx->scene.light_count);
-        unsigned long long per_sample = 16 + (ring && pipeline != PRT_PIPELINE_PERSISTENT ? 128 : 0);
+        unsigned long long per_sample = 32 + (ring && pipeline != PRT_PIPELINE_PERSISTENT ? 128 : 0);
         if (pipeline == PRT_PIPELINE_WAVEFRONT) per_sample += (lv * fr4 + 7 + 3 * nl) * 16 + (ring ? 32 : 16) + 4 * (1 + nl);
         if (pipeline == PRT_PIPELINE_POOL) per_sample += lv * fr4 * 16 + 32;
         if (adaptive) per_sample += ((unsigned long long)P.max_spp + 2) * 16;
@@ -752,16 +808,16 @@ int render_pixels(prt_ctx * ctx, const prt_camera * cam_in, const prt_params * p
     }
     const size_t n_samples64 = (size_t)pass_pixels * unit_spp;              // work items of the largest pass
     if (n_samples64 > 0x7FFFFFFFull) { ctx->error = "prt_render: spp too large for one pixel per pass"; return -1; }
-    HIP_TRY(ctx, ctx->sample_rgb.ensure(n_samples64));
+    HIP_TRY(ctx, ctx->sample_rgb.ensure(2 * n_samples64));      // float4 colours (megakernel, persistent) or 32-byte fixed-point accumulators
     HIP_TRY(ctx, ctx->counters.ensure(1));
     if (ring && pipeline != PRT_PIPELINE_PERSISTENT) HIP_TRY(ctx, ctx->ring_ws.ensure(n_samples64 * 16));
 
-    // Traversal stack: LDS column of up to STACK_LDS_CAP entries per lane (occupancy); rays that would need more
-    // - 3 pushes per 4-wide level are possible, nothing real comes close - are re-traced on a full-height global
-    // column (dev_trace.h LdsStack / GlobalStack).
+    // Traversal stack: LDS column of up to STACK_LDS_CAP entries per lane (occupancy); the rest of the worst-case bound
+    // - 3 pushes per 4-wide level are possible, nothing real comes close - lives in a per-lane global column behind it
+    // (dev_trace.h LdsStack).
     constexpr int BLOCK = 256;
     unsigned int stack_cap = 24;
-    if (const char * e = getenv("PRT_STACK_CAP")) stack_cap = (unsigned int)std::max(2, std::min(40, atoi(e)));   // test hook: force the fallback
+    if (const char * e = getenv("PRT_STACK_CAP")) stack_cap = (unsigned int)std::max(2, std::min(40, atoi(e)));   // test hook: force the spill area into use
     const unsigned int stack_entries = std::min(ctx->stack_bound, stack_cap);
     const size_t lds = (size_t)stack_entries * BLOCK * sizeof(int);
     P.stack_lds_entries = stack_entries;
@@ -770,13 +826,13 @@ int render_pixels(prt_ctx * ctx, const prt_camera * cam_in, const prt_params * p
 
 
     {
-        const unsigned int spill_entries = ctx->stack_bound;        // the slow stack holds the whole bound
-        // one slow-stack column per lane that may need it: every sample lane (megakernel), every persistent lane
-        // (persistent), every ray of a round (wavefront: the overflow kernel indexes columns by list position)
+        const unsigned int spill_entries = ctx->stack_bound > stack_entries ? ctx->stack_bound - stack_entries : 0;
+        // one spill column per lane that may need it: every sample lane (megakernel), every persistent lane (persistent);
+        // the pool and wavefront pipelines size theirs where they know their grids (launch_pool, chain_setup)
         const size_t spill_lanes = pipeline == PRT_PIPELINE_MEGAKERNEL ? ((n_samples64 + BLOCK - 1) / BLOCK) * BLOCK
                                  : pipeline == PRT_PIPELINE_PERSISTENT ? (size_t)8 * (size_t)ctx->cu_count * BLOCK
                                                                        : 0;                      // wavefront: per chain, see chain_setup
-        if (spill_entries > stack_entries && spill_lanes) {
+        if (spill_entries && spill_lanes) {
             if (spill_lanes >= (1ull << 32)) { ctx->error = "prt_render: too many lanes for the stack spill area"; return -1; }
             HIP_TRY(ctx, ctx->stack_spill.ensure((size_t)spill_entries * spill_lanes));
             P.stack_spill = ctx->stack_spill.p;
@@ -847,10 +903,10 @@ int render_pixels(prt_ctx * ctx, const prt_camera * cam_in, const prt_params * p
         HIP_TRY(ctx, hipGetLastError());
         if (single_launch) HIP_TRY(ctx, hipEventRecord(ctx->ev[3], stream));
         if (adaptive)       // k_pool<ADAPT> has already divided by each pixel's own sample count
-            hipLaunchKernelGGL(k_resolve, dim3((n_px + 255) / 256), dim3(256), 0, stream,
+            hipLaunchKernelGGL(k_resolve<false>, dim3((n_px + 255) / 256), dim3(256), 0, stream,
                                ctx->adapt_f4.p + ((size_t)P.max_spp + 1u) * n_samples, d_out + p0, n_px, 1u);
         else
-            launch_resolve(stream, ctx->sample_rgb.p, d_out + p0, n_px, P.spp);
+            launch_resolve(stream, ctx->sample_rgb.p, pipeline == PRT_PIPELINE_WAVEFRONT || pipeline == PRT_PIPELINE_POOL, d_out + p0, n_px, P.spp);
         HIP_TRY(ctx, hipGetLastError());
         if (single_launch && (counters || !last_pass)) {
             // the next pass reuses ev[2] / ev[3] (and the workspace is stream ordered anyway): take this pass's time now
@@ -863,6 +919,21 @@ int render_pixels(prt_ctx * ctx, const prt_camera * cam_in, const prt_params * p
     HIP_TRY(ctx, hipEventRecord(ctx->ev[1], stream));
     HIP_TRY(ctx, hipEventSynchronize(ctx->ev[1]));
 
+    *park_overflow = false;
+    if (counters || pipeline == PRT_PIPELINE_POOL) {
+        DevCounters h;
+        HIP_TRY(ctx, hipMemcpy(&h, ctx->counters.p, sizeof(h), hipMemcpyDeviceToHost));
+        if (pipeline == PRT_PIPELINE_POOL && (h.park_peak[0] > ctx->pool_park_cap || h.park_peak[1] > ctx->pool_spark_cap)) {
+            // a park list was too short for this frame (kernels_pool.h PoolBuffers::park): rays were dropped.  Longer lists,
+            // then the caller renders the frame again.  The lists are never longer than launch_pool's worst-case clamp.
+            if (getenv("PRT_DEBUG_UTIL")) fprintf(stderr, "[prt] park lists too short (%llu of %zu rays, %llu of %zu shadow rays): enlarging\n",
+                                                    (unsigned long long)h.park_peak[0], ctx->pool_park_cap, (unsigned long long)h.park_peak[1], ctx->pool_spark_cap);
+            ctx->pool_park_cap = std::max<size_t>(ctx->pool_park_cap, (size_t)h.park_peak[0] + (size_t)h.park_peak[0] / 2);
+            ctx->pool_spark_cap = std::max<size_t>(ctx->pool_spark_cap, (size_t)h.park_peak[1] + (size_t)h.park_peak[1] / 2);
+            *park_overflow = true;
+            return 0;
+        }
+    }
     if (counters) {
         DevCounters h;
         HIP_TRY(ctx, hipMemcpy(&h, ctx->counters.p, sizeof(h), hipMemcpyDeviceToHost));
@@ -899,6 +970,17 @@ int render_pixels(prt_ctx * ctx, const prt_camera * cam_in, const prt_params * p
         counters->pipeline = pipeline;
     }
     return 0;
+}
+
+int render_pixels(prt_ctx * ctx, const prt_camera * cam_in, const prt_params * params, uint32_t width, uint32_t height,
+                  const PixelSet & px, float4 * d_out, prt_counters * counters) {
+    for (int attempt = 0; attempt < 4; ++attempt) {
+        bool park_overflow = false;
+        const int rc = render_pixels_once(ctx, cam_in, params, width, height, px, d_out, counters, &park_overflow);
+        if (rc || !park_overflow) return rc;
+    }
+    ctx->error = "prt_render: the pool pipeline's park lists kept overflowing";
+    return -7;
 }
 
 }  // namespace
@@ -956,6 +1038,7 @@ prt_ctx * prt_create(int device_id) {
     e = make_stream(&ctx->stream);
     for (int i = 0; i < 4 && e == hipSuccess; ++i) e = hipEventCreate(&ctx->ev[i]);
     ctx->chain[0].stream = ctx->stream;
+    if (const char * pc = getenv("PRT_POOL_PARK_CAP")) ctx->pool_park_cap = ctx->pool_spark_cap = (size_t)std::max(1, atoi(pc));   // tests: start tiny, grow
     for (int c = 1; c < PRT_MAX_CHAINS && e == hipSuccess; ++c) e = make_stream(&ctx->chain[c].stream);
     for (int c = 0; c < PRT_MAX_CHAINS && e == hipSuccess; ++c) {
         prt_ctx::ChainWs & w = ctx->chain[c];
@@ -979,7 +1062,7 @@ void prt_destroy(prt_ctx * ctx) {
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     ctx->nodes.release(); ctx->tris.release(); ctx->shade.release(); ctx->diffuse_dirs.release(); ctx->spec_dirs.release();
     ctx->tri_rank.release(); ctx->materials.release(); ctx->lights.release();
-    ctx->sample_rgb.release(); ctx->frame_out.release(); ctx->counters.release(); ctx->ring_ws.release(); ctx->pixel_list.release(); ctx->wf_counts.release(); ctx->stack_spill.release(); ctx->pool_f4.release(); ctx->pool_fin.release(); ctx->pool_args.release(); ctx->adapt_f4.release();
+    ctx->sample_rgb.release(); ctx->frame_out.release(); ctx->counters.release(); ctx->ring_ws.release(); ctx->pixel_list.release(); ctx->wf_counts.release(); ctx->stack_spill.release(); ctx->pool_f4.release(); ctx->pool_park.release(); ctx->pool_fin.release(); ctx->pool_args.release(); ctx->adapt_f4.release();
     ctx->textures.release(); ctx->texels.release(); ctx->srgb_lut.release(); ctx->tri_uv.release(); ctx->tri_tan.release();
     for (int c = 0; c < PRT_MAX_CHAINS; ++c) {
         prt_ctx::ChainWs & w = ctx->chain[c];
@@ -1213,6 +1296,8 @@ int prt_upload_scene(prt_ctx * ctx, const prt_scene_desc * s) {
         for (int k = 0; k < 3; ++k) { d.color[k] = pl.color[k]; d.position[k] = pl.position[k]; d.facing[k] = pl.facing[k]; }
         d.falloff = pl.falloff;
     }
+    ctx->point_lights = false;
+    for (uint32_t l = 0; l < s->light_count; ++l) ctx->point_lights = ctx->point_lights || s->lights[l].type == PRT_LIGHT_POINT;
     std::vector<float4> ddirs(1024);
     for (uint32_t i = 0; i < 1024; ++i) ddirs[i] = diffuse_tangent_dir(i);
 
