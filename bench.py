@@ -1,7 +1,11 @@
 #!/usr/bin/env python3
 """bench.py - Mrays/s of the HIP ray-trace hot path on BASELINE.json's headline config.
 
-    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1 needs no launcher: the process starts its own N ranks as child processes (one per GPU, RANK / LOCAL_RANK / WORLD_SIZE /
+MASTER_* set, rendezvous on 127.0.0.1) before it has imported torch or touched HIP, relays rank 0's JSON line and exits
+non-zero if any rank failed.  Started under `python -m torch.distributed.run` it simply is one of the ranks.
 
 Workload (config C4): synthetic 1,002,528-triangle height-field OBJ in 1,024 groups, written
 to disk and loaded through the host OBJ loader, 1920x1080, 8 spp, bounce depth 2, seed 1234, the reference's
@@ -12,21 +16,23 @@ and their de-interleave on GPU 0.  Excluded, as in the reference's TIME_BLOCK("R
 (main.cpp:327): OBJ parse, hierarchy/BVH build, upload, tone map, PNG.
 
 A ray is one TraceRay call (raytracer.cpp:161): primary, shadow, bounce.  value = rays of all ranks / time.
-With several GPUs up to --frames-in-flight (default 2; 1 on a single GPU) consecutive frames overlap on each GPU, each on its own context / stream: the
-persistent kernels of a frame leave the GPU partly idle while their last rays drain, and the next frame fills that
-(1/8-frame shard: 2.74 -> 2.38 ms per frame).  Every frame is rendered, gathered and assembled inside the timed
-region; `render_ms_device` stays the per-frame device latency.
+With several GPUs up to --frames-in-flight (default 2; 1 on a single GPU) consecutive frames overlap on each GPU, each on
+its own context / stream: the persistent kernels of a frame leave the GPU partly idle while their last rays drain, and the
+next frame fills that.  Every frame is rendered, gathered and assembled inside the timed region; `render_ms_device` stays
+the per-frame device latency.  With N > 1 the render streams leave 8 compute units to the RCCL gather (PRT_RESERVE_CUS).
 Total work is fixed as N grows -> "scaling": "strong".
 
 Extra objects on the JSON line:
-  roofline      dominant kernel (k_trace, the persistent traversal kernel; one launch per bounce round):
-                SURVEY.md §8d algorithmic bytes of its launches in a frame (rays x 52 B + BVH nodes fetched x 64 B
-                + triangle tests x 48 B) / their summed duration, measured with HIP events on the kernel's own
-                stream inside the timed region.  `traffic` = HBM bytes per launch from rocprofv3 PMC passes of this
-                command (profiles/traffic_C4.json, FETCH_SIZE x 2 + WRITE_SIZE as the gfx950 guide prescribes), or null.
-  cpu_baseline  the CPU oracle ("port", oracle/prt_oracle.cpp, proven bit-identical to the compiled
-                reference) timed on this host's cores on a sparse pixel lattice of the SAME frame; rank 0,
-                N = 1 only.  The same lattice is the parity check of the GPU frame (max |dRGB|, ray counts).
+  roofline      the dominant kernel (k_pool: one launch = one frame): SURVEY.md §8d algorithmic bytes of a launch (rays x 52 B +
+                BVH nodes fetched x 64 B + triangle tests x 36 B + shaded hits x 80 B + pixels x 16 B) / its duration, measured
+                with HIP events on the kernel's own stream inside the timed region.  `traffic` = HBM bytes per launch from
+                rocprofv3 PMC passes of this command (profiles/traffic_C4.json, FETCH_SIZE x 2 + WRITE_SIZE as the gfx950
+                guide prescribes), or null.  `lane_utilisation`, `valu_busy`, `ta_busy`: what really bounds the kernel.
+  cpu_baseline  the CPU oracle ("port", oracle/prt_oracle.cpp, bit-identical to the compiled reference on every fixture) timed
+                on the physical cores of this host's socket 0, one pinned thread each, on a sparse pixel lattice of the SAME
+                frame; rank 0, N = 1 only.  The same lattice is the parity check of the GPU frame (max |dRGB|, ray counts).
+  extra.other_workloads   C2, C3, C5 and C4 with the reference's adaptive 10..50 spp sampling: 3 timed frames each and a lattice
+                of the frame compared with the unmodified reference's own pixels (tests/golden/).
 """
 from __future__ import annotations
 
@@ -55,8 +61,18 @@ WORKLOADS = {
 SHARD_BLOCK_ROWS = 8
 SEED = 1234
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s HBM3E spec peak
-# SURVEY.md §8d algorithmic bytes per unit, with this build's record sizes
-B_RAY, B_NODE, B_TRI, B_SHADE, B_PIXEL = 52, 64, 48, 144, 16
+# SURVEY.md §8d algorithmic bytes per unit of work: ray 52 (32 read + 20 written), BVH node = the build's node (64 B, 4-wide),
+# triangle test 36 (three float3), shaded hit 80 (3 normals + 3 indices + material), pixel 16.  `roofline.achieved` / `frac`
+# use THESE.  The build's own records are fatter (48 B pre-differenced triangle, 64 B shading record + 64 B material + 16 B
+# hit record = 144 B per shaded hit); the same figure with those sizes is reported next to it, not instead of it.
+B_RAY, B_NODE, B_TRI, B_SHADE, B_PIXEL = 52, 64, 36, 80, 16
+B_TRI_BUILD, B_SHADE_BUILD = 48, 144
+
+# The other BASELINE configs, timed in the same run (extra.other_workloads) and checked against the reference's golden pixels
+# (tests/golden/*.npz: the unmodified reference's own output on a pixel lattice of exactly this frame).
+#   key: (workload, golden fixture, adaptive max_spp or 0)
+OTHER_WORKLOADS = [("C2", "c2_cornell_512_l4", 0), ("C3", "c3_icosphere_1080p_l24", 0), ("C5", "c5_terrain1m_4k_l120", 0),
+                   ("C4-adaptive", "c4_terrain1m_adaptive_l60", 50)]
 
 
 def log(msg):
@@ -119,6 +135,8 @@ def main():
     ap.add_argument("--pipeline", type=int, default=0)
     ap.add_argument("--cpu-lattice", type=int, default=0, help="lattice stride of the CPU baseline (0 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=120.0, help="CPU work of the baseline sample in core-seconds (the lattice is chosen to match)")
+    ap.add_argument("--no-other-workloads", action="store_true", help="skip extra.other_workloads (C2, C3, C5, C4-adaptive)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend; gloo (host-staged) only exists to rehearse the N > 1 path on a 1-GPU box")
     ap.add_argument("--share-device", action="store_true", help="rehearsal: every rank uses GPU 0")
@@ -147,6 +165,11 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    if world > 1 and args.backend == "nccl":
+        # The RCCL gather of frame k runs while frame k + 1 renders (frames in flight).  The render kernels are persistent and
+        # fill every wave slot they are offered: their streams are created with a CU mask that leaves 8 compute units free, so
+        # the gather's kernels never wait for a render block to retire (csrc/prt_api.hip prt_create).
+        os.environ.setdefault("PRT_RESERVE_CUS", "8")
     if args.share_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -307,6 +330,7 @@ def main():
         cc = r.render_device(cam, pcount, width, height, 0, width * height, shard.data_ptr(), True)
     else:
         cc = r.render_shard_device(cam, pcount, width, height, SHARD_BLOCK_ROWS, rank, world, shard.data_ptr(), True)
+    st = r.render_stats()
     n_px_local = my_rows * width if world > 1 else width * height
     used = int(cc.pipeline)                       # what PRT_PIPELINE_DEFAULT resolved to for this shard size
     pipeline_name = {1: "megakernel", 2: "wavefront", 3: "persistent", 4: "pool"}[used]
@@ -314,20 +338,35 @@ def main():
     fused = used != 2
     # k_trace moves rays, nodes and triangle records; shading records and the framebuffer belong to k_shade / k_resolve.
     # The single-launch pipelines do all of it in the one kernel that is timed.
-    alg_bytes = cc.ray_count * B_RAY + cc.node_visits * B_NODE + cc.tri_tests * B_TRI
-    if fused:
-        alg_bytes += cc.shaded_hits * B_SHADE + n_px_local * B_PIXEL
+    def algorithmic_bytes(b_tri, b_shade):
+        n = cc.ray_count * B_RAY + cc.node_visits * B_NODE + cc.tri_tests * b_tri
+        if fused:
+            n += cc.shaded_hits * b_shade + n_px_local * B_PIXEL
+        return n
+    alg_bytes = algorithmic_bytes(B_TRI, B_SHADE)
+    alg_bytes_build = algorithmic_bytes(B_TRI_BUILD, B_SHADE_BUILD)
     kernel_ms = float(np.mean(trace_ms))
     achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
-    traffic = None
+    traffic = valu_busy = ta_busy = None
     tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.workload)
     if os.path.exists(tpath) and world == 1 and used in (2, 4):
         try:
             with open(tpath) as f:
-                traffic = json.load(f).get("hbm_bytes_per_frame_" + kernel_name)
+                tj = json.load(f)
+            traffic = tj.get("hbm_bytes_per_frame_" + kernel_name)
+            valu_busy = tj.get("valu_busy_" + kernel_name)          # SQ_ACTIVE_INST_VALU x 4 / SQ_BUSY_CYCLES of the same command (PMC)
+            ta_busy = tj.get("ta_busy_" + kernel_name)              # TA_TA_BUSY / (GRBM_GUI_ACTIVE per XCD x compute units)
         except Exception:
             traffic = None
     launches = max(1, int(cc.trace_kernel_launches))
+    lane_util = None
+    if st.wave_node_steps and st.wave_tri_steps:
+        # what actually bounds the kernel: vector issue with divergent lanes.  Lane-level work / (64 x
+        # wave-level steps) of the two traversal loops, from the counting render above.
+        lane_util = {"node_loop": round(st.node_visits / (64.0 * st.wave_node_steps), 4),
+                     "triangle_loop": round(st.tri_tests / (64.0 * st.wave_tri_steps), 4),
+                     "wave_node_steps": int(st.wave_node_steps), "wave_triangle_steps": int(st.wave_tri_steps),
+                     "rays_parked_for_the_exact_launch": int(st.parked_rays)}
     # `achieved` = algorithmic bytes per launch / mean launch duration; `traffic` = measured HBM bytes per launch.  Both are
     # also given per frame (launches_per_frame launches of the kernel make one frame).
     roofline = {"bound": "hbm", "kernel": kernel_name, "launches_per_frame": launches,
@@ -339,6 +378,12 @@ def main():
                 "per_frame": {"rays": int(cc.ray_count), "node_visits": int(cc.node_visits), "tri_tests": int(cc.tri_tests),
                                "shaded_hits": int(cc.shaded_hits), "pixels": int(n_px_local)},
                 "bytes_per_unit": {"ray": B_RAY, "node": B_NODE, "tri_test": B_TRI, "shaded_hit": B_SHADE, "pixel": B_PIXEL},
+                "with_this_builds_record_sizes": {"bytes_per_unit": {"tri_test": B_TRI_BUILD, "shaded_hit": B_SHADE_BUILD},
+                                                  "achieved": round(alg_bytes_build / (kernel_ms * 1e-3) / 1e9, 2) if kernel_ms > 0 else 0.0,
+                                                  "frac": round(alg_bytes_build / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if kernel_ms > 0 else 0.0},
+                # The algorithmic figure counts every per-lane node fetch; most are served by L1 / L2 / Infinity Cache.  What
+                # the kernel is bounded by is vector issue with divergent lanes, with the texture addresser not far behind:
+                "lane_utilisation": lane_util, "valu_busy": valu_busy, "ta_busy": ta_busy,
                 # SURVEY.md §8d asks for these two beside the algorithmic figure: what the kernel really moved through HBM
                 # (PMC, per second of kernel time, as a fraction of the 8 TB/s peak) and the compulsory minimum of a frame
                 # (every ray record once, the resident scene once, the framebuffer once)
@@ -352,27 +397,89 @@ def main():
     if world == 1 and not args.no_cpu_baseline:
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import oracle_py as orc
-        cores = max(1, min(len(os.sched_getaffinity(0)), 64))
+        # one thread per physical core of socket 0, pinned; the CPU model is part of the record
+        cpus, cpu_model = orc.socket0_physical_cpus()
+        cpus = cpus[:64]
+        cores = len(cpus)
+        orc.set_worker_cpus(cpus)
         lattice = args.cpu_lattice
         if lattice <= 0:
-            # aim at ~20 s of CPU work: probe a very sparse lattice first, then scale
-            probe = max(8, int(round((width * height / 200.0) ** 0.5)))
+            # a bounded sample: --cpu-seconds core-seconds of CPU work (default 40).  Probe a very sparse lattice first, then scale.
+            probe = max(8, int(round((width * height / 400.0) ** 0.5)))
             _, pc = orc.render(hs.desc, cam, params, width, height, probe, cores)
             per_px = pc.render_seconds * cores / max(1, ((width + probe - 1) // probe) * ((height + probe - 1) // probe))
-            want_px = 20.0 / max(per_px, 1e-9)
+            want_px = args.cpu_seconds / max(per_px, 1e-9)
             lattice = int(max(1, min(probe, round((width * height / want_px) ** 0.5))))
         cpu_img, octr = orc.render(hs.desc, cam, params, width, height, lattice, cores)
+        orc.set_worker_cpus([])
         gpu_img, gctr = r.render_lattice(cam, params, width, height, lattice)
         diff = np.abs(gpu_img[:, :, :3] - cpu_img[:, :, :3])
         cpu_mrays = octr.ray_count / octr.render_seconds / 1e6
         cpu_baseline = {"value": round(cpu_mrays, 4), "unit": "Mrays/s", "cores": cores, "kind": "port",
-                        "sample": "every %dth pixel in x and y of the same %dx%d x %d spp frame (%d pixels, %d rays, %.1f s wall on %d threads)" % (
-                            lattice, width, height, spp, cpu_img.shape[0] * cpu_img.shape[1], octr.ray_count, octr.render_seconds, cores),
+                        "cpu_model": cpu_model, "pinned_to_cpus": cpus,
+                        "pinned_to": "tests/test_oracle_golden.py: the port reproduces the compiled, unmodified reference bit for bit "
+                                     "(float framebuffer and all three DebugCounters) on 26 fixtures; the reference itself never leaves the build container",
+                        "sample": "every %dth pixel in x and y of the same %dx%d x %d spp frame (%d pixels, %d rays, %.1f s wall on %d pinned threads = %.0f core-seconds)" % (
+                            lattice, width, height, spp, cpu_img.shape[0] * cpu_img.shape[1], octr.ray_count, octr.render_seconds, cores,
+                            octr.render_seconds * cores),
                         "speedup_gpu_over_cpu": round(value / cpu_mrays, 1) if cpu_mrays > 0 else None}
         parity = {"pixels": int(cpu_img.shape[0] * cpu_img.shape[1]), "max_abs_diff_rgb": float(diff.max()),
                   "pixels_over_1e-4": int((diff.max(axis=2) > 1e-4).sum()),
                   "ray_count_gpu": int(gctr.ray_count), "ray_count_cpu": int(octr.ray_count),
                   "ray_count_equal": bool(gctr.ray_count == octr.ray_count)}
+
+    # ---- the other BASELINE configs, in the same run: time a few frames, check a lattice against the reference's own pixels
+    other = None
+    if world == 1 and rank == 0 and args.workload == "C4" and not args.no_other_workloads:
+        other = []
+        golden_dir = os.path.join(ROOT, "tests", "golden")
+        for wl, fixture, max_spp in OTHER_WORKLOADS:
+            gpath = os.path.join(golden_dir, fixture + ".npz")
+            base_wl = "C4" if wl == "C4-adaptive" else wl
+            sname, w2, h2, spp2, depth2, descr2 = WORKLOADS[base_wl]
+            if max_spp:
+                spp2 = 10                                      # the reference's own default: RenderPixel(min 10, max 50), main.cpp:308-309
+            try:
+                if sname == scene_name:
+                    r2, own = r, False
+                    cam_pos2, cam_dir2, fov2 = cam_pos, cam_dir, fov
+                else:
+                    sc2 = scenes.make_scene(sname)
+                    d2 = tempfile.mkdtemp(prefix="prt_bench_%s_" % sname)
+                    scenes.write_obj(sc2, d2, "scene.obj")
+                    cam_pos2, cam_dir2, fov2 = list(sc2.camera_position), list(sc2.camera_facing), float(sc2.fov)
+                    hs2 = api.HostScene(d2, "scene.obj", 0, cam_pos2)
+                    r2, own = api.Renderer(local_rank), True
+                    r2.upload(hs2)
+                cam2 = api.make_camera(fov2, w2, h2, cam_pos2, cam_dir2)
+                p2 = api.default_params(spp2, SEED, bounce_depth=depth2, pipeline=args.pipeline, max_spp=max_spp)
+                n_out = w2 * h2
+                buf2 = torch.zeros((n_out, 4), dtype=torch.float32, device=dev)
+                torch.cuda.synchronize()
+                r2.render_device(cam2, p2, w2, h2, 0, n_out, buf2.data_ptr(), True)           # workspace allocation + warm-up
+                t0 = time.perf_counter()
+                cs = [r2.render_device(cam2, p2, w2, h2, 0, n_out, buf2.data_ptr(), True) for _ in range(3)]
+                torch.cuda.synchronize()
+                dt = (time.perf_counter() - t0) / 3.0
+                rec = {"workload": wl, "description": descr2 + (", adaptive %d..%d spp (the reference's default sampling)" % (spp2, max_spp) if max_spp else ""),
+                       "steps": 3, "ms_per_frame": round(dt * 1e3, 4), "kernel_ms_per_frame": round(float(np.mean([c.trace_kernel_ms for c in cs])), 4),
+                       "rays_per_frame": int(cs[0].ray_count), "mrays_per_s": round(cs[0].ray_count / dt / 1e6, 1),
+                       "pipeline": {1: "megakernel", 2: "wavefront", 3: "persistent", 4: "pool"}[int(cs[0].pipeline)]}
+                if os.path.exists(gpath):
+                    g = np.load(gpath, allow_pickle=False)
+                    lat = int(g["lattice"])
+                    img, c = r2.render_lattice(cam2, p2, w2, h2, lat)
+                    dd = np.abs(img[:, :, :3] - g["rgb"])
+                    rec["parity_vs_reference_golden"] = {"fixture": fixture, "lattice": lat, "pixels": int(img.shape[0] * img.shape[1]),
+                                                         "max_abs_diff_rgb": float(dd.max()), "pixels_over_1e-4": int((dd.max(axis=2) > 1e-4).sum()),
+                                                         "ray_count_gpu": int(c.ray_count), "ray_count_reference": int(g["ray_count"]),
+                                                         "ray_count_equal": bool(int(c.ray_count) == int(g["ray_count"]))}
+                other.append(rec)
+                del buf2
+                if own:
+                    r2.close()
+            except Exception as e:                                 # an extra must not take the headline line down with it
+                other.append({"workload": wl, "error": repr(e)[:300]})
 
     multi_check = None
     if world > 1 and rank == 0 and frame is not None:
@@ -398,6 +505,7 @@ def main():
                        "pipeline": pipeline_name, "frames_in_flight": F},
             "render_ms_device": round(float(np.mean(render_ms)), 4),
             "roofline": roofline, "cpu_baseline": cpu_baseline, "parity": parity, "multi_gpu_check": multi_check,
+            "extra": {"other_workloads": other},
         }
         print(json.dumps(out), flush=True)
     if pool:

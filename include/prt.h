@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PRT_ABI_VERSION 2
+#define PRT_ABI_VERSION 3
 
 /* ---- scene description: the reference's pointer graph flattened to POD arrays ---------------- */
 
@@ -217,6 +217,19 @@ typedef struct prt_scene_info {
     double bvh_build_ms;
 } prt_scene_info;
 int prt_get_scene_info(const prt_ctx * ctx, prt_scene_info * info);
+
+/* Diagnostics of the context's last render call made with PRT_FLAG_COUNT_VISITS (bench.py's roofline block):
+ * wave-level step counts - lane utilisation of a loop = lane-level count / (64 x wave-level count) -, where the waves of the
+ * pool pipeline spent their time, and how many rays took the slow path (near-tied hits, include/prt.h "Determinism"). */
+typedef struct prt_render_stats {
+    uint64_t node_visits, tri_tests;           /* lane level, as in prt_counters */
+    uint64_t wave_node_steps, wave_tri_steps, wave_leaf_visits, wave_refills;
+    uint64_t deepest_stack;                    /* entries of a traversal stack column ever in use */
+    uint64_t phase_cycles[5];                  /* pool pipeline: top-up, trace, shade, whole main loop, adaptive finalise step */
+    uint64_t parked_rays, parked_shadow_rays;  /* pool pipeline: most rays any pass handed to its slow launches */
+    uint32_t stack_lds_entries, stack_bound;   /* LDS stack column height used, worst-case bound of the tree */
+} prt_render_stats;
+int prt_get_render_stats(const prt_ctx * ctx, prt_render_stats * stats);
 
 /* Host-only self check of the acceleration structure prt_upload_scene builds (runs without a GPU; the
  * CPU test-suite calls it): every triangle inside every ancestor's de-quantised box, every triangle in

@@ -38,6 +38,7 @@ def lib() -> C.CDLL:
         l = C.CDLL(PORT_LIB)
         l.prt_oracle_render.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32,
                                         C.c_uint32, C.c_void_p, C.POINTER(OracleCounters)]
+        l.prt_oracle_set_worker_cpus.argtypes = [C.POINTER(C.c_int), C.c_uint32]
         l.prt_oracle_rng_seed_state.argtypes = [C.c_uint64, C.c_void_p]
         l.prt_oracle_rng_next.argtypes = [C.c_uint64, C.c_uint32, C.c_void_p]
         l.prt_oracle_rng_float01.argtypes = [C.c_uint64, C.c_uint32, C.c_void_p]
@@ -54,6 +55,39 @@ def lib() -> C.CDLL:
         l.prt_oracle_camera_ray.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_void_p]
         _lib = l
     return _lib
+
+
+def set_worker_cpus(cpus) -> None:
+    """Worker thread t of render() pins itself to cpus[t % len(cpus)]; an empty list removes the pinning."""
+    arr = (C.c_int * max(1, len(cpus)))(*cpus)
+    lib().prt_oracle_set_worker_cpus(arr, len(cpus))
+
+
+def socket0_physical_cpus():
+    """One logical CPU per physical core of socket 0, among the CPUs this process may run on (BASELINE.md section 3's
+    protocol for the CPU baseline), and the CPU model name."""
+    allowed = sorted(os.sched_getaffinity(0))
+    per_core = {}
+    for c in allowed:
+        base = "/sys/devices/system/cpu/cpu%d/topology/" % c
+        try:
+            pkg = int(open(base + "physical_package_id").read())
+            core = int(open(base + "core_id").read())
+        except (OSError, ValueError):
+            pkg, core = 0, c
+        per_core.setdefault((pkg, core), c)
+    pkgs = sorted({k[0] for k in per_core})
+    first = pkgs[0] if pkgs else 0
+    cpus = sorted(v for k, v in per_core.items() if k[0] == first)
+    model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return cpus, model
 
 
 def render(desc_ptr, cam, params, width: int, height: int, lattice: int = 1, threads: int = 1

@@ -231,6 +231,12 @@ class Renderer:
         self._check(self._lib.prt_get_scene_info(self._ctx, C.byref(info)), "prt_get_scene_info")
         return info
 
+    def render_stats(self) -> "capi.PrtRenderStats":
+        """Diagnostics of the last render made with FLAG_COUNT_VISITS (lane utilisation, phase times, parked rays)."""
+        st = capi.PrtRenderStats()
+        self._check(self._lib.prt_get_render_stats(self._ctx, C.byref(st)), "prt_get_render_stats")
+        return st
+
     def render(self, cam: PrtCamera, params: PrtParams, width: int, height: int, start_idx: int = 0,
                end_idx: Optional[int] = None) -> Tuple[np.ndarray, PrtCounters]:
         if end_idx is None:

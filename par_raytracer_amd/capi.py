@@ -88,13 +88,20 @@ class PrtSceneInfo(C.Structure):
         return {n: getattr(self, n) for n, _ in self._fields_}
 
 
+class PrtRenderStats(C.Structure):
+    _fields_ = [("node_visits", C.c_uint64), ("tri_tests", C.c_uint64), ("wave_node_steps", C.c_uint64),
+                ("wave_tri_steps", C.c_uint64), ("wave_leaf_visits", C.c_uint64), ("wave_refills", C.c_uint64),
+                ("deepest_stack", C.c_uint64), ("phase_cycles", C.c_uint64 * 5), ("parked_rays", C.c_uint64),
+                ("parked_shadow_rays", C.c_uint64), ("stack_lds_entries", C.c_uint32), ("stack_bound", C.c_uint32)]
+
+
 PIPELINE_DEFAULT, PIPELINE_MEGAKERNEL, PIPELINE_WAVEFRONT, PIPELINE_PERSISTENT, PIPELINE_POOL = 0, 1, 2, 3, 4
 FLAG_COUNT_VISITS = 0x100
 FLAG_TRYOUT = 0x200
 
 # Every symbol include/prt.h declares; tests/test_capi_symbols.py checks the library exports them all.
 PRT_SYMBOLS = ["prt_create", "prt_destroy", "prt_last_error", "prt_abi_version", "prt_upload_scene", "prt_render",
-               "prt_render_device", "prt_shard_rows", "prt_render_shard_device", "prt_render_shard", "prt_render_pixel_list", "prt_get_scene_info", "prt_debug_check_bvh", "prt_debug_check_bvh_lbvh", "prt_debug_device_kat"]
+               "prt_render_device", "prt_shard_rows", "prt_render_shard_device", "prt_render_shard", "prt_render_pixel_list", "prt_get_scene_info", "prt_get_render_stats", "prt_debug_check_bvh", "prt_debug_check_bvh_lbvh", "prt_debug_device_kat"]
 PRT_HOST_SYMBOLS = ["prt_host_load_obj", "prt_host_free_scene", "prt_host_scene_desc", "prt_host_scene_hierarchy_seconds",
                     "prt_host_scene_parse_seconds", "prt_host_last_error", "prt_host_make_camera",
                     "prt_host_default_params", "prt_host_render", "prt_host_render_error", "prt_host_write_image", "prt_host_tonemap",
@@ -141,6 +148,7 @@ def hip_lib() -> C.CDLL:
         lib.prt_render_pixel_list.argtypes = [C.c_void_p, C.POINTER(PrtCamera), C.POINTER(PrtParams), C.c_uint32, C.c_uint32,
                                               C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(PrtCounters)]
         lib.prt_get_scene_info.argtypes = [C.c_void_p, C.POINTER(PrtSceneInfo)]
+        lib.prt_get_render_stats.argtypes = [C.c_void_p, C.POINTER(PrtRenderStats)]
         lib.prt_debug_check_bvh.argtypes = [C.POINTER(PrtSceneDesc), C.POINTER(C.c_uint64)]
         lib.prt_debug_check_bvh_lbvh.argtypes = [C.c_void_p, C.POINTER(PrtSceneDesc), C.POINTER(C.c_uint64)]
         lib.prt_debug_device_kat.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_uint32,

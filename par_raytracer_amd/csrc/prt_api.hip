@@ -119,6 +119,7 @@ struct prt_ctx {
     } chain[PRT_MAX_CHAINS];
     DevBuf<unsigned int> wf_counts;       // persistent / pool pipelines' sample counter
     DevBuf<float4> pool_f4;               // pool pipeline: the waves' private ray lists
+    prt_render_stats last_stats;          // of the last render call (prt_get_render_stats)
     DevBuf<float4> pool_park;             // pool pipeline: rays parked for the slow launches (kernels_pool.h PoolBuffers::park)
     size_t pool_park_cap = 1u << 18, pool_spark_cap = 1u << 18;     // entries; enlarged when a frame needed more (render_pixels)
     DevBuf<unsigned int> pool_fin;        // adaptive mode: per-wave lists of pixels to finalise
@@ -937,6 +938,16 @@ int render_pixels_once(prt_ctx * ctx, const prt_camera * cam_in, const prt_param
     if (counters) {
         DevCounters h;
         HIP_TRY(ctx, hipMemcpy(&h, ctx->counters.p, sizeof(h), hipMemcpyDeviceToHost));
+        {
+            prt_render_stats & rs = ctx->last_stats;
+            memset(&rs, 0, sizeof(rs));
+            rs.node_visits = h.node_visits; rs.tri_tests = h.tri_tests;
+            rs.wave_node_steps = h.wave_node_steps; rs.wave_tri_steps = h.wave_tri_steps; rs.wave_leaf_visits = h.wave_leaf_steps;
+            rs.wave_refills = h.wave_refills; rs.deepest_stack = h.max_sp;
+            for (int k = 0; k < 5; ++k) rs.phase_cycles[k] = h.phase_cycles[k];
+            rs.parked_rays = h.park_peak[0]; rs.parked_shadow_rays = h.park_peak[1];
+            rs.stack_lds_entries = stack_entries; rs.stack_bound = ctx->stack_bound;
+        }
         float ms = 0.0f;
         const float trace_ms = trace_ms_accum;
         HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
@@ -1016,6 +1027,7 @@ prt_ctx * prt_create(int device_id) {
     }
     memset(&ctx->scene, 0, sizeof(ctx->scene));
     memset(&ctx->info, 0, sizeof(ctx->info));
+    memset(&ctx->last_stats, 0, sizeof(ctx->last_stats));
     // PRT_RESERVE_CUS=k (multi-GPU callers): the context's streams are created with a CU mask that leaves the last k compute
     // units to others - the RCCL gather of the previous frame must not wait for a wave slot while this context's persistent
     // kernels hold every one of theirs (bench.py sets it for N > 1 with frames in flight).  The persistent grids are sized
@@ -1077,6 +1089,12 @@ void prt_destroy(prt_ctx * ctx) {
     for (int i = 0; i < 4; ++i) if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
+}
+
+int prt_get_render_stats(const prt_ctx * ctx, prt_render_stats * stats) {
+    if (!ctx || !stats) return -1;
+    *stats = ctx->last_stats;
+    return 0;
 }
 
 int prt_upload_scene(prt_ctx * ctx, const prt_scene_desc * s) {

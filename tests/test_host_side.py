@@ -33,7 +33,7 @@ def test_hip_library_exports_every_declared_symbol():
     assert set(names) == set(capi.PRT_SYMBOLS), "capi.PRT_SYMBOLS out of sync with include/prt.h"
     for n in names:
         assert hasattr(lib, n), "libprt_hip.so does not export %s" % n
-    assert lib.prt_abi_version() == 2
+    assert lib.prt_abi_version() == 3
 
 
 def test_host_library_exports_every_declared_symbol():

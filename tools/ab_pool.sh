@@ -5,7 +5,7 @@ cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
 for v in "$@"; do
     cp "$v" par_raytracer_amd/libprt_hip.so
-    python bench.py --no-cpu-baseline --pipeline 4 --steps ${AB_STEPS:-10} --warmup 2 ${AB_ARGS} 2>/dev/null | python -c "
+    python bench.py --no-cpu-baseline --no-other-workloads --pipeline 4 --steps ${AB_STEPS:-10} --warmup 2 ${AB_ARGS} 2>/dev/null | python -c "
 import json,sys
 j=json.loads(sys.stdin.read().strip().splitlines()[-1])
 r=j['roofline']
