@@ -93,6 +93,13 @@ struct PoolEmit {
 
 enum { POOL_PARKED_MARK = 0x7FFFFFFE };        // hits[].w of a closest-hit ray that was parked: not shaded here (never a triangle index)
 enum { POOL_PARK_CLOSEST = 0, POOL_PARK_FINALISE = 2 };
+// Adaptive mode, per-pixel state word jobsum[].w: the index of the pixel's current sample in the low bits, and
+enum { POOL_JOB_SAMPLE_MASK = 0x00FFFFFF,
+       POOL_JOB_DEFERRED = (int)0x80000000,    // a shadow ray of the pixel is parked: its finalise step waits for the EXACT launch
+       POOL_JOB_SPEC_FLYING = 0x40000000,      // the NEXT sample's camera ray is already in the pool (started speculatively)
+       POOL_JOB_SPEC_DRAWN = 0x20000000 };     // ... its jitter is drawn (RNG advanced, offsets in final_rgb[].xy) but no ray is in flight
+enum { POOL_CANCELLED_MARK = 0x7FFFFFFD };     // hits[].w of a speculative camera ray that must not be shaded (nor counted)
+enum { POOL_SPEC_PENDING_BIT = 0x800000 };     // in a list entry's `pending` field: this camera ray was started speculatively
 enum { POOL_PARKED_SHADOW_BLOCKS = 64 };         // k_pool_parked_shadows' fixed grid
 
 PRT_D void pool_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }
@@ -196,6 +203,7 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_pool(const PoolArgs * args, De
     pool_stack_spill(stack, (PoolArgsPtr)args);
 
     unsigned int n_f = 0;                      // wave-uniform (ADAPT): pixels waiting to be finalised
+    unsigned int n_spec = 0;                   // wave-uniform (ADAPT): of those, pixels whose next camera ray is already in the closest list
     int cur = 0;
     unsigned int n_c = 0, n_s = 0;             // wave-uniform: rays in the current closest / shadow list
     bool fetch_done = false;                   // wave-uniform: the sample counter ran past n_samples
@@ -277,8 +285,8 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_pool(const PoolArgs * args, De
                     rays -= cnt;                  // these rays were counted when the first launch traced them (raytracer.cpp:161: one TraceRay each)
                 }
             }
-          } else if (n_c + n_f + Q.topup_min <= cap) {
-            const unsigned int want = cap - n_c - n_f;
+          } else if (n_c + n_f - n_spec + Q.topup_min <= cap) {
+            const unsigned int want = cap - (n_c + n_f - n_spec);
             unsigned int base = 0;
             if (lane == 0) base = atomicAdd(Q.head, want);
             base = (unsigned int)__builtin_amdgcn_readfirstlane((int)base);
@@ -391,7 +399,11 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_pool(const PoolArgs * args, De
                         if (!EXACT && trav_needs_slow_path(r)) {
                             // rare: the hit has company within a few ulp and the reference's visit order decides, or a push did
                             // not fit the LDS column (dev_trace.h).  Not here: the ray is parked for the launches that follow.
-                            if ((unsigned int)ray < n_c) {
+                            if (ADAPT && (unsigned int)ray < n_c && ((unsigned int)as_i(cd[ray].w) >> 8 & POOL_SPEC_PENDING_BIT)) {
+                                // a speculative camera ray (see the end of the shade phase) is not worth parking: call it off; the
+                                // finalise step notices and starts the sample again, in the open
+                                hits[ray] = make_float4(0.0f, 0.0f, 0.0f, as_f(POOL_CANCELLED_MARK));
+                            } else if ((unsigned int)ray < n_c) {
                                 const unsigned int slot = atomicAdd(A.Q.park_count, 1u);
                                 if (slot < A.Q.park_cap) {
                                     const float4 t4 = ct[ray];
@@ -469,10 +481,23 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_pool(const PoolArgs * args, De
                     if (live) {
                         j = fin[i];
                     }
+                    int job = 0;                                                    // the pixel's state word (POOL_JOB_*)
+                    unsigned int spec_idx = 0;
+                    float4 spec_off = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                    if (live) {
+                        job = as_i(Q.jobsum[j].w);
+                        if (job & (POOL_JOB_SPEC_FLYING | POOL_JOB_SPEC_DRAWN)) {
+                            spec_off = Q.final_rgb[j];                              // (jitter x, jitter y, list index of the ray, -)
+                            spec_idx = (unsigned int)as_i(spec_off.z);
+                            // called off in the trace phase (it would have had to be parked)?
+                            if ((job & POOL_JOB_SPEC_FLYING) && as_i(hits[spec_idx].w) == POOL_CANCELLED_MARK)
+                                job = (job & ~POOL_JOB_SPEC_FLYING) | POOL_JOB_SPEC_DRAWN;
+                        }
+                    }
                     bool defer = false;
                     if (live && !EXACT) {
                         // a shadow ray of this pixel is parked (see the trace phase): the step waits for the EXACT launch
-                        defer = as_i(Q.jobsum[j].w) < 0;
+                        defer = (job & POOL_JOB_DEFERRED) != 0;
                         if (defer) {
                             const unsigned int slot = atomicAdd(Q.park_count, 1u);
                             if (slot < Q.park_cap) {
@@ -480,12 +505,19 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_pool(const PoolArgs * args, De
                                 Q.park[(size_t)Q.park_cap + slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
                                 Q.park[2u * (size_t)Q.park_cap + slot] = make_float4(0.0f, 0.0f, 0.0f, as_f(POOL_PARK_FINALISE));
                             }
+                            if (job & POOL_JOB_SPEC_FLYING) {
+                                // its next camera ray, started ahead, cannot be shaded before the step has run: call it off (the
+                                // jitter stays drawn) - the EXACT launch starts the sample again from the saved offsets
+                                hits[spec_idx].w = as_f(POOL_CANCELLED_MARK);
+                                job = (job & ~POOL_JOB_SPEC_FLYING) | POOL_JOB_SPEC_DRAWN;
+                            }
+                            Q.jobsum[j].w = as_f(job);
                         }
                     }
                     if (live && !defer) {
                         const f3 a = accum_read(B.accum + j);
                         const float4 st = Q.jobsum[j];
-                        unsigned int samp = (unsigned int)as_i(st.w);              // index of the sample that just ended
+                        unsigned int samp = (unsigned int)(job & POOL_JOB_SAMPLE_MASK);  // index of the sample that just ended
                         const f3 sum_prev = mk3(st.x, st.y, st.z);
                         const f3 c = a;
                         Q.scratch[(size_t)samp * n_px + j] = make_float4(c.x, c.y, c.z, 0.0f);
@@ -507,26 +539,36 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_pool(const PoolArgs * args, De
                             stop = samp >= P.max_spp;
                         }
                         if (stop) {
+                            // the pixel is done; a camera ray started ahead for a sample that does not exist is called off
+                            if (job & POOL_JOB_SPEC_FLYING) hits[spec_idx].w = as_f(POOL_CANCELLED_MARK);
                             const f3 out = sum / (float)samp;                       // color /= samp, main.cpp:262
                             Q.final_rgb[j] = make_float4(out.x, out.y, out.z, 1.0f);
                         } else {
                             Q.jobsum[j] = make_float4(sum.x, sum.y, sum.z, as_f((int)samp));
                             accum_zero(B.accum + j);
-                            Rng rng;
-                            const ulonglong2 rs = B.rng[j], ra = B.rng_aux[j];
-                            rng.chain = rs.x; rng.prev = rs.y; rng.seed0 = ra.x; rng.k = (u32)ra.y;
-                            u64 * ring = B.ring + j;
-                            const float off_y = rng_float11<true>(rng, ring, n_px);  // first draw -> .y (main.cpp:238, 247)
-                            const float off_x = rng_float11<true>(rng, ring, n_px);
-                            B.rng[j] = make_ulonglong2(rng.chain, rng.prev);
-                            B.rng_aux[j] = make_ulonglong2(rng.seed0, (u64)rng.k);
-                            const float jitter = samp < P.spp ? 0.5f : 1.0f;        // main.cpp:240 vs :249
-                            const unsigned int pixel = pixel_of_local(P, B.sample_base + j);
-                            const unsigned int x = pixel % P.width, y = pixel / P.width;
-                            const DevCamera cam = A.cam;
-                            ray_o = cam.position;
-                            ray_d = make_camera_dir(cam, (float)x + off_x * jitter, (float)y + off_y * jitter);
-                            go_on = true;
+                            if (!(job & POOL_JOB_SPEC_FLYING)) {
+                                // the sample's camera ray is not in the pool yet (the common case is that it is: see below)
+                                float off_x, off_y;
+                                if (job & POOL_JOB_SPEC_DRAWN) {
+                                    off_x = spec_off.x; off_y = spec_off.y;              // drawn ahead, the ray was called off
+                                } else {
+                                    Rng rng;
+                                    const ulonglong2 rs = B.rng[j], ra = B.rng_aux[j];
+                                    rng.chain = rs.x; rng.prev = rs.y; rng.seed0 = ra.x; rng.k = (u32)ra.y;
+                                    u64 * ring = B.ring + j;
+                                    off_y = rng_float11<true>(rng, ring, n_px);          // first draw -> .y (main.cpp:238, 247)
+                                    off_x = rng_float11<true>(rng, ring, n_px);
+                                    B.rng[j] = make_ulonglong2(rng.chain, rng.prev);
+                                    B.rng_aux[j] = make_ulonglong2(rng.seed0, (u64)rng.k);
+                                }
+                                const float jitter = samp < P.spp ? 0.5f : 1.0f;        // main.cpp:240 vs :249
+                                const unsigned int pixel = pixel_of_local(P, B.sample_base + j);
+                                const unsigned int x = pixel % P.width, y = pixel / P.width;
+                                const DevCamera cam = A.cam;
+                                ray_o = cam.position;
+                                ray_d = make_camera_dir(cam, (float)x + off_x * jitter, (float)y + off_y * jitter);
+                                go_on = true;
+                            }
                         }
                     }
                     emit.closest(go_on, j, ray_o, ray_d, mk3(1.0f, 1.0f, 1.0f), 0, 0u, false);
@@ -555,10 +597,67 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_pool(const PoolArgs * args, De
                     hit.t = h.x; hit.v = h.y; hit.w = h.z; hit.tri = as_i(h.w);
                 }
                 const bool parked = !EXACT && live && hit.tri == POOL_PARKED_MARK;      // continues in the EXACT launch
+                // adaptive mode: a camera ray started ahead of its pixel's finalise step, which then ended the pixel (or had to
+                // wait): as if it had never been traced
+                const bool cancelled = ADAPT && live && hit.tri == POOL_CANCELLED_MARK;
+                if (ADAPT) {
+                    pending &= ~(unsigned int)POOL_SPEC_PENDING_BIT;
+                    rays -= (unsigned long long)__popcll(__ballot(cancelled));
+                }
                 unsigned int shaded = 0;
                 // the frame under construction lives in this lane's (idle) traversal stack column
-                shade_entry_lds<RING, TEX, BLOCK, RINGMEM>(sc, P, B, tb, live && !parked, s, level, pending, ray_o, ray_d, T, hit, emit, shaded, stack.col);
+                shade_entry_lds<RING, TEX, BLOCK, RINGMEM>(sc, P, B, tb, live && !parked && !cancelled, s, level, pending, ray_o, ray_d, T, hit, emit, shaded, stack.col);
                 shaded_w += (unsigned int)__popcll(__ballot(shaded != 0));
+            }
+            if (ADAPT) {
+                // ---- start ahead: a pixel whose sample just ended would sit out the next trace phase - its finalise step has to
+                // wait for the sample's last shadow rays - and that is one round in three or four with no ray from the pixel.
+                // The next sample's camera ray needs nothing from that step but the fact that there IS a next sample: below
+                // max_spp - 1 only the variance rule can end the pixel, and it rarely does.  So the jitter is drawn now (the
+                // RNG state is final when a sample ends: shadow rays draw nothing) and the ray joins the list, marked; the
+                // finalise step calls it off if the pixel ends, and a called-off ray is not shaded and not counted.
+                pool_fence();
+                const size_t n_px = B.n_samples;
+                const unsigned int ended = emit.m_f;
+                unsigned int started = 0;
+                for (unsigned int b0 = 0; b0 < ended; b0 += 64u) {
+                    const unsigned int i = b0 + lane;
+                    bool go = false;
+                    unsigned int j = 0;
+                    f3 ray_o = mk3(0, 0, 0), ray_d = mk3(0, 0, 1);
+                    float off_x = 0.0f, off_y = 0.0f;
+                    if (i < ended) {
+                        j = fin[i];
+                        const int job = as_i(Q.jobsum[j].w);
+                        const unsigned int next = (unsigned int)(job & POOL_JOB_SAMPLE_MASK) + 1u;
+                        if (next < P.max_spp && !(job & (POOL_JOB_SPEC_FLYING | POOL_JOB_SPEC_DRAWN))) {
+                            Rng rng;
+                            const ulonglong2 rs = B.rng[j], ra = B.rng_aux[j];
+                            rng.chain = rs.x; rng.prev = rs.y; rng.seed0 = ra.x; rng.k = (u32)ra.y;
+                            u64 * ring = B.ring + j;
+                            off_y = rng_float11<true>(rng, ring, n_px);              // first draw -> .y (main.cpp:238, 247)
+                            off_x = rng_float11<true>(rng, ring, n_px);
+                            B.rng[j] = make_ulonglong2(rng.chain, rng.prev);
+                            B.rng_aux[j] = make_ulonglong2(rng.seed0, (u64)rng.k);
+                            const float jitter = next < P.spp ? 0.5f : 1.0f;        // main.cpp:240 vs :249
+                            const unsigned int pixel = pixel_of_local(P, B.sample_base + j);
+                            const unsigned int x = pixel % P.width, y = pixel / P.width;
+                            const DevCamera cam = A.cam;
+                            ray_o = cam.position;
+                            ray_d = make_camera_dir(cam, (float)x + off_x * jitter, (float)y + off_y * jitter);
+                            go = true;
+                        }
+                    }
+                    const unsigned long long m = __ballot(go);
+                    if (go) {
+                        const unsigned int slot = emit.m_c + __builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m, 0u));
+                        Q.final_rgb[j] = make_float4(off_x, off_y, as_f((int)slot), 0.0f);
+                        Q.jobsum[j].w = as_f(as_i(Q.jobsum[j].w) | POOL_JOB_SPEC_FLYING);
+                    }
+                    emit.closest(go, j, ray_o, ray_d, mk3(1.0f, 1.0f, 1.0f), 0, (unsigned int)POOL_SPEC_PENDING_BIT, false);
+                    started += (unsigned int)__popcll(m);
+                }
+                n_spec = started;
             }
             n_c = emit.m_c;
             n_s = emit.m_s;

@@ -439,6 +439,30 @@ def test_stack_overflow_falls_back_to_the_slow_stack(gpu_renderer_factory, pipel
     assert c_ref.ray_count == c_got.ray_count == int(g["ray_count"])
 
 
+@pytest.mark.parametrize("name", ["terrain64_adaptive_3_12_d4", "cornell_adaptive_4_16", "gallery_adaptive_10_50"])
+def test_adaptive_sampling_slow_paths(gpu_renderer_factory, name, monkeypatch):
+    """Adaptive mode where nearly every ray takes the slow route (stack columns of two entries: closest-hit rays AND shadow
+    rays are parked, so finalise steps are deferred to the EXACT launch and camera rays started ahead are called off), with
+    park lists that start far too short, and with the EXACT kernel doing everything: always the reference's pixels and the
+    reference's sample counts (equal ray counts)."""
+    g = load_golden(name)
+    r = gpu_renderer_factory(str(g["scene"]), int(g["light_mode"]))
+    w, h, lat = int(g["width"]), int(g["height"]), int(g["lattice"])
+    cam, p = camera_and_params(g)
+    ref, c_ref = r.render_lattice(cam, p, w, h, lat)
+    assert c_ref.ray_count == int(g["ray_count"])
+    results = []
+    monkeypatch.setenv("PRT_STACK_CAP", "2")
+    results.append(r.render_lattice(cam, p, w, h, lat))
+    monkeypatch.delenv("PRT_STACK_CAP")
+    monkeypatch.setenv("PRT_POOL_EXACT", "1")
+    results.append(r.render_lattice(cam, p, w, h, lat))
+    monkeypatch.delenv("PRT_POOL_EXACT")
+    for img, c in results:
+        assert c.ray_count == c_ref.ray_count
+        assert np.array_equal(img.view(np.uint32), ref.view(np.uint32))
+
+
 def test_near_ties_park_lists_grow_and_the_exact_kernel_agrees(monkeypatch):
     """Coincident geometry on the pool pipeline: the fast kernel parks every ray whose hit has company within a few ulp and
     the EXACT launch that follows decides them by the reference's visit order (dev_trace.h).  Three ways to the same bits:
