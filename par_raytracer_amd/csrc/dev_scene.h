@@ -116,14 +116,29 @@ struct DevParams {
     int * exact_stack;
     unsigned int exact_stack_stride;
     unsigned int local_base;                    // large calls run in passes of bounded workspace (prt_api.hip render_pixels)
+    // Work order: the first tile_pixels pixels of the set (whole bands of 8 rows; full-width row sets only, width % 8 == 0)
+    // are handed out tile by tile - 64 consecutive work items are an 8 x 8 pixel tile, not a 64 x 1 strip - so that the rays
+    // a wave traces together start from one compact patch of the image (local_of_work below).  0 = off.
+    unsigned int tile_pixels;
     // adaptive sampling (main.cpp:245-258): on when max_spp > spp; k_pool<ADAPT> only
     unsigned int max_spp;
     float variance_threshold;
 };
 
+// Work item (position in the order pixels are handed out, whole call) -> local pixel (position in the call's output).
+PRT_HD unsigned int local_of_work(unsigned int wi, unsigned int width, unsigned int tile_pixels) {
+    if (wi >= tile_pixels) return wi;
+    const unsigned int band_px = 8u * width;
+    const unsigned int b = wi / band_px, q = wi - b * band_px;
+    const unsigned int t = q >> 6, i = q & 63u;
+    return b * band_px + (i >> 3) * width + t * 8u + (i & 7u);
+}
+
+// Work item lp of the current pass -> linear image pixel.
 PRT_HD unsigned int pixel_of_local(const DevParams & P, unsigned int lp) {
-    lp += P.local_base;                         // this pass's first pixel within the call's pixel set
+    lp += P.local_base;                         // this pass's first work item within the call's pixel set
     if (P.pixel_list) return P.pixel_list[lp];
+    lp = local_of_work(lp, P.width, P.tile_pixels);
     if (P.shard_nranks <= 1) return P.first_pixel + lp;
     const unsigned int row = lp / P.width, x = lp - row * P.width;
     const unsigned int blk = row / P.shard_block_rows, r = row - blk * P.shard_block_rows;

@@ -526,9 +526,22 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_pool(const PoolArgs * args, De
                         if (samp >= P.spp) {                                        // second loop: CalculateVariance(scratch, samp), main.cpp:253
                             const f3 mean = sum_prev / (float)samp;                 // the mean's running sum IS the colour sum so far
                             float variance = 0.0f;
-                            for (unsigned int k = 0; k < samp; ++k) {
+                            // the sum runs in sample order, as in the reference; the LOADS do not have to: eight in flight at a
+                            // time (one dependent load per iteration made this loop a chain of memory round trips)
+                            unsigned int k = 0;
+                            for (; k + 8u <= samp; k += 8u) {
+                                float4 v[8];
+#pragma unroll
+                                for (int u = 0; u < 8; ++u) v[u] = Q.scratch[(size_t)(k + (unsigned int)u) * n_px + j];
+#pragma unroll
+                                for (int u = 0; u < 8; ++u) {
+                                    const float d = (fabsf(v[u].x - mean.x) + fabsf(v[u].y - mean.y)) + fabsf(v[u].z - mean.z);   // main.cpp:179-186
+                                    variance += d * d;
+                                }
+                            }
+                            for (; k < samp; ++k) {
                                 const float4 v = Q.scratch[(size_t)k * n_px + j];
-                                const float d = (fabsf(v.x - mean.x) + fabsf(v.y - mean.y)) + fabsf(v.z - mean.z);   // main.cpp:179-186
+                                const float d = (fabsf(v.x - mean.x) + fabsf(v.y - mean.y)) + fabsf(v.z - mean.z);
                                 variance += d * d;
                             }
                             variance /= (float)(samp - 1u);

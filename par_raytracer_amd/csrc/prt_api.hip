@@ -611,22 +611,22 @@ int launch_pool(prt_ctx * ctx, bool count, const DevCamera & cam, DevParams P, u
 }
 
 template <bool FIXED>
-void launch_resolve_t(hipStream_t stream, const void * samples, float4 * out, unsigned int n_px, unsigned int spp) {
+void launch_resolve_t(hipStream_t stream, const void * samples, float4 * out, unsigned int n_px, unsigned int spp, ResolveMap map) {
     const unsigned int grid2 = (unsigned int)(((unsigned long long)n_px * spp + 255ull) / 256ull);
     switch (spp) {
-        case 2: hipLaunchKernelGGL((k_resolve_pow2<2, FIXED>), dim3(grid2), dim3(256), 0, stream, samples, out, n_px); break;
-        case 4: hipLaunchKernelGGL((k_resolve_pow2<4, FIXED>), dim3(grid2), dim3(256), 0, stream, samples, out, n_px); break;
-        case 8: hipLaunchKernelGGL((k_resolve_pow2<8, FIXED>), dim3(grid2), dim3(256), 0, stream, samples, out, n_px); break;
-        case 16: hipLaunchKernelGGL((k_resolve_pow2<16, FIXED>), dim3(grid2), dim3(256), 0, stream, samples, out, n_px); break;
-        case 32: hipLaunchKernelGGL((k_resolve_pow2<32, FIXED>), dim3(grid2), dim3(256), 0, stream, samples, out, n_px); break;
-        case 64: hipLaunchKernelGGL((k_resolve_pow2<64, FIXED>), dim3(grid2), dim3(256), 0, stream, samples, out, n_px); break;
-        default: hipLaunchKernelGGL(k_resolve<FIXED>, dim3((n_px + 255) / 256), dim3(256), 0, stream, samples, out, n_px, spp);
+        case 2: hipLaunchKernelGGL((k_resolve_pow2<2, FIXED>), dim3(grid2), dim3(256), 0, stream, samples, out, n_px, map); break;
+        case 4: hipLaunchKernelGGL((k_resolve_pow2<4, FIXED>), dim3(grid2), dim3(256), 0, stream, samples, out, n_px, map); break;
+        case 8: hipLaunchKernelGGL((k_resolve_pow2<8, FIXED>), dim3(grid2), dim3(256), 0, stream, samples, out, n_px, map); break;
+        case 16: hipLaunchKernelGGL((k_resolve_pow2<16, FIXED>), dim3(grid2), dim3(256), 0, stream, samples, out, n_px, map); break;
+        case 32: hipLaunchKernelGGL((k_resolve_pow2<32, FIXED>), dim3(grid2), dim3(256), 0, stream, samples, out, n_px, map); break;
+        case 64: hipLaunchKernelGGL((k_resolve_pow2<64, FIXED>), dim3(grid2), dim3(256), 0, stream, samples, out, n_px, map); break;
+        default: hipLaunchKernelGGL(k_resolve<FIXED>, dim3((n_px + 255) / 256), dim3(256), 0, stream, samples, out, n_px, spp, map);
     }
 }
 // fixed: the samples are the wavefront / pool pipelines' fixed-point accumulators (dev_scene.h Accum), else float4 colours
-void launch_resolve(hipStream_t stream, const void * samples, bool fixed, float4 * out, unsigned int n_px, unsigned int spp) {
-    if (fixed) launch_resolve_t<true>(stream, samples, out, n_px, spp);
-    else launch_resolve_t<false>(stream, samples, out, n_px, spp);
+void launch_resolve(hipStream_t stream, const void * samples, bool fixed, float4 * out, unsigned int n_px, unsigned int spp, ResolveMap map) {
+    if (fixed) launch_resolve_t<true>(stream, samples, out, n_px, spp, map);
+    else launch_resolve_t<false>(stream, samples, out, n_px, spp, map);
 }
 
 // GPU radix-tree build + host collapse / quantise.  verts: 9 floats per triangle.
@@ -702,6 +702,12 @@ int render_pixels_once(prt_ctx * ctx, const prt_camera * cam_in, const prt_param
     P.shard_rank = px.rank;
     P.shard_nranks = std::max(1u, px.nranks);
     P.pixel_list = px.d_pixel_list;
+    // tiled work order: sets made of full-width rows only (a whole frame or a range that starts at a row, row-block shards)
+    P.tile_pixels = 0;
+    if (!px.d_pixel_list && width % 8u == 0u && !getenv("PRT_NO_TILES")) {
+        const bool rows = px.nranks > 1 ? std::max(1u, px.block_rows) % 8u == 0u : px.first_pixel % width == 0u;
+        if (rows) P.tile_pixels = px.n_pixels / (8u * width) * (8u * width);
+    }
 
     const bool count_visits = (params->pipeline & PRT_FLAG_COUNT_VISITS) != 0;
     // the compact 2-register RNG only covers opaque scenes with <= 15 draws per sample; textured scenes always take the
@@ -903,11 +909,14 @@ int render_pixels_once(prt_ctx * ctx, const prt_camera * cam_in, const prt_param
         if (rc) return rc;
         HIP_TRY(ctx, hipGetLastError());
         if (single_launch) HIP_TRY(ctx, hipEventRecord(ctx->ev[3], stream));
+        // work items of this pass -> their places in the call's output (tiled work order, dev_scene.h local_of_work)
+        ResolveMap rmap;
+        rmap.base = p0; rmap.width = P.width; rmap.tile_pixels = P.tile_pixels;
         if (adaptive)       // k_pool<ADAPT> has already divided by each pixel's own sample count
             hipLaunchKernelGGL(k_resolve<false>, dim3((n_px + 255) / 256), dim3(256), 0, stream,
-                               ctx->adapt_f4.p + ((size_t)P.max_spp + 1u) * n_samples, d_out + p0, n_px, 1u);
+                               ctx->adapt_f4.p + ((size_t)P.max_spp + 1u) * n_samples, d_out, n_px, 1u, rmap);
         else
-            launch_resolve(stream, ctx->sample_rgb.p, pipeline == PRT_PIPELINE_WAVEFRONT || pipeline == PRT_PIPELINE_POOL, d_out + p0, n_px, P.spp);
+            launch_resolve(stream, ctx->sample_rgb.p, pipeline == PRT_PIPELINE_WAVEFRONT || pipeline == PRT_PIPELINE_POOL, d_out, n_px, P.spp, rmap);
         HIP_TRY(ctx, hipGetLastError());
         if (single_launch && (counters || !last_pass)) {
             // the next pass reuses ev[2] / ev[3] (and the workspace is stream ordered anyway): take this pass's time now
