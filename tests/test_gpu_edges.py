@@ -225,3 +225,27 @@ def test_host_render_forgets_a_freed_scene_and_runs_on_two_contexts(monkeypatch)
         hs.close()
     assert not np.array_equal(frames[0], frames[1])
     assert np.array_equal(frames[0], frames[2])
+
+
+def test_reserved_compute_units_do_not_change_the_image(monkeypatch):
+    """PRT_RESERVE_CUS=8 (what bench.py sets for N > 1 with RCCL): the context's streams are created with a CU mask that
+    leaves eight compute units to the collective, and the persistent grids are sized for the rest.  Same pixels, same
+    ray count, on both production pipelines."""
+    from par_raytracer_amd import api
+    w, h = 160, 90
+    s, hs, cam = _setup("terrain_64", w, h)
+    for pipeline in sorted(PIPELINES):
+        p = api.default_params(3, 5, pipeline=PIPELINES[pipeline])
+        frames = []
+        for reserve in ("0", "8"):
+            monkeypatch.setenv("PRT_RESERVE_CUS", reserve)
+            r = api.Renderer(0)
+            try:
+                r.upload(hs)
+                frames.append(r.render(cam, p, w, h))
+            finally:
+                r.close()
+        monkeypatch.delenv("PRT_RESERVE_CUS")
+        (a, ca), (b, cb) = frames
+        assert ca.ray_count == cb.ray_count
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
