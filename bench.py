@@ -470,6 +470,12 @@ def main():
                     lat = int(g["lattice"])
                     img, c = r2.render_lattice(cam2, p2, w2, h2, lat)
                     dd = np.abs(img[:, :, :3] - g["rgb"])
+                    # the timed frames went through the full-size path (C5: 9 passes of whole pixels): its pixels at the lattice
+                    # positions must be the lattice render's, bit for bit, and with them the reference's
+                    full = buf2.reshape(h2, w2, 4)[::lat, ::lat].cpu().numpy()
+                    rec["full_frame_path"] = {"equals_lattice_render_bitwise": bool(np.array_equal(full.view(np.uint32), img.view(np.uint32))),
+                                              "max_abs_diff_rgb_vs_reference": float(np.abs(full[:, :, :3] - g["rgb"]).max()),
+                                              "launches_per_frame": int(cs[0].trace_kernel_launches)}
                     rec["parity_vs_reference_golden"] = {"fixture": fixture, "lattice": lat, "pixels": int(img.shape[0] * img.shape[1]),
                                                          "max_abs_diff_rgb": float(dd.max()), "pixels_over_1e-4": int((dd.max(axis=2) > 1e-4).sum()),
                                                          "ray_count_gpu": int(c.ray_count), "ray_count_reference": int(g["ray_count"]),

@@ -127,7 +127,12 @@ typedef struct prt_params {
      * <= variance_threshold or max_spp is reached (the reference hard-codes 10, 50 and 0.01).  The reference's quirks are
      * kept: the newest sample is added to the sum but the sum is divided by the count without it when the rule stops the
      * loop.  One RNG stream per pixel, seeded with prt_sample_key(seed, pixel, 0), as the loop needs; the fixed mode
-     * (max_spp <= spp) reseeds per sample.  0 / 0.0f = off / the reference's threshold. */
+     * (max_spp <= spp) reseeds per sample.  0 / 0.0f = off / the reference's threshold.
+     * The stopping rule compares a float variance of the pixel's sample colours with the threshold.  The device's sample
+     * colours are reproducible bit for bit (fixed-point accumulation, see "Determinism" in DESIGN.md) but differ from the CPU
+     * reference's in the last bits (device powf, throughput form of the colour polynomial), so a variance that lands within
+     * ~1e-6 of the threshold can stop a pixel one sample earlier or later than the reference would: in adaptive mode ray_count
+     * equals the reference's on every fixture tested, but that is an observation, not a guarantee as it is for fixed spp. */
     uint32_t max_spp;
     float variance_threshold;
 } prt_params;

@@ -37,7 +37,7 @@ struct TmpNode {
     uint32_t depth;
 };
 
-enum { BINS = 16, MAX_FORCED_DEPTH = 56 };
+enum { MAX_BINS = 64, MAX_FORCED_DEPTH = 56 };
 
 struct Builder {
     std::vector<Prim> prims;
@@ -47,6 +47,8 @@ struct Builder {
     std::atomic<int> threads_free;
     uint32_t leaf_max;
     float trav_cost = 1.0f;     // SAH: cost of one traversal step relative to one triangle test
+    int BINS = 16;              // SAH bins per axis (PRT_SAH_BINS, <= MAX_BINS)
+    uint32_t sweep_max = 0;     // nodes of at most this many triangles try every split position of every axis (PRT_SAH_SWEEP)
 
     uint32_t alloc() { return next_node.fetch_add(1); }
 
@@ -81,8 +83,8 @@ struct Builder {
                 float cmin = cbounds.lo[axis], cmax = cbounds.hi[axis];
                 if (!(cmax > cmin)) continue;
                 float scale = (float)BINS / (cmax - cmin);
-                Box bin_box[BINS];
-                uint32_t bin_n[BINS];
+                Box bin_box[MAX_BINS];
+                uint32_t bin_n[MAX_BINS];
                 for (int b = 0; b < BINS; ++b) { bin_box[b].reset(); bin_n[b] = 0; }
                 for (uint32_t i = first; i < first + count; ++i) {
                     int b = (int)((prims[i].c[axis] - cmin) * scale);
@@ -90,8 +92,8 @@ struct Builder {
                     bin_box[b].grow(prims[i].box);
                     bin_n[b]++;
                 }
-                float right_area[BINS];
-                uint32_t right_n[BINS];
+                float right_area[MAX_BINS];
+                uint32_t right_n[MAX_BINS];
                 Box acc;
                 acc.reset();
                 uint32_t cnt = 0;
@@ -113,6 +115,29 @@ struct Builder {
             }
         }
 
+        // --- small nodes: every split position of every axis (sorted sweep) instead of the bins
+        int sweep_axis = -1;
+        uint32_t sweep_left = 0;
+        if (count <= sweep_max && depth < MAX_FORCED_DEPTH && count >= 2) {
+            std::vector<float> right_area(count);
+            for (int axis = 0; axis < 3; ++axis) {
+                std::sort(prims.begin() + first, prims.begin() + first + count,
+                          [axis](const Prim & a, const Prim & b) { return a.c[axis] < b.c[axis] || (a.c[axis] == b.c[axis] && a.id < b.id); });
+                Box acc;
+                acc.reset();
+                for (uint32_t i = count - 1; i > 0; --i) { acc.grow(prims[first + i].box); right_area[i] = acc.half_area(); }
+                acc.reset();
+                for (uint32_t i = 0; i + 1 < count; ++i) {
+                    acc.grow(prims[first + i].box);
+                    float cost = acc.half_area() * (float)(i + 1) + right_area[i + 1] * (float)(count - i - 1);
+                    if (cost < best_cost) { best_cost = cost; sweep_axis = axis; sweep_left = i + 1; best_axis = axis; }
+                }
+            }
+            if (sweep_axis >= 0 && sweep_axis != 2)
+                std::sort(prims.begin() + first, prims.begin() + first + count,
+                          [sweep_axis](const Prim & a, const Prim & b) { return a.c[sweep_axis] < b.c[sweep_axis] || (a.c[sweep_axis] == b.c[sweep_axis] && a.id < b.id); });
+        }
+
         // leaf if allowed and cheaper than splitting (traversal step cost 1, triangle test cost 1)
         if (count <= leaf_max) {
             float split_cost = (best_axis >= 0 && parent_area > 0.0f) ? trav_cost + best_cost / parent_area : FLT_MAX;
@@ -120,7 +145,9 @@ struct Builder {
         }
 
         uint32_t mid;
-        if (best_axis >= 0) {
+        if (sweep_axis >= 0) {
+            mid = first + sweep_left;                  // the range is sorted along the winning axis
+        } else if (best_axis >= 0) {
             float cmin = cbounds.lo[best_axis];
             float scale = (float)BINS / (cbounds.hi[best_axis] - cmin);
             Prim * b = &prims[first];
@@ -466,6 +493,8 @@ void build_bvh4q(const float * verts, uint32_t n_tris, uint32_t leaf_max, uint32
     Builder b;
     b.leaf_max = leaf_max;
     b.trav_cost = trav_cost;
+    if (const char * e = getenv("PRT_SAH_BINS")) b.BINS = std::max(4, std::min((int)MAX_BINS, atoi(e)));
+    if (const char * e = getenv("PRT_SAH_SWEEP")) b.sweep_max = (uint32_t)std::max(0, atoi(e));
     b.prims.resize(n_tris);
     Box scene;
     scene.reset();

@@ -249,3 +249,24 @@ def test_reserved_compute_units_do_not_change_the_image(monkeypatch):
         (a, ca), (b, cb) = frames
         assert ca.ray_count == cb.ray_count
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+def test_render_stats_of_a_counting_render(gpu_renderer_factory):
+    """prt_get_render_stats (include/prt.h): the diagnostics bench.py's roofline block is built from.  Lane-level counts equal
+    the counters of the call; wave-level counts bound them (a wave step serves 1..64 lanes); nothing was parked on a scene
+    without coincident geometry."""
+    from par_raytracer_amd import api, capi
+    w, h = 160, 90
+    _, hs, cam = _setup("terrain_64", w, h)
+    r = gpu_renderer_factory("terrain_64", 0)
+    for name in sorted(PIPELINES):
+        p = api.default_params(4, 11, pipeline=PIPELINES[name] | capi.FLAG_COUNT_VISITS)
+        img, c = r.render(cam, p, w, h)
+        st = r.render_stats()
+        assert st.node_visits == c.node_visits > 0 and st.tri_tests == c.tri_tests > 0
+        assert st.wave_node_steps * 64 >= st.node_visits >= st.wave_node_steps > 0
+        assert st.wave_tri_steps * 64 >= st.tri_tests >= st.wave_tri_steps > 0
+        assert 0 < st.deepest_stack <= st.stack_bound and st.stack_lds_entries > 0
+        if name == "pool":
+            assert st.phase_cycles[3] >= st.phase_cycles[0] + st.phase_cycles[1] + st.phase_cycles[2] > 0
+            assert st.parked_rays <= 4 and st.parked_shadow_rays == 0
