@@ -8,7 +8,7 @@ import oracle_py as orc
 from par_raytracer_amd import api, scenes
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
-names = ["cornell_box", "sphere_plane", "icosphere_l3", "terrain_64", "many_materials", "textured_gallery", "terrain_192", "jpeg_gallery", "png_gallery", "bmp_gallery", "tga_gallery"]
+names = ["coincident", "cornell_box", "sphere_plane", "icosphere_l3", "terrain_64", "many_materials", "textured_gallery", "terrain_192", "jpeg_gallery", "png_gallery", "bmp_gallery", "tga_gallery"]
 dirs, hosts, rends = {}, {}, {}
 bad = 0
 t0 = time.time()
