@@ -175,6 +175,9 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_pool(const PoolArgs * args, De
     __shared__ DevMaterial s_mats[LDS_MATS];
     __shared__ DevLight s_lights[LDS_LIGHTS];
     __shared__ unsigned long long s_red[2];
+#ifdef PRT_POOL_PREFETCH
+    __shared__ float4 s_pref[BLOCK / 64][2][64];     // experiment: the next 64 list entries of each wave, filled by LDS-direct loads
+#endif
     {
         const PoolArgs A0 = pool_args(args);
         const DevScene & sc = A0.sc;
@@ -344,26 +347,66 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_pool(const PoolArgs * args, De
             float4 payload = make_float4(0, 0, 0, 0);
             int sample = 0;
             unsigned int next = 0;                                         // wave-uniform: rays handed out so far
+#ifdef PRT_POOL_PREFETCH
+            // Experiment (profiles/r02_experiments.txt): the next 64 list entries travel to LDS by LDS-direct loads
+            // (global_load_lds_dwordx4: no registers, nobody waits) while the wave traverses; a refill then reads LDS.
+            float4 * const pfA = &s_pref[threadIdx.x >> 6][0][0];
+            float4 * const pfB = &s_pref[threadIdx.x >> 6][1][0];
+            unsigned int win_base = 0, win_cnt = 0;                        // wave-uniform: entries [win_base, win_base + win_cnt) are in the window
+            auto prefetch = [&](unsigned int base) {
+                const unsigned int cnt = total - base < 64u ? total - base : 64u;
+                const unsigned int idx = base + lane;
+                if (lane < cnt) {
+                    const float4 * a = idx < n_c ? co + idx : sq_o + (idx - n_c);
+                    const float4 * b = idx < n_c ? cd + idx : sq_c + (idx - n_c);
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)a, (__attribute__((address_space(3))) void *)pfA, 16, 0, 0);
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)b, (__attribute__((address_space(3))) void *)pfB, 16, 0, 0);
+                }
+                win_base = base;
+                win_cnt = cnt;
+            };
+            if (total) prefetch(0u);
+#endif
             for (;;) {
                 const unsigned long long idle = __ballot(ray < 0);
                 if (idle != 0ull && next < total) {
                     if (COUNT && lane == 0) st.wrefills++;
+#ifdef PRT_POOL_PREFETCH
+                    const unsigned int avail = win_base + win_cnt - next;                      // what is left of the window
+#else
                     const unsigned int avail = total - next;
+#endif
                     const unsigned int prefix = __builtin_amdgcn_mbcnt_hi((unsigned int)(idle >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)idle, 0u));
                     const unsigned int n_idle = (unsigned int)__popcll(idle);
                     const unsigned int take = n_idle < avail ? n_idle : avail;
+#ifdef PRT_POOL_PREFETCH
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                            // the window has landed
+#endif
                     if (ray < 0 && prefix < take) {
                         const unsigned int idx = next + prefix;
                         float4 ro, rd;
                         int kind;
+#ifdef PRT_POOL_PREFETCH
+                        const float4 e0 = pfA[idx - win_base], e1 = pfB[idx - win_base];
+#endif
                         if (idx < n_c) {
+#ifdef PRT_POOL_PREFETCH
+                            ro = e0;
+                            rd = e1;
+#else
                             ro = co[idx];
                             rd = cd[idx];
+#endif
                             kind = WF_KIND_CLOSEST;
                         } else {
                             const unsigned int j = idx - n_c;
+#ifdef PRT_POOL_PREFETCH
+                            ro = e0;
+                            payload = e1;
+#else
                             ro = sq_o[j];
                             payload = sq_c[j];
+#endif
                             if (payload.w < 0.0f) {          // directional light: the direction is a per-light constant
                                 const DevLight & L = lights[(unsigned int)(-payload.w) - 1u];
                                 const f3 lv = mk3(L.facing[0], L.facing[1], L.facing[2]) * -1.0f;   // raytracer.cpp:240
@@ -381,6 +424,9 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_pool(const PoolArgs * args, De
                         ray = (int)idx;
                     }
                     next += take;
+#ifdef PRT_POOL_PREFETCH
+                    if (next == win_base + win_cnt && next < total) prefetch(next);             // the window is used up: fetch the next one
+#endif
                 }
                 if (__ballot(ray >= 0) == 0ull) break;
 
