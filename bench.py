@@ -338,8 +338,12 @@ def main():
     fused = used != 2
     # k_trace moves rays, nodes and triangle records; shading records and the framebuffer belong to k_shade / k_resolve.
     # The single-launch pipelines do all of it in the one kernel that is timed.
+    # Shadow rays whose radiance-if-unoccluded is exactly zero are counted (ray_count is the reference's) but not traced: they
+    # have no ray record, so they are not priced either
+    rays_elided = int(st.elided_shadow_rays)
+    rays_traced = int(cc.ray_count) - rays_elided
     def algorithmic_bytes(b_tri, b_shade):
-        n = cc.ray_count * B_RAY + cc.node_visits * B_NODE + cc.tri_tests * b_tri
+        n = rays_traced * B_RAY + cc.node_visits * B_NODE + cc.tri_tests * b_tri
         if fused:
             n += cc.shaded_hits * b_shade + n_px_local * B_PIXEL
         return n
@@ -375,7 +379,8 @@ def main():
                 "traffic_per_frame": traffic, "algorithmic_bytes_per_launch": int(alg_bytes / launches),
                 "launch_ms_mean": round(kernel_ms / launches, 4),
                 "algorithmic_bytes_per_frame": int(alg_bytes), "kernel_ms_per_frame": round(kernel_ms, 4),
-                "per_frame": {"rays": int(cc.ray_count), "node_visits": int(cc.node_visits), "tri_tests": int(cc.tri_tests),
+                "per_frame": {"rays": int(cc.ray_count), "rays_traced": rays_traced, "rays_counted_not_traced": rays_elided,
+                               "node_visits": int(cc.node_visits), "tri_tests": int(cc.tri_tests),
                                "shaded_hits": int(cc.shaded_hits), "pixels": int(n_px_local)},
                 "bytes_per_unit": {"ray": B_RAY, "node": B_NODE, "tri_test": B_TRI, "shaded_hit": B_SHADE, "pixel": B_PIXEL},
                 "with_this_builds_record_sizes": {"bytes_per_unit": {"tri_test": B_TRI_BUILD, "shaded_hit": B_SHADE_BUILD},
@@ -536,6 +541,12 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": descr, "seed": SEED, "triangles": int(info.triangle_count), "width": width, "height": height,
                        "spp": spp, "bounce_depth": depth, "rays_per_frame": int(rays_total / args.steps),
+                       # A ray is one TraceRay call of the reference (raytracer.cpp:161) and ray_count equals the reference's.  Of
+                       # those, the shadow rays whose radiance-if-unoccluded is exactly zero (surface facing away from the light, no
+                       # highlight) cannot change the image and are counted without being traced; PRT_TRACE_DEAD_SHADOW_RAYS=1
+                       # traces them too.  `value_traced_rays_only` is the rate without them.
+                       "rays_counted_not_traced_per_frame": rays_elided if world == 1 else None,
+                       "value_traced_rays_only": round(value * rays_traced / max(1, int(cc.ray_count)), 3) if world == 1 else None,
                        "parallelism": "pixel rows sharded in %d-row blocks over %d GPU(s)%s" % (
                            SHARD_BLOCK_ROWS, world, (", RCCL gather to rank 0" if args.backend == "nccl" else ", gloo gather (rehearsal)") if world > 1 else ""),
                        "pipeline": pipeline_name, "frames_in_flight": F},

@@ -232,6 +232,9 @@ typedef struct prt_render_stats {
     uint64_t deepest_stack;                    /* entries of a traversal stack column ever in use */
     uint64_t phase_cycles[5];                  /* pool pipeline: top-up, trace, shade, whole main loop, adaptive finalise step */
     uint64_t parked_rays, parked_shadow_rays;  /* pool pipeline: most rays any pass handed to its slow launches */
+    uint64_t elided_shadow_rays;               /* shadow rays that are in ray_count but were not traced: their radiance-if-unoccluded
+                                                * was exactly zero, so no outcome could change the image (PRT_TRACE_DEAD_SHADOW_RAYS=1
+                                                * traces them all the same) */
     uint32_t stack_lds_entries, stack_bound;   /* LDS stack column height used, worst-case bound of the tree */
 } prt_render_stats;
 int prt_get_render_stats(const prt_ctx * ctx, prt_render_stats * stats);

@@ -120,6 +120,9 @@ struct DevParams {
     // are handed out tile by tile - 64 consecutive work items are an 8 x 8 pixel tile, not a 64 x 1 strip - so that the rays
     // a wave traces together start from one compact patch of the image (local_of_work below).  0 = off.
     unsigned int tile_pixels;
+    // 1: a shadow ray whose radiance-if-unoccluded is exactly zero is counted, not traced (kernels_wave.h shade_entry);
+    // 0 (PRT_TRACE_DEAD_SHADOW_RAYS): traced like every other one
+    unsigned int elide_dead_shadow_rays;
     // adaptive sampling (main.cpp:245-258): on when max_spp > spp; k_pool<ADAPT> only
     unsigned int max_spp;
     float variance_threshold;
@@ -159,6 +162,7 @@ struct DevCounters {          // device-side accumulators (atomics, one add per 
     // pool pipeline: the most entries any pass wanted to put on its park lists ([0] closest-hit rays + finalise steps, [1] shadow
     // rays); above the lists' capacities the frame is incomplete and render_pixels renders it again with longer lists
     unsigned long long park_peak[2];
+    unsigned long long elided_shadow_rays;     // shadow rays counted (they are in ray_count) but not traced: they could not change the image
 };
 
 // Per-sample radiance accumulator of the wavefront and pool pipelines: 2^-32 fixed point in 64-bit integers.  A sample's

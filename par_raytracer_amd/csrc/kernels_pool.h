@@ -61,6 +61,8 @@ struct PoolEmit {
     float4 * so, * sc, * sd;     // next shadow list
     unsigned int * fin;          // ADAPT: pixels to finalise after the next trace phase
     unsigned int m_c, m_s, m_f;  // wave-uniform fill counts
+    unsigned int m_elided;       // wave-uniform: shadow rays counted, not traced (their radiance-if-unoccluded is zero)
+    PRT_D void elided(bool dead) { m_elided += (unsigned int)__popcll(__ballot(dead)); }
     PRT_D void shadow(bool want, unsigned int s, f3 o, f3 d, f3 contrib, float w, int kind) {
         const unsigned long long mask = __ballot(want);
         const unsigned int prefix = __builtin_amdgcn_mbcnt_hi((unsigned int)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)mask, 0u));
@@ -212,6 +214,7 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_pool(const PoolArgs * args, De
     bool fetch_done = false;                   // wave-uniform: the sample counter ran past n_samples
     unsigned long long rays = 0ull;            // wave-uniform
     unsigned int shaded_w = 0;                 // wave-uniform
+    unsigned int elided_w = 0;                 // wave-uniform: shadow rays counted, not traced
     TraceStats st;
     st.nodes = st.tris = st.wnodes = st.wleaves = st.wtris = st.wrefills = st.max_sp = st.culled = 0;
 
@@ -511,7 +514,7 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_pool(const PoolArgs * args, De
             emit.ct = emit.cd + cap;
             emit.so = sq_o; emit.sc = sq_c; emit.sd = sq_d;
             emit.fin = fin;
-            emit.m_c = 0; emit.m_s = 0; emit.m_f = 0;
+            emit.m_c = 0; emit.m_s = 0; emit.m_f = 0; emit.m_elided = 0;
             if (ADAPT) {
                 // ---- finalise: pixels whose sample ended one round ago; its last shadow rays have landed by now.
                 // RenderPixel's loops (main.cpp:236-258) one step at a time: store the sample, apply the stopping rule,
@@ -718,6 +721,8 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_pool(const PoolArgs * args, De
                 }
                 n_spec = started;
             }
+            rays += emit.m_elided;                                             // counted as the reference counts them (raytracer.cpp:161)
+            elided_w += emit.m_elided;
             n_c = emit.m_c;
             n_s = emit.m_s;
             n_f = emit.m_f;
@@ -734,6 +739,7 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_pool(const PoolArgs * args, De
     if (lane == 0) {
         atomicAdd(&s_red[0], rays);
         atomicAdd(&s_red[1], (unsigned long long)shaded_w);
+        if (elided_w) atomicAdd(&ctr->elided_shadow_rays, (unsigned long long)elided_w);
     }
     __syncthreads();
     if (threadIdx.x == 0) {

@@ -48,7 +48,7 @@ struct WaveBuffers {
                                  //               it (raytracer.cpp:393-396); w < 0: directional light number -w - 1, whose
                                  //               direction comes from the light table - no per-ray copy of a constant
     float4 * sq_d;               //               (d.xyz, -)   written and read for point lights only
-    unsigned int * counts;       // [0] next closest count, [1] next shadow count, [2] trace fetch head, [3] rays handed to k_trace_exact
+    unsigned int * counts;       // [0] next closest count, [1] next shadow count, [2] trace fetch head, [3] rays handed to k_trace_exact, [4] shadow rays of this round's hits that were counted, not traced
     unsigned int * overflow;     // ray indices whose hit has a near tie or whose stack overflowed (traced again, exactly, by k_trace_exact)
     unsigned int n_samples;      // samples of THIS chain (all per-sample arrays are indexed 0 .. n_samples)
     unsigned int sample_base;    // global id of its first sample (pixel / key derivation only)
@@ -554,7 +554,12 @@ PRT_D void shade_entry_on(const DevScene & sc, const DevParams & P, const WaveBu
             so = f.hit_p;
             sd = light_vector;
         }
-        emit.shadow(want_shadow, s, so, sd, contrib, kind == WF_KIND_SHADOW_DIST ? dist_sq : -(float)(li + 1u), kind);
+        // A shadow ray whose radiance-if-unoccluded is exactly zero - the surface faces away from the light and the highlight
+        // term is zero too - cannot change the image whatever it hits.  The reference casts it all the same (raytracer.cpp:385,
+        // and counts it, :161); here it is COUNTED (ray_count stays the reference's) and not traced.
+        const bool dead = want_shadow && P.elide_dead_shadow_rays && contrib.x == 0.0f && contrib.y == 0.0f && contrib.z == 0.0f;
+        emit.elided(dead);
+        emit.shadow(want_shadow && !dead, s, so, sd, contrib, kind == WF_KIND_SHADOW_DIST ? dist_sq : -(float)(li + 1u), kind);
     }
 
     // ---- step 2: walk the bounce tree in depth-first order until the next ray or the end of the sample ----
@@ -668,6 +673,8 @@ struct QueueEmit {
     const WaveBuffers & B;
     int nxt;
     unsigned int * s_cnt;
+    unsigned int * n_elided;          // this thread's count of shadow rays that were counted, not traced
+    PRT_D void elided(bool dead) const { if (dead) ++*n_elided; }
     PRT_D void shadow(bool want, unsigned int s, f3 o, f3 d, f3 contrib, float w, int kind) const {
         const unsigned int slot = block_append<BLOCK / 64>(B.counts + 1, want, s_cnt);
         if (want) {
@@ -734,7 +741,8 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, DevParams P, WaveB
         T = mk3(rt.x, rt.y, rt.z);
         hit.t = h.x; hit.v = h.y; hit.w = h.z; hit.tri = as_i(h.w);
     }
-    QueueEmit<BLOCK> emit = { B, cur ^ 1, s_cnt };
+    unsigned int n_elided = 0;
+    QueueEmit<BLOCK> emit = { B, cur ^ 1, s_cnt, &n_elided };
     unsigned int shaded = 0;
     shade_entry<RING, TEX>(sc, P, B, tb, live, s, level, pending, ray_o, ray_d, T, hit, emit, shaded);
 
@@ -747,6 +755,19 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, DevParams P, WaveB
             unsigned int total = 0;
             for (int w = 0; w < BLOCK / 64; ++w) total += s_cnt[w];
             if (total) atomicAdd(&ctr->shaded_hits, (unsigned long long)total);
+        }
+    }
+    // shadow rays counted but not traced: one atomic per workgroup on the round's counter (the host adds it to the ray count)
+    {
+        unsigned int n = n_elided;
+        for (int off = 32; off > 0; off >>= 1) n += (unsigned int)__shfl_down((int)n, off);
+        __syncthreads();
+        if (lane_id() == 0) s_cnt[threadIdx.x >> 6] = n;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned int total = 0;
+            for (int w = 0; w < BLOCK / 64; ++w) total += s_cnt[w];
+            if (total) { atomicAdd(B.counts + 4, total); atomicAdd(&ctr->elided_shadow_rays, (unsigned long long)total); }
         }
     }
 }

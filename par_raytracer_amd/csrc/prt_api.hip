@@ -319,7 +319,7 @@ int chain_issue_round(prt_ctx * ctx, Chain & c, const WaveTuning & t) {
     hipStream_t stream = c.ws->stream;
     const WaveBuffers & B = c.B;
     c.rays += (unsigned long long)c.n_closest + c.n_shadow;
-    HIP_TRY(ctx, hipMemsetAsync(B.counts, 0, 16, stream));
+    HIP_TRY(ctx, hipMemsetAsync(B.counts, 0, 32, stream));
     const unsigned int total = c.n_closest + c.n_shadow;
     const unsigned int max_blocks = (unsigned int)t.per_cu * (unsigned int)ctx->cu_count;
     const unsigned int grid = std::max(1u, std::min(max_blocks, (total + BLOCK - 1) / BLOCK));
@@ -360,7 +360,7 @@ int chain_issue_round(prt_ctx * ctx, Chain & c, const WaveTuning & t) {
         }
         HIP_TRY(ctx, hipGetLastError());
     }
-    HIP_TRY(ctx, hipMemcpyAsync(c.ws->host_counts, B.counts, 8, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(ctx, hipMemcpyAsync(c.ws->host_counts, B.counts, 32, hipMemcpyDeviceToHost, stream));
     HIP_TRY(ctx, hipEventRecord(c.ws->ev_done, stream));
     return 0;
 }
@@ -375,6 +375,7 @@ int chain_finish_round(prt_ctx * ctx, Chain & c) {
     const unsigned int n_lights = std::max(1u, ctx->scene.light_count);
     const unsigned int next_closest = c.n_closest ? c.ws->host_counts[0] : 0;
     const unsigned int next_shadow = c.n_closest ? c.ws->host_counts[1] : 0;
+    if (c.n_closest) c.rays += c.ws->host_counts[4];          // shadow rays of this round's hits that were counted, not traced
     if (next_closest > c.B.n_samples || next_shadow > c.B.n_samples * n_lights) { ctx->error = "prt_render: wavefront queue overflow"; return -6; }
     c.n_closest = next_closest;
     c.n_shadow = next_shadow;
@@ -702,6 +703,7 @@ int render_pixels_once(prt_ctx * ctx, const prt_camera * cam_in, const prt_param
     P.shard_rank = px.rank;
     P.shard_nranks = std::max(1u, px.nranks);
     P.pixel_list = px.d_pixel_list;
+    P.elide_dead_shadow_rays = getenv("PRT_TRACE_DEAD_SHADOW_RAYS") ? 0u : 1u;
     // tiled work order: sets made of full-width rows only (a whole frame or a range that starts at a row, row-block shards)
     P.tile_pixels = 0;
     if (!px.d_pixel_list && width % 8u == 0u && !getenv("PRT_NO_TILES")) {
@@ -955,6 +957,7 @@ int render_pixels_once(prt_ctx * ctx, const prt_camera * cam_in, const prt_param
             rs.wave_refills = h.wave_refills; rs.deepest_stack = h.max_sp;
             for (int k = 0; k < 5; ++k) rs.phase_cycles[k] = h.phase_cycles[k];
             rs.parked_rays = h.park_peak[0]; rs.parked_shadow_rays = h.park_peak[1];
+            rs.elided_shadow_rays = h.elided_shadow_rays;
             rs.stack_lds_entries = stack_entries; rs.stack_bound = ctx->stack_bound;
         }
         float ms = 0.0f;
