@@ -151,7 +151,9 @@ enum { PRT_PIPELINE_DEFAULT = 0, PRT_PIPELINE_MEGAKERNEL = 1, PRT_PIPELINE_WAVEF
 enum { PRT_FLAG_COUNT_VISITS = 0x100, PRT_FLAG_TRYOUT = 0x200 };
 
 /* DebugCounters (globals.h:3-7) re-cast for a per-triangle BVH.  ray_count has the reference's
- * meaning (one per TraceRay call, raytracer.cpp:161) and must equal the CPU value exactly. */
+ * meaning (one per TraceRay call, raytracer.cpp:161) and must equal the CPU value exactly.  It includes the shadow rays
+ * the device does not trace because the radiance that would ride with them is exactly zero (no outcome could change the
+ * image; prt_render_stats.elided_shadow_rays says how many): the reference casts and counts those too. */
 typedef struct prt_counters {
     uint64_t ray_count;
     uint64_t node_visits;          /* BVH nodes fetched (replaces sphere_check_count) */
