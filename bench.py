@@ -394,7 +394,7 @@ def main():
                 # (every ray record once, the resident scene once, the framebuffer once)
                 "hbm_measured": ({"GBps": round(traffic / (kernel_ms * 1e-3) / 1e9, 1),
                                   "frac_of_peak": round(traffic / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)} if traffic and kernel_ms > 0 else None),
-                "compulsory_bytes_per_frame": int(cc.ray_count * B_RAY + info.device_bytes + n_px_local * B_PIXEL)}
+                "compulsory_bytes_per_frame": int(rays_traced * B_RAY + info.device_bytes + n_px_local * B_PIXEL)}
 
     # ---- CPU baseline + parity on a sparse lattice of the same frame (rank 0, N = 1 only)
     cpu_baseline = None

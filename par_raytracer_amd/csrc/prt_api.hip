@@ -893,7 +893,6 @@ int render_pixels_once(prt_ctx * ctx, const prt_camera * cam_in, const prt_param
             // adaptive (41; no gain measured) renders: 4 waves per SIMD.  6 waves (80 VGPRs) spill 90-230 dwords: 29 ms.
             if (adaptive)
                 rc = ctx->textured ? launch_pool<256, 4, false, true, true, true>(ctx, count_visits, cam, P, n_samples, stack_entries)
-                   : getenv("PRT_ADAPT_WAVES5") ? launch_pool<256, 5, false, true, false, true>(ctx, count_visits, cam, P, n_samples, stack_entries)
                                    : launch_pool<256, 4, false, true, false, true>(ctx, count_visits, cam, P, n_samples, stack_entries);
             else
                 rc = ctx->textured ? launch_pool<256, 4, false, true, true, false>(ctx, count_visits, cam, P, n_samples, stack_entries)
