@@ -232,6 +232,17 @@ PRT_D void trav_node_step(const DevScene & sc, TravRay & r, const STK & stk, Tra
     const uint4 * np = reinterpret_cast<const uint4 *>(sc.nodes) + 4 * (size_t)r.node;
     const uint4 w0 = np[0], w1 = np[1], w2 = np[2], w3 = np[3];
     if (COUNT) { st.nodes++; if (first_active_lane()) st.wnodes++; if ((unsigned int)r.sp > st.max_sp) st.max_sp = (unsigned int)r.sp; }
+#ifdef PRT_PROBE_EXTRA_LOAD
+    // sensitivity probe (tools/ab_probe.sh): one more divergent vector-memory instruction per node step
+    { unsigned int e; asm volatile("global_load_dword %0, %1, off offset:32\n\ts_waitcnt vmcnt(0)" : "=v"(e) : "v"(np) : "memory"); }
+#endif
+#ifdef PRT_PROBE_EXTRA_VALU
+    // sensitivity probe: PRT_PROBE_EXTRA_VALU more vector ALU instructions per node step, on a value the step needs
+    { unsigned int x = w0.w;
+#pragma unroll
+      for (int i = 0; i < PRT_PROBE_EXTRA_VALU; ++i) asm volatile("v_mov_b32 %0, %0" : "+v"(x));
+      const_cast<uint4 &>(w0).w = x; }
+#endif
     const float kx = __uint_as_float(w0.w) * r.ix;
     const float ky = __uint_as_float(w3.z) * r.iy;
     const float kz = __uint_as_float(w3.w) * r.iz;
