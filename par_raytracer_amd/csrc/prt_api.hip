@@ -881,16 +881,12 @@ int render_pixels_once(prt_ctx * ctx, const prt_camera * cam_in, const prt_param
             else rc = launch_persistent<17, true>(ctx, count_visits, lds, cam, P, n_samples, keep_min, node_min, blocks_cap);
             launches += 1;
         } else if (pipeline == PRT_PIPELINE_POOL) {
-            // 256-thread blocks, 4 waves per SIMD (128 VGPRs), 4 blocks per CU; the Hammersley direction table stays in
-            // global memory (staging it in LDS measured 17.04 vs 17.15 ms: nothing).  Small blocks retire - and let the
-            // blocks of the next frame's kernel in - at a finer grain: with two frames in flight a 1/8-frame shard takes
-            // 2.24 ms per frame instead of 2.59 with 512-thread blocks.  Measured alternatives at other occupancies: 5 waves
-            // per SIMD (96 VGPRs, 93 dwords spilled) 29-31 ms, 6 waves (80 VGPRs, 154 spilled) 29.5 ms on a C4 frame.
             // 256-thread blocks, the Hammersley direction table in global memory (staging it in LDS measured 17.04 vs 17.15 ms:
             // nothing).  Small blocks retire - and let the blocks of the next frame's kernel in - at a finer grain: with two
             // frames in flight a 1/8-frame shard takes 2.24 ms per frame instead of 2.59 with 512-thread blocks.
-            // Untextured fixed-spp renders: 5 waves per SIMD (96 VGPRs, 29 dwords spilled).  Textured (64 spilled at 96) and
-            // adaptive (41; no gain measured) renders: 4 waves per SIMD.  6 waves (80 VGPRs) spill 90-230 dwords: 29 ms.
+            // Untextured fixed-spp renders: 5 waves per SIMD (96 VGPRs, 23 dwords spilled).  Textured (64 spilled at 96) and
+            // adaptive (68 spilled at 96, no gain measured: profiles/r02_experiments.txt item 11) renders: 4 waves per SIMD.
+            // 6 waves (80 VGPRs) spill 90-230 dwords: 29 ms.
             if (adaptive)
                 rc = ctx->textured ? launch_pool<256, 4, false, true, true, true>(ctx, count_visits, cam, P, n_samples, stack_entries)
                                    : launch_pool<256, 4, false, true, false, true>(ctx, count_visits, cam, P, n_samples, stack_entries);
