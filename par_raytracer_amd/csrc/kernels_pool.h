@@ -49,7 +49,7 @@ struct PoolBuffers {
     unsigned int adopt;          // EXACT kernels: 1 = top up from the park list, not from the sample counter
     // adaptive mode (k_pool<ADAPT>): the unit in the pool is a PIXEL that runs its samples one after the other
     unsigned int * fin;          // [waves][cap]         pixels whose current sample has no ray left; finalised after the next trace phase
-    float4 * scratch;            // [max_spp][n_pixels]  every sample's colour (RenderPixel's scratch_buffer, main.cpp:232)
+    float4 * scratch;            // [n_pixels][max_spp]  every sample's colour (RenderPixel's scratch_buffer, main.cpp:232)
     float4 * jobsum;             // [n_pixels]           (running colour sum .xyz, samples finished so far as int bits)
     float4 * final_rgb;          // [n_pixels]           the pixel's colour when it is done
 };
@@ -307,13 +307,13 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_pool(const PoolArgs * args, De
                     const unsigned int gsid = B.sample_base + sid;
                     SampleState S;
                     Frame fr;
-                    u64 * ring = RING && RINGMEM ? B.ring + sid : nullptr;
+                    u64 * ring = RING && RINGMEM ? B.ring + (size_t)sid * B.ring_step : nullptr;
                     if (ADAPT) {
                         // the unit is the pixel: one RNG stream, key of sample 0 (include/prt.h prt_params::max_spp)
-                        sample_begin<RING>(cam, P, pixel_of_local(P, gsid), 0u, S, fr, ring, B.n_samples);
+                        sample_begin<RING>(cam, P, pixel_of_local(P, gsid), 0u, S, fr, ring, B.ring_stride);
                         Q.jobsum[sid] = make_float4(0.0f, 0.0f, 0.0f, as_f(0));
                     } else {
-                        sample_begin<RING>(cam, P, pixel_of_local(P, gsid / P.spp), gsid % P.spp, S, fr, ring, B.n_samples);
+                        sample_begin<RING>(cam, P, pixel_of_local(P, gsid / P.spp), gsid % P.spp, S, fr, ring, B.ring_stride);
                     }
                     B.rng[sid] = make_ulonglong2(S.rng.chain, S.rng.prev);
                     if (RING) B.rng_aux[sid] = make_ulonglong2(S.rng.seed0, (u64)S.rng.k);
@@ -520,6 +520,10 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_pool(const PoolArgs * args, De
                 // RenderPixel's loops (main.cpp:236-258) one step at a time: store the sample, apply the stopping rule,
                 // start the next sample on the same RNG stream.
                 const size_t n_px = B.n_samples;
+                // the pixel's sample colours, pixel-major: the variance loop of a lane walks 16-byte neighbours (four samples per
+                // 64-byte line) instead of one line per sample (12-byte entries measured no better: profiles/r02_experiments.txt)
+                float4 * const scratch = Q.scratch;
+#define POOL_SCRATCH_AT(k, j) ((size_t)(j) * P.max_spp + (k))
                 const unsigned long long ph_f0 = COUNT ? __builtin_readcyclecounter() : 0ull;
                 for (unsigned int b0 = 0; b0 < n_f; b0 += 64u) {
                     const unsigned int i = b0 + lane;
@@ -569,7 +573,7 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_pool(const PoolArgs * args, De
                         unsigned int samp = (unsigned int)(job & POOL_JOB_SAMPLE_MASK);  // index of the sample that just ended
                         const f3 sum_prev = mk3(st.x, st.y, st.z);
                         const f3 c = a;
-                        Q.scratch[(size_t)samp * n_px + j] = make_float4(c.x, c.y, c.z, 0.0f);
+                        scratch[POOL_SCRATCH_AT(samp, j)] = make_float4(c.x, c.y, c.z, 0.0f);
                         const f3 sum = sum_prev + c;                                // color += scratch_buffer[samp]
                         bool stop = false;
                         if (samp >= P.spp) {                                        // second loop: CalculateVariance(scratch, samp), main.cpp:253
@@ -581,7 +585,7 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_pool(const PoolArgs * args, De
                             for (; k + 8u <= samp; k += 8u) {
                                 float4 v[8];
 #pragma unroll
-                                for (int u = 0; u < 8; ++u) v[u] = Q.scratch[(size_t)(k + (unsigned int)u) * n_px + j];
+                                for (int u = 0; u < 8; ++u) v[u] = scratch[POOL_SCRATCH_AT(k + (unsigned int)u, j)];
 #pragma unroll
                                 for (int u = 0; u < 8; ++u) {
                                     const float d = (fabsf(v[u].x - mean.x) + fabsf(v[u].y - mean.y)) + fabsf(v[u].z - mean.z);   // main.cpp:179-186
@@ -589,7 +593,7 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_pool(const PoolArgs * args, De
                                 }
                             }
                             for (; k < samp; ++k) {
-                                const float4 v = Q.scratch[(size_t)k * n_px + j];
+                                const float4 v = scratch[POOL_SCRATCH_AT(k, j)];
                                 const float d = (fabsf(v.x - mean.x) + fabsf(v.y - mean.y)) + fabsf(v.z - mean.z);
                                 variance += d * d;
                             }
@@ -617,9 +621,9 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_pool(const PoolArgs * args, De
                                     Rng rng;
                                     const ulonglong2 rs = B.rng[j], ra = B.rng_aux[j];
                                     rng.chain = rs.x; rng.prev = rs.y; rng.seed0 = ra.x; rng.k = (u32)ra.y;
-                                    u64 * ring = B.ring + j;
-                                    off_y = rng_float11<true>(rng, ring, n_px);          // first draw -> .y (main.cpp:238, 247)
-                                    off_x = rng_float11<true>(rng, ring, n_px);
+                                    u64 * ring = B.ring + (size_t)j * B.ring_step;
+                                    off_y = rng_float11<true>(rng, ring, B.ring_stride);          // first draw -> .y (main.cpp:238, 247)
+                                    off_x = rng_float11<true>(rng, ring, B.ring_stride);
                                     B.rng[j] = make_ulonglong2(rng.chain, rng.prev);
                                     B.rng_aux[j] = make_ulonglong2(rng.seed0, (u64)rng.k);
                                 }
@@ -696,9 +700,9 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_pool(const PoolArgs * args, De
                             Rng rng;
                             const ulonglong2 rs = B.rng[j], ra = B.rng_aux[j];
                             rng.chain = rs.x; rng.prev = rs.y; rng.seed0 = ra.x; rng.k = (u32)ra.y;
-                            u64 * ring = B.ring + j;
-                            off_y = rng_float11<true>(rng, ring, n_px);              // first draw -> .y (main.cpp:238, 247)
-                            off_x = rng_float11<true>(rng, ring, n_px);
+                            u64 * ring = B.ring + (size_t)j * B.ring_step;
+                            off_y = rng_float11<true>(rng, ring, B.ring_stride);              // first draw -> .y (main.cpp:238, 247)
+                            off_x = rng_float11<true>(rng, ring, B.ring_stride);
                             B.rng[j] = make_ulonglong2(rng.chain, rng.prev);
                             B.rng_aux[j] = make_ulonglong2(rng.seed0, (u64)rng.k);
                             const float jitter = next < P.spp ? 0.5f : 1.0f;        // main.cpp:240 vs :249

@@ -37,7 +37,12 @@ struct WaveBuffers {
     Accum * accum;               // [N] per-sample radiance (xyz), fixed point (dev_scene.h)
     ulonglong2 * rng;            // [N] (chain, prev)
     ulonglong2 * rng_aux;        // [N] (seed0, k)            RING only
-    u64 * ring;                  // [16][N]                   RING only
+    u64 * ring;                  // RING only: a sample's 16 slots at ring[sample * ring_step + slot * ring_stride].  Fixed spp:
+                                 // [16][N] (step 1, stride N) - the lanes of a wave are consecutive samples making the same
+                                 // draw, one run of 8-byte words.  Adaptive mode: [N][16] (step 16, stride 1) - the lanes are
+                                 // pixels at different draws, and a pixel's slots share one 128-byte line
+                                 // (profiles/r02_experiments.txt item 17)
+    unsigned int ring_step, ring_stride;
     float4 * frames;             // [levels][FR4][N] pending frames
     float4 * rq_o[2];            // closest-hit queues, double buffered: (o.xyz, sample)
     float4 * rq_d[2];            //                                      (d.xyz, level | pending_mask << 8)
@@ -102,8 +107,8 @@ __global__ __launch_bounds__(256) void k_raygen(DevCamera cam, DevParams P, Wave
     const unsigned int samp = gsid % P.spp;
     SampleState S;
     Frame cur;
-    u64 * ring = RING ? B.ring + sid : nullptr;
-    sample_begin<RING>(cam, P, pixel, samp, S, cur, ring, B.n_samples);
+    u64 * ring = RING ? B.ring + (size_t)sid * B.ring_step : nullptr;
+    sample_begin<RING>(cam, P, pixel, samp, S, cur, ring, B.ring_stride);
     B.rng[sid] = make_ulonglong2(S.rng.chain, S.rng.prev);
     if (RING) B.rng_aux[sid] = make_ulonglong2(S.rng.seed0, (u64)S.rng.k);
     accum_zero(B.accum + sid);
@@ -420,8 +425,8 @@ PRT_D void shade_entry_on(const DevScene & sc, const DevParams & P, const WaveBu
     }
     // RINGMEM = false: the general-RNG code without its draw ring in memory, for renders whose samples provably make at
     // most 15 draws (dev_rng.h) - a compile-time NULL, so the ring code folds away
-    u64 * ring = RING && RINGMEM ? B.ring + s : nullptr;
-    const size_t ring_stride = B.n_samples;
+    u64 * ring = RING && RINGMEM ? B.ring + (size_t)s * B.ring_step : nullptr;
+    const size_t ring_stride = B.ring_stride;
 
     f3 add = mk3(0.0f, 0.0f, 0.0f);          // radiance this invocation adds to the sample
     bool emit_closest = false;

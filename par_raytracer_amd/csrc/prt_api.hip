@@ -291,6 +291,8 @@ int chain_setup(prt_ctx * ctx, Chain & c, int index, const DevParams & P, bool r
     B.rng = w.rng.p;
     B.rng_aux = ring ? w.rng.p + N : nullptr;
     B.ring = ring ? ctx->ring_ws.p + (size_t)16 * base : nullptr;   // this chain's own [16][n_samples] block of the shared ring workspace
+    B.ring_step = 1;
+    B.ring_stride = n_samples;
     float4 * f = w.f4.p;
     B.frames = f; f += (size_t)levels * fr4 * N;
     for (int q = 0; q < 2; ++q) { B.rq_o[q] = f; f += N; B.rq_d[q] = f; f += N; B.rq_t[q] = f; f += N; }
@@ -508,6 +510,10 @@ int launch_pool(prt_ctx * ctx, bool count, const DevCamera & cam, DevParams P, u
     // waves, 64..512
     unsigned int cap = (n_samples / waves / 2u + 63u) / 64u * 64u;
     cap = std::max(64u, std::min(512u, cap));
+    // adaptive mode: a pixel stays in its pool for all its samples (up to 50 x several rounds), so what a wave takes it keeps;
+    // smaller pools leave more of the frame on the counter for the waves whose pixels end early (C4: 512 slots 195 ms,
+    // 256 168 ms, 64 - 192 161 - 164 ms, profiles/r02_adaptive_pool_capacity.txt)
+    if (ADAPT) cap = std::min(cap, 192u);
     if (const char * e = getenv("PRT_POOL_CAP")) cap = (unsigned int)std::max(64, std::min(4096, atoi(e) / 64 * 64));
     const unsigned int n_lights = std::max(1u, ctx->scene.light_count);
     const unsigned int scap = cap * n_lights;
@@ -546,6 +552,8 @@ int launch_pool(prt_ctx * ctx, bool count, const DevCamera & cam, DevParams P, u
     B.rng = w.rng.p;
     B.rng_aux = RING ? w.rng.p + N : nullptr;
     B.ring = RING && RINGMEM ? ctx->ring_ws.p : nullptr;
+    B.ring_step = ADAPT ? 16u : 1u;                              // WaveBuffers::ring: pixel-major in adaptive mode
+    B.ring_stride = ADAPT ? 1u : (unsigned int)n_samples;
     B.frames = w.f4.p;
     PoolBuffers Q;
     memset(&Q, 0, sizeof(Q));
@@ -571,7 +579,7 @@ int launch_pool(prt_ctx * ctx, bool count, const DevCamera & cam, DevParams P, u
         Q.jobsum = Q.scratch + (size_t)P.max_spp * N;
         Q.final_rgb = Q.jobsum + N;
     }
-    Q.topup_min = std::max(64u, cap / 4u);
+    Q.topup_min = ADAPT ? std::max(64u, cap / 2u) : std::max(64u, cap / 4u);
     if (const char * e = getenv("PRT_POOL_TOPUP")) Q.topup_min = (unsigned int)std::max(1, std::min((int)cap, atoi(e)));
     int keep_min = 40, node_min = 32;
     if (const char * e = getenv("PRT_KEEP_MIN")) keep_min = std::max(1, std::min(64, atoi(e)));
