@@ -10,8 +10,10 @@ cam = api.make_camera(s.fov, w, h, s.camera_position, s.camera_facing)
 buf = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda"); torch.cuda.synchronize()
 configs = [dict(), dict(PRT_SAH_BINS="32"), dict(PRT_SAH_BINS="64"), dict(PRT_SAH_SWEEP="64"), dict(PRT_SAH_SWEEP="1024"),
            dict(PRT_SAH_BINS="32", PRT_SAH_SWEEP="256"), dict(PRT_SAH_SWEEP="16384")]
+if len(sys.argv) > 1 and sys.argv[1] == "leaves":       # leaf size limit x SAH traversal cost
+    configs = [dict(PRT_LEAF_MAX=str(l), PRT_SAH_TRAV_COST=t) for l in (4, 3, 2, 1) for t in ("1", "0.5", "2")] + [dict()]
 for cfg in configs:
-    for k in ("PRT_SAH_BINS", "PRT_SAH_SWEEP"):
+    for k in ("PRT_SAH_BINS", "PRT_SAH_SWEEP", "PRT_LEAF_MAX", "PRT_SAH_TRAV_COST"):
         os.environ.pop(k, None)
     os.environ.update(cfg)
     r = api.Renderer(0); info = r.upload(hs)
