@@ -161,8 +161,19 @@ template <int BLOCK> PRT_D void pool_stack_spill(LdsSpillStack<BLOCK> & stack, P
 
 // Puts the arguments where k_pool reads them.  A kernel rather than a hipMemcpyAsync: kernel arguments are captured at
 // launch, whatever the runtime does with asynchronous copies from pageable memory.
-__global__ void k_pool_store_args(PoolArgs a, PoolArgs * dst) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) *dst = a;
+// One launch prepares a whole render: dst[0] for the fast kernel, dst[1] - the same arguments with the park list as the
+// source of work - for the adopting EXACT launch behind it, and the render's counters (sample counter, park counts, the
+// adopting launch's counter) zeroed.
+__global__ void k_pool_store_args(PoolArgs a, PoolArgs * dst, unsigned int * zero, unsigned int n_zero, unsigned int * adopt_head) {
+    if (threadIdx.x < n_zero) zero[threadIdx.x] = 0u;
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        dst[0] = a;
+        if (adopt_head) {
+            a.Q.adopt = 1;
+            a.Q.head = adopt_head;
+            dst[1] = a;
+        }
+    }
 }
 
 // grid = resident blocks; dynamic LDS = max(stack_entries, WFRAME_LDS_DWORDS) * BLOCK * 4 (traversal stack columns).

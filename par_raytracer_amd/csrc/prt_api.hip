@@ -526,8 +526,7 @@ int launch_pool(prt_ctx * ctx, bool count, const DevCamera & cam, DevParams P, u
     HIP_TRY(ctx, w.rng.ensure(RING ? 2 * N : N));
     HIP_TRY(ctx, ctx->pool_f4.ensure((size_t)waves * (7u * (size_t)cap + 3u * (size_t)scap)));
     // [0] sample counter, [1] parked closest-hit / finalise entries, [2] parked shadow rays, [3] the adopting launch's counter
-    HIP_TRY(ctx, ctx->wf_counts.ensure(16));
-    HIP_TRY(ctx, hipMemsetAsync(ctx->wf_counts.p, 0, 16 * sizeof(unsigned int), ctx->stream));
+    HIP_TRY(ctx, ctx->wf_counts.ensure(16));          // zeroed by k_pool_store_args below
     // Park lists: sized for what scenes with coincident geometry need in practice, never for the worst case (every sample's
     // ray parked: 48 bytes x samples x (1 + lights)).  The kernels count what they could not store; render_pixels looks at
     // the counts after the frame and, if a list was too short, enlarges it and renders the frame again.
@@ -596,7 +595,8 @@ int launch_pool(prt_ctx * ctx, bool count, const DevCamera & cam, DevParams P, u
     A.node_min = node_min;
     A.multi_light = multi_light;
     HIP_TRY(ctx, ctx->pool_args.ensure(2));
-    hipLaunchKernelGGL(k_pool_store_args, dim3(1), dim3(64), 0, ctx->stream, A, ctx->pool_args.p);
+    hipLaunchKernelGGL(k_pool_store_args, dim3(1), dim3(64), 0, ctx->stream, A, ctx->pool_args.p, ctx->wf_counts.p, 16u,
+                       exact_only ? (unsigned int *)nullptr : ctx->wf_counts.p + 3);
     HIP_TRY(ctx, hipGetLastError());
     int rc;
     if (exact_only) {
@@ -611,10 +611,6 @@ int launch_pool(prt_ctx * ctx, bool count, const DevCamera & cam, DevParams P, u
     HIP_TRY(ctx, hipGetLastError());
     // the adopting launch: one block per compute unit; they find the park list empty and leave at once - except in scenes
     // with coincident geometry, where they finish what the first launch set aside
-    A.Q.adopt = 1;
-    A.Q.head = ctx->wf_counts.p + 3;
-    hipLaunchKernelGGL(k_pool_store_args, dim3(1), dim3(64), 0, ctx->stream, A, ctx->pool_args.p + 1);
-    HIP_TRY(ctx, hipGetLastError());
     return count ? launch_pool_kernel<BLOCK, WAVES, LDSTAB, RING, true, TEX, ADAPT, RINGMEM, true>(ctx, grid2, lds, ctx->pool_args.p + 1)
                  : launch_pool_kernel<BLOCK, WAVES, LDSTAB, RING, false, TEX, ADAPT, RINGMEM, true>(ctx, grid2, lds, ctx->pool_args.p + 1);
 }
