@@ -156,6 +156,7 @@ struct DevCounters {          // device-side accumulators (atomics, one add per 
     unsigned long long shaded_hits;
     // wave-level step counts (COUNT builds only): lane utilisation = lane-level count / (64 * wave-level count)
     unsigned long long wave_node_steps, wave_leaf_steps, wave_tri_steps, wave_refills, max_sp, culled;
+    unsigned long long wave_node_step_rays;          // k_pool: lanes holding a ray, summed over its wave-level node steps
     // k_pool, COUNT builds: wave-cycles (s_memtime) spent in the top-up / trace / shade phase, in the whole main loop, and
     // (adaptive mode) in the finalise step, which is part of the shade phase
     unsigned long long phase_cycles[5];

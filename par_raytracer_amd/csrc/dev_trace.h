@@ -36,6 +36,7 @@ enum { TRACE_CLOSEST = 0, TRACE_ANY = 1 };
 struct TraceStats {
     unsigned int nodes, tris;
     unsigned int wnodes, wleaves, wtris, wrefills;   // counted by the first active lane only (wave-level steps)
+    unsigned int wrays;                              // k_pool: lanes that held a ray, summed over the wave-level node steps
     unsigned int max_sp, culled;                     // deepest stack use; popped nodes whose entry distance was already beyond the hit
 };
 

@@ -56,7 +56,7 @@ __global__ __launch_bounds__(BLOCK) void k_render_mega(DevScene sc, DevCamera ca
     hit.t = 0.0f; hit.v = hit.w = 0.0f; hit.tri = -1;
     RayReq req;
     TraceStats st;
-    st.nodes = st.tris = st.wnodes = st.wleaves = st.wtris = st.wrefills = st.max_sp = st.culled = 0;
+    st.nodes = st.tris = st.wnodes = st.wleaves = st.wtris = st.wrefills = st.wrays = st.max_sp = st.culled = 0;
     unsigned int rays = 0, shaded = 0;
     while (sample_advance<RING>(sc, P, S, cur, store, hit, req, shaded, ring, ring_stride)) {
         rays++;                                                     // debug->ray_count++  raytracer.cpp:161

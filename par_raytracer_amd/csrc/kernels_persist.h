@@ -56,7 +56,7 @@ __global__ __launch_bounds__(BLOCK, 4) void k_render_persistent(DevScene sc, Dev
     TravRay r;
     r.node = TRAV_SENTINEL; r.sp = 0; r.kind = 0;
     TraceStats st;
-    st.nodes = st.tris = st.wnodes = st.wleaves = st.wtris = st.wrefills = st.max_sp = st.culled = 0;
+    st.nodes = st.tris = st.wnodes = st.wleaves = st.wtris = st.wrefills = st.wrays = st.max_sp = st.culled = 0;
     unsigned int rays = 0, shaded = 0;
     unsigned int chunk_next = 0, chunk_end = 0;      // wave-uniform: samples reserved for this wave
     bool exhausted = false;                          // wave-uniform: the sample counter ran past n_samples

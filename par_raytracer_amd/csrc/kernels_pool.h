@@ -227,7 +227,7 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_pool(const PoolArgs * args, De
     unsigned int shaded_w = 0;                 // wave-uniform
     unsigned int elided_w = 0;                 // wave-uniform: shadow rays counted, not traced
     TraceStats st;
-    st.nodes = st.tris = st.wnodes = st.wleaves = st.wtris = st.wrefills = st.max_sp = st.culled = 0;
+    st.nodes = st.tris = st.wnodes = st.wleaves = st.wtris = st.wrefills = st.wrays = st.max_sp = st.culled = 0;
 
 // this wave's lists, from the arguments as re-read in the current phase
 #define PRT_POOL_LISTS(A)                                                                              \
@@ -448,8 +448,10 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_pool(const PoolArgs * args, De
                 while (ray >= 0) {
                     const int walkers = __popcll(__ballot(r.node >= 0));
                     const int nmin = node_min < (walkers >> 1) ? node_min : (walkers >> 1);
+                    const unsigned int with_ray = COUNT ? (unsigned int)__popcll(__ballot(true)) : 0u;
                     while (r.node >= 0) {
                         trav_node_step<Stack, COUNT>(sc, r, stack, st);
+                        if (COUNT && first_active_lane()) st.wrays += with_ray;
                         if (__popcll(__ballot(r.node >= 0)) < nmin) break;
                     }
                     bool fin = trav_done(r.node);
@@ -770,6 +772,7 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_pool(const PoolArgs * args, De
         atomicAdd(&ctr->wave_refills, (unsigned long long)st.wrefills);
         atomicMax(&ctr->max_sp, (unsigned long long)st.max_sp);
         atomicAdd(&ctr->culled, (unsigned long long)st.culled);
+        atomicAdd(&ctr->wave_node_step_rays, (unsigned long long)st.wrays);
         if (lane == 0) {
             atomicAdd(&ctr->phase_cycles[0], ph_topup);
             atomicAdd(&ctr->phase_cycles[1], ph_trace);
@@ -797,7 +800,7 @@ __global__ __launch_bounds__(256) void k_pool_parked_shadows(const PoolArgs * ar
         atomicMax(&ctr->park_peak[1], (unsigned long long)A.Q.park_count[1]);
     }
     TraceStats st;
-    st.nodes = st.tris = st.wnodes = st.wleaves = st.wtris = st.wrefills = st.max_sp = st.culled = 0;
+    st.nodes = st.tris = st.wnodes = st.wleaves = st.wtris = st.wrefills = st.wrays = st.max_sp = st.culled = 0;
     GlobalStack slow;
     slow.col = P.exact_stack + gid;
     slow.stride = P.exact_stack_stride;

@@ -140,7 +140,7 @@ __global__ __launch_bounds__(BLOCK, 6) void k_trace(DevScene sc, DevParams P, Wa
     int sample = 0;
     bool exhausted = false;              // wave-uniform: the queue has no more rays to hand out
     TraceStats st;
-    st.nodes = st.tris = st.wnodes = st.wleaves = st.wtris = st.wrefills = st.max_sp = st.culled = 0;
+    st.nodes = st.tris = st.wnodes = st.wleaves = st.wtris = st.wrefills = st.wrays = st.max_sp = st.culled = 0;
 
     unsigned int chunk_next = 0, chunk_end = 0;      // wave-uniform: rays reserved for this wave, not yet handed out
     for (;;) {
@@ -257,7 +257,7 @@ __global__ __launch_bounds__(256) void k_trace_exact(DevScene sc, DevParams P, W
     const unsigned int gid = blockIdx.x * blockDim.x + threadIdx.x;
     const unsigned int n_overflow = B.counts[3];
     TraceStats st;
-    st.nodes = st.tris = st.wnodes = st.wleaves = st.wtris = st.wrefills = st.max_sp = st.culled = 0;
+    st.nodes = st.tris = st.wnodes = st.wleaves = st.wtris = st.wrefills = st.wrays = st.max_sp = st.culled = 0;
     GlobalStack slow;
     slow.col = P.exact_stack + gid;
     slow.stride = P.exact_stack_stride;

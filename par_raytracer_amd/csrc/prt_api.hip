@@ -971,6 +971,11 @@ int render_pixels_once(prt_ctx * ctx, const prt_camera * cam_in, const prt_param
                     100.0 * (double)h.tri_tests / (64.0 * (double)h.wave_tri_steps), (unsigned long long)h.wave_tri_steps,
                     (unsigned long long)h.wave_leaf_steps, (unsigned long long)h.wave_refills,
                     h.wave_refills ? (double)host_ray_count / (double)h.wave_refills : 0.0);
+        if (getenv("PRT_DEBUG_UTIL") && h.wave_node_step_rays)
+            fprintf(stderr, "[prt] k_pool node loop, lane slots per wave step: %.1f%% walking, %.1f%% holding a ray but not walking (at a leaf, or done), %.1f%% without a ray\n",
+                    100.0 * (double)h.node_visits / (64.0 * (double)h.wave_node_steps),
+                    100.0 * ((double)h.wave_node_step_rays - (double)h.node_visits) / (64.0 * (double)h.wave_node_steps),
+                    100.0 * (64.0 * (double)h.wave_node_steps - (double)h.wave_node_step_rays) / (64.0 * (double)h.wave_node_steps));
         if (getenv("PRT_DEBUG_UTIL") && h.phase_cycles[3])
             fprintf(stderr, "[prt] k_pool wave time by phase: top-up %.1f%%, trace %.1f%%, shade %.1f%% of the main loop\n",
                     100.0 * (double)h.phase_cycles[0] / (double)h.phase_cycles[3], 100.0 * (double)h.phase_cycles[1] / (double)h.phase_cycles[3],
