@@ -117,7 +117,7 @@ struct PoolArgs {
     DevParams P;
     WaveBuffers B;
     PoolBuffers Q;
-    int keep_min, node_min, multi_light, pad;
+    int keep_min, node_min, multi_light, node_frac;      // node_frac / 8 of the walkers must still be walking, or the node loop ends
 };
 typedef const PoolArgs __attribute__((address_space(4))) * PoolArgsPtr;
 
@@ -352,7 +352,7 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_pool(const PoolArgs * args, De
             const DevScene & sc = A.sc;
             const DevParams & P = A.P;
             const WaveBuffers & B = A.B;
-            const int keep_min = A.keep_min, node_min = A.node_min;
+            const int keep_min = A.keep_min, node_min = A.node_min, node_frac = A.node_frac;
             PRT_POOL_LISTS(A);
             const DevLight * lights = sc.light_count <= (unsigned int)LDS_LIGHTS ? s_lights : sc.lights;
             TravRay r;
@@ -447,7 +447,8 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_pool(const PoolArgs * args, De
                 const int leave_below = next == total ? 1 : keep_min;
                 while (ray >= 0) {
                     const int walkers = __popcll(__ballot(r.node >= 0));
-                    const int nmin = node_min < (walkers >> 1) ? node_min : (walkers >> 1);
+                    const int wfrac = (walkers * node_frac) >> 3;
+                    const int nmin = node_min < wfrac ? node_min : wfrac;
                     const unsigned int with_ray = COUNT ? (unsigned int)__popcll(__ballot(true)) : 0u;
                     while (r.node >= 0) {
                         trav_node_step<Stack, COUNT>(sc, r, stack, st);

@@ -593,6 +593,8 @@ int launch_pool(prt_ctx * ctx, bool count, const DevCamera & cam, DevParams P, u
     A.Q = Q;
     A.keep_min = keep_min;
     A.node_min = node_min;
+    A.node_frac = 4;
+    if (const char * e = getenv("PRT_NODE_FRAC")) A.node_frac = std::max(0, std::min(8, atoi(e)));
     A.multi_light = multi_light;
     HIP_TRY(ctx, ctx->pool_args.ensure(2));
     hipLaunchKernelGGL(k_pool_store_args, dim3(1), dim3(64), 0, ctx->stream, A, ctx->pool_args.p, ctx->wf_counts.p, 16u,
