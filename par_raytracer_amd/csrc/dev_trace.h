@@ -193,6 +193,19 @@ PRT_D bool trav_wants_resolve(const TravRay & r) { return r.kind == TRACE_CLOSES
 // fast kernels: the ray cannot be finished here (near tie, or a dropped push): it goes to the slow path
 PRT_D bool trav_needs_slow_path(const TravRay & r) { return (trav_end_flags(r) & TRAV_FLAG_OVERFLOW) != 0 || trav_wants_resolve(r); }
 
+// Pop and push through the ray.  (The top entry mirrored in a register, so that the entry a pop hands out was read one step
+// earlier and the LDS latency is off the node-to-node chain, measured 0.8 % slower: profiles/r02_experiments.txt item 19.)
+template <class STK>
+PRT_D void trav_pop(TravRay & r, const STK & stk) {
+    r.sp--;
+    r.node = stk.pop(r.sp);
+}
+template <class STK>
+PRT_D void trav_push(TravRay & r, const STK & stk, int link) {
+    if (stk.push(r.sp, link)) r.sp++;
+    else stk.flag(TRAV_FLAG_OVERFLOW);
+}
+
 template <class STK>
 PRT_D void trav_init(TravRay & r, f3 o, f3 d, int kind, float pad, const STK & stk) {
     r.o = o;
@@ -280,14 +293,13 @@ PRT_D void trav_node_step(const DevScene & sc, TravRay & r, const STK & stk, Tra
     cswap(key[1], key[3], link[1], link[3]);
     cswap(key[1], key[2], link[1], link[2]);
     if (key[0] < inf) {
-        if (key[3] < inf) { if (stk.push(r.sp, link[3])) r.sp++; else stk.flag(TRAV_FLAG_OVERFLOW); }
-        if (key[2] < inf) { if (stk.push(r.sp, link[2])) r.sp++; else stk.flag(TRAV_FLAG_OVERFLOW); }
-        if (key[1] < inf) { if (stk.push(r.sp, link[1])) r.sp++; else stk.flag(TRAV_FLAG_OVERFLOW); }
+        if (key[3] < inf) trav_push(r, stk, link[3]);
+        if (key[2] < inf) trav_push(r, stk, link[2]);
+        if (key[1] < inf) trav_push(r, stk, link[1]);
         r.node = link[0];
     } else {
         if (COUNT && r.best.tri >= 0) st.culled++;
-        r.sp--;
-        r.node = stk.pop(r.sp);
+        trav_pop(r, stk);
     }
 }
 
@@ -316,8 +328,7 @@ PRT_D bool trav_leaf(const DevScene & sc, TravRay & r, const STK & stk, TraceSta
             if (r.kind & TRACE_ANY) return true;
         }
     }
-    r.sp--;
-    r.node = stk.pop(r.sp);
+    trav_pop(r, stk);
     return false;
 }
 
@@ -373,8 +384,7 @@ PRT_D HitRec resolve_near_ties(const DevScene & sc, f3 o, f3 d, float pad, float
                     const unsigned int rk = sc.tri_rank[ti];
                     if (rk >= next_rank && rk < c_rank) { c_rank = rk; c_tri = (int)ti; }
                 }
-                r.sp--;
-                r.node = stk.pop(r.sp);
+                trav_pop(r, stk);
             }
             if (c_tri < 0 || occupied) break;
             const float4 * tp = sc.tris + 3 * (size_t)c_tri;
