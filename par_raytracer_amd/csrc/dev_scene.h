@@ -160,6 +160,7 @@ struct DevCounters {          // device-side accumulators (atomics, one add per 
     // k_pool, COUNT builds: wave-cycles (s_memtime) spent in the top-up / trace / shade phase, in the whole main loop, and
     // (adaptive mode) in the finalise step, which is part of the shade phase
     unsigned long long phase_cycles[5];
+    unsigned long long wave_cycles_max, wave_cycles_sum, wave_count;   // k_pool (fast kernel), COUNT builds: the waves' main loops
     // pool pipeline: the most entries any pass wanted to put on its park lists ([0] closest-hit rays + finalise steps, [1] shadow
     // rays); above the lists' capacities the frame is incomplete and render_pixels renders it again with longer lists
     unsigned long long park_peak[2];

@@ -778,7 +778,13 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_pool(const PoolArgs * args, De
             atomicAdd(&ctr->phase_cycles[0], ph_topup);
             atomicAdd(&ctr->phase_cycles[1], ph_trace);
             atomicAdd(&ctr->phase_cycles[2], ph_shade);
-            atomicAdd(&ctr->phase_cycles[3], __builtin_readcyclecounter() - ph_begin);
+            const unsigned long long ph_all = __builtin_readcyclecounter() - ph_begin;
+            atomicAdd(&ctr->phase_cycles[3], ph_all);
+            if (!EXACT) {
+                atomicMax(&ctr->wave_cycles_max, ph_all);
+                atomicAdd(&ctr->wave_cycles_sum, ph_all);
+                atomicAdd(&ctr->wave_count, 1ull);
+            }
             if (ADAPT) atomicAdd(&ctr->phase_cycles[4], ph_final);
         }
     }

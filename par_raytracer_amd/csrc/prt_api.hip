@@ -982,6 +982,10 @@ int render_pixels_once(prt_ctx * ctx, const prt_camera * cam_in, const prt_param
             fprintf(stderr, "[prt] k_pool wave time by phase: top-up %.1f%%, trace %.1f%%, shade %.1f%% of the main loop\n",
                     100.0 * (double)h.phase_cycles[0] / (double)h.phase_cycles[3], 100.0 * (double)h.phase_cycles[1] / (double)h.phase_cycles[3],
                     100.0 * (double)h.phase_cycles[2] / (double)h.phase_cycles[3]);
+        if (getenv("PRT_DEBUG_UTIL") && h.wave_count)
+            fprintf(stderr, "[prt] k_pool waves: %llu, main loop mean %.3f of the longest wave's (what the others idle at the end of the frame: %.1f%%)\n",
+                    (unsigned long long)h.wave_count, (double)h.wave_cycles_sum / (double)h.wave_count / (double)h.wave_cycles_max,
+                    100.0 * (1.0 - (double)h.wave_cycles_sum / (double)h.wave_count / (double)h.wave_cycles_max));
         if (getenv("PRT_DEBUG_UTIL") && h.phase_cycles[3] && h.phase_cycles[4])
             fprintf(stderr, "[prt] k_pool adaptive finalise step (store the sample, variance rule, next camera ray): %.1f%% of the main loop\n",
                     100.0 * (double)h.phase_cycles[4] / (double)h.phase_cycles[3]);

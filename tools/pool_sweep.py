@@ -35,6 +35,7 @@ if "cap" in which: sweep("cap", {"PRT_POOL_CAP": [64, 128, 256, 512, 1024, 2048]
 if "keep" in which: sweep("keep", {"PRT_KEEP_MIN": [24, 32, 40, 48], "PRT_NODE_MIN": [16, 32]})
 if "keep2" in which: sweep("keep2", {"PRT_KEEP_MIN": [36, 40, 44, 48, 56], "PRT_NODE_MIN": [24, 32, 40, 48]})
 if "frac" in which: sweep("frac", {"PRT_NODE_FRAC": [4, 2, 3, 5, 6, 7, 4], "PRT_NODE_MIN": [32, 64]})
+if "shard" in which: sweep("shard", {"PRT_POOL_BLOCKS_PER_CU": [5, 4, 3], "PRT_POOL_CAP": [None, 128, 192, 256, 320, 384]})
 if "blocks" in which: sweep("blocks", {"PRT_POOL_BLOCKS_PER_CU": [1, 2]})
 if "topup" in which: sweep("topup", {"PRT_POOL_CAP": [256, 512], "PRT_POOL_TOPUP": [64, 128, 256]})
 if "default" in which: sweep("default", {"PRT_POOL_NOP": [0]})
