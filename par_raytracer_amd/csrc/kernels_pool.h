@@ -533,7 +533,6 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_pool(const PoolArgs * args, De
                 // ---- finalise: pixels whose sample ended one round ago; its last shadow rays have landed by now.
                 // RenderPixel's loops (main.cpp:236-258) one step at a time: store the sample, apply the stopping rule,
                 // start the next sample on the same RNG stream.
-                const size_t n_px = B.n_samples;
                 // the pixel's sample colours, pixel-major: the variance loop of a lane walks 16-byte neighbours (four samples per
                 // 64-byte line) instead of one line per sample (12-byte entries measured no better: profiles/r02_experiments.txt)
                 float4 * const scratch = Q.scratch;
@@ -697,7 +696,6 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_pool(const PoolArgs * args, De
                 // RNG state is final when a sample ends: shadow rays draw nothing) and the ray joins the list, marked; the
                 // finalise step calls it off if the pixel ends, and a called-off ray is not shaded and not counted.
                 pool_fence();
-                const size_t n_px = B.n_samples;
                 const unsigned int ended = emit.m_f;
                 unsigned int started = 0;
                 for (unsigned int b0 = 0; b0 < ended; b0 += 64u) {
