@@ -810,7 +810,21 @@ int render_pixels_once(prt_ctx * ctx, const prt_camera * cam_in, const prt_param
         if (pipeline == PRT_PIPELINE_POOL) per_sample += lv * fr4 * 16 + 32;
         if (adaptive) per_sample += ((unsigned long long)P.max_spp + 2) * 16;
         if (pipeline == PRT_PIPELINE_MEGAKERNEL && ctx->stack_bound > 24) per_sample += 4ull * ctx->stack_bound;
-        unsigned long long max_samples = 64ull << 20, max_mb = 64ull << 10;
+        // A pass ends with a drain (the waves run dry one by one), so fewer, larger passes are faster - C5: 8 passes 1,046 - 1,076
+        // ms, 4 passes 1,002, 3 passes 977 - 992 (profiles/r02_c5_pass_size.txt) - and 288 GB are there to be used: up to 192 M
+        // samples and 160 GB of workspace per pass, but no more than 80 % of what the device has free plus what this context
+        // already holds (a second context on the same GPU - two frames in flight - gets what is left, not an allocation failure).
+        unsigned long long max_samples = 192ull << 20, max_mb = 160ull << 10;
+        {
+            size_t free_b = 0, total_b = 0;
+            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+                unsigned long long held = ctx->sample_rgb.bytes() + ctx->ring_ws.bytes() + ctx->pool_f4.bytes() + ctx->adapt_f4.bytes() +
+                                          ctx->stack_spill.bytes() + ctx->pool_fin.bytes();
+                for (int c = 0; c < PRT_MAX_CHAINS; ++c) held += ctx->chain[c].f4.bytes() + ctx->chain[c].rng.bytes() + ctx->chain[c].overflow.bytes() + ctx->chain[c].slow_stack.bytes();
+                const unsigned long long budget_mb = (unsigned long long)(0.8 * (double)(free_b + held)) >> 20;
+                max_mb = std::max(1024ull, std::min(max_mb, budget_mb));
+            }
+        }
         if (const char * e = getenv("PRT_PASS_SAMPLES")) max_samples = std::max(1ull, strtoull(e, nullptr, 10));
         if (const char * e = getenv("PRT_PASS_MB")) max_mb = std::max(1ull, strtoull(e, nullptr, 10));
         max_samples = std::min(max_samples, std::max(1ull, (max_mb << 20) / per_sample));
