@@ -173,7 +173,8 @@ void prt_destroy(prt_ctx * ctx);
 const char * prt_last_error(const prt_ctx * ctx);   /* ctx may be NULL: last creation error */
 int prt_abi_version(void);
 
-/* Copies the scene to the device, builds the per-triangle BVH and the sampler tables. */
+/* Copies the scene to the device, builds the per-triangle BVH and the sampler tables.  At most 2^26 - 1 triangles (the
+ * traversal addresses nodes and triangle records by 32-bit byte offsets); more is an error, as is any index out of range. */
 int prt_upload_scene(prt_ctx * ctx, const prt_scene_desc * scene);
 
 /* Replaces RenderTask (main.cpp:267-283): pixels [start_idx, end_idx) of a w x h image, 16 B/pixel,

