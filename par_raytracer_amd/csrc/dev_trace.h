@@ -312,16 +312,27 @@ PRT_D bool trav_leaf(const DevScene & sc, TravRay & r, const STK & stk, TraceSta
     const unsigned int leaf = (unsigned int)~r.node;
     const unsigned int first = leaf >> 2, count = (leaf & 3u) + 1u;
     if (COUNT) { if (first_active_lane()) st.wleaves++; }
+    // the entry this leaf will pop, read before the triangle tests (nothing pushes while a leaf is tested): its LDS latency
+    // runs beside the triangle fetches instead of between the last test and the next node's fetch (-1.1 % frame time;
+    // requesting the next triangle before testing this one gains as much alone and loses with this: registers)
+    int next_node = stk.pop(r.sp - 1);
+    bool flagged = false;
     for (unsigned int i = 0; i < count; ++i) {
         const unsigned int ti = first + i;
         const float4 * tp = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(sc.tris) + ti * 48u);
         const float4 r0 = tp[0], r1 = tp[1], r2 = tp[2];
+        // all 48 bytes at once: left alone, the compiler sinks the load of `a` below the facing test - a second memory round
+        // trip inside every test of a front-facing triangle, 3.8 % of the frame (profiles/r02_experiments.txt item 26)
+        asm volatile("" :: "v"(r0.x), "v"(r0.y), "v"(r0.z));
         if (COUNT) { st.tris++; if (first_active_lane()) st.wtris++; }
         float t, v, w;
         bool near;
         const bool hit = tri_test(r.o, r.d, qp, mk3(r0.x, r0.y, r0.z), mk3(r0.w, r1.x, r1.y), mk3(r1.z, r1.w, r2.x),
                                   mk3(r2.y, r2.z, r2.w), r.best.t, t, v, w, near);
-        if (near) stk.flag(TRAV_FLAG_NEAR);
+        if (near) {
+            stk.flag(TRAV_FLAG_NEAR);
+            flagged = true;
+        }
         if (hit) {
             r.best.t = t;
             r.best.v = v;
@@ -330,7 +341,9 @@ PRT_D bool trav_leaf(const DevScene & sc, TravRay & r, const STK & stk, TraceSta
             if (r.kind & TRACE_ANY) return true;
         }
     }
-    trav_pop(r, stk);
+    if (flagged && r.sp == 1) next_node |= TRAV_FLAG_NEAR;      // the entry read ahead was the marker itself
+    r.sp--;
+    r.node = next_node;
     return false;
 }
 
