@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PRT_ABI_VERSION 3
+#define PRT_ABI_VERSION 4
 
 /* ---- scene description: the reference's pointer graph flattened to POD arrays ---------------- */
 
@@ -144,6 +144,9 @@ typedef struct prt_params {
  * POOL is not at least 3 % faster - worth it for many frames of one configuration, not for a single one.  Adaptive
  * sampling always runs on POOL.  All pipelines produce the same image (tests/test_gpu_parity.py); prt_counters.pipeline
  * reports which ran. */
+/* The shipped library has the two production pipelines, WAVEFRONT and POOL.  MEGAKERNEL (round 1's first version, which keeps
+ * the reference's float association exactly) and PERSISTENT (a measured negative result) exist only in a library built with
+ * -DPRT_EXPERIMENTAL (make hip-experimental); elsewhere asking for them is an error. */
 enum { PRT_PIPELINE_DEFAULT = 0, PRT_PIPELINE_MEGAKERNEL = 1, PRT_PIPELINE_WAVEFRONT = 2, PRT_PIPELINE_PERSISTENT = 3,
        PRT_PIPELINE_POOL = 4, PRT_PIPELINE_MASK = 0xFF };
 /* OR-ed into prt_params.pipeline: also count BVH node visits and triangle tests (costs a few percent;
@@ -167,11 +170,29 @@ typedef struct prt_counters {
 
 typedef struct prt_ctx prt_ctx;
 
-/* Lifecycle.  device_id is a HIP device ordinal. */
+/* Lifecycle.  device_id is a HIP device ordinal.  (A context is one device; prt_multi_* below is the n-device form of
+ * SURVEY.md 8(b)'s prt_create(const int * device_ids, int n_dev).) */
 prt_ctx * prt_create(int device_id);
 void prt_destroy(prt_ctx * ctx);
 const char * prt_last_error(const prt_ctx * ctx);   /* ctx may be NULL: last creation error */
 int prt_abi_version(void);
+
+/* Options.  Every tuning / test knob of the library is an entry of the context's option table (csrc/prt_options.h).
+ * prt_create reads the environment ONCE - PRT_<NAME>=value - and nothing on the upload or render path reads it again;
+ * prt_set_option changes an entry afterwards (name with or without the PRT_ prefix, any case; value NULL = default).
+ * Three entries change what a render does rather than how fast it is:
+ *   TRACE_DEAD_SHADOW_RAYS  0 (default): a shadow ray whose radiance-if-unoccluded is exactly zero is counted in ray_count but
+ *                           not traced (no outcome could change the image); 1: traced all the same
+ *   BVH_BUILDER             "sah" (default): binned-SAH build on the host; "lbvh": radix tree built on the GPU (applies to the
+ *                           next prt_upload_scene)
+ *   POOL_EXACT              1: the pool pipeline's slow-path kernel renders everything (test hook; same image)
+ * Returns 0, or -1 (unknown name, value that does not parse, RESERVE_CUS after creation). */
+int prt_set_option(prt_ctx * ctx, const char * name, const char * value);
+
+/* How the library was built: PRT_BUILD_EXPERIMENTAL - the MEGAKERNEL / PERSISTENT pipelines are present;
+ * PRT_BUILD_BVH4 - the 4-wide sorted traversal of rounds 1-2 instead of the 8-wide octant-ordered one. */
+enum { PRT_BUILD_EXPERIMENTAL = 1, PRT_BUILD_BVH4 = 2 };
+int prt_build_flags(void);
 
 /* Copies the scene to the device, builds the per-triangle BVH and the sampler tables.  At most 2^26 - 1 triangles (the
  * traversal addresses nodes and triangle records by 32-bit byte offsets); more is an error, as is any index out of range. */
@@ -236,8 +257,8 @@ typedef struct prt_render_stats {
     uint64_t phase_cycles[5];                  /* pool pipeline: top-up, trace, shade, whole main loop, adaptive finalise step */
     uint64_t parked_rays, parked_shadow_rays;  /* pool pipeline: most rays any pass handed to its slow launches */
     uint64_t elided_shadow_rays;               /* shadow rays that are in ray_count but were not traced: their radiance-if-unoccluded
-                                                * was exactly zero, so no outcome could change the image (PRT_TRACE_DEAD_SHADOW_RAYS=1
-                                                * traces them all the same) */
+                                                * was exactly zero, so no outcome could change the image (option
+                                                * TRACE_DEAD_SHADOW_RAYS=1 traces them all the same) */
     uint32_t stack_lds_entries, stack_bound;   /* LDS stack column height used, worst-case bound of the tree */
 } prt_render_stats;
 int prt_get_render_stats(const prt_ctx * ctx, prt_render_stats * stats);
@@ -246,7 +267,7 @@ int prt_get_render_stats(const prt_ctx * ctx, prt_render_stats * stats);
  * CPU test-suite calls it): every triangle inside every ancestor's de-quantised box, every triangle in
  * exactly one leaf, links in range.  out[6] = { violations, nodes, depth, stack bound, leaves, triangle refs }. */
 int prt_debug_check_bvh(const prt_scene_desc * scene, uint64_t * out);
-/* The same check on the tree of the GPU LBVH builder (environment PRT_BVH_BUILDER=lbvh at upload: radix tree built on the
+/* The same check on the tree of the GPU LBVH builder (option BVH_BUILDER=lbvh at upload: radix tree built on the
  * device, bvh_lbvh.h; an alternative for scenes that change every frame - ~10x faster to build, slower to traverse). */
 int prt_debug_check_bvh_lbvh(prt_ctx * ctx, const prt_scene_desc * scene, uint64_t * out);
 

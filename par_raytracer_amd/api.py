@@ -221,6 +221,12 @@ class Renderer:
         if rc != 0:
             raise RuntimeError("%s failed (%d): %s" % (what, rc, self._lib.prt_last_error(self._ctx).decode()))
 
+    def set_option(self, name: str, value=None) -> None:
+        """prt_set_option: one entry of the context's option table (csrc/prt_options.h); value None restores the default.
+        The environment (PRT_<NAME>) is only read when the context is created."""
+        v = None if value is None else str(value).encode()
+        self._check(self._lib.prt_set_option(self._ctx, name.encode(), v), "prt_set_option(%s)" % name)
+
     def upload(self, scene) -> PrtSceneInfo:
         desc = scene.desc if isinstance(scene, (HostScene, FlatDesc)) else scene
         self._check(self._lib.prt_upload_scene(self._ctx, desc), "prt_upload_scene")

@@ -98,9 +98,10 @@ class PrtRenderStats(C.Structure):
 PIPELINE_DEFAULT, PIPELINE_MEGAKERNEL, PIPELINE_WAVEFRONT, PIPELINE_PERSISTENT, PIPELINE_POOL = 0, 1, 2, 3, 4
 FLAG_COUNT_VISITS = 0x100
 FLAG_TRYOUT = 0x200
+BUILD_EXPERIMENTAL, BUILD_BVH4 = 1, 2
 
 # Every symbol include/prt.h declares; tests/test_capi_symbols.py checks the library exports them all.
-PRT_SYMBOLS = ["prt_create", "prt_destroy", "prt_last_error", "prt_abi_version", "prt_upload_scene", "prt_render",
+PRT_SYMBOLS = ["prt_create", "prt_destroy", "prt_last_error", "prt_abi_version", "prt_set_option", "prt_build_flags", "prt_upload_scene", "prt_render",
                "prt_render_device", "prt_shard_rows", "prt_render_shard_device", "prt_render_shard", "prt_render_pixel_list", "prt_get_scene_info", "prt_get_render_stats", "prt_debug_check_bvh", "prt_debug_check_bvh_lbvh", "prt_debug_device_kat"]
 PRT_HOST_SYMBOLS = ["prt_host_load_obj", "prt_host_free_scene", "prt_host_scene_desc", "prt_host_scene_hierarchy_seconds",
                     "prt_host_scene_parse_seconds", "prt_host_last_error", "prt_host_make_camera",
@@ -127,13 +128,17 @@ def hip_lib() -> C.CDLL:
     """libprt_hip.so: the HIP kernels + C ABI."""
     global _hip
     if _hip is None:
-        lib = _load(os.path.join(PKG_DIR, "libprt_hip.so"), "HIP extension")
+        # PRT_HIP_LIB names a variant build of the same ABI inside the package directory (make hip-experimental, hip-bvh4;
+        # tools/ab_*.sh); the product is libprt_hip.so
+        lib = _load(os.path.join(PKG_DIR, os.path.basename(os.environ.get("PRT_HIP_LIB", "libprt_hip.so"))), "HIP extension")
         lib.prt_create.restype = C.c_void_p
         lib.prt_create.argtypes = [C.c_int]
         lib.prt_destroy.argtypes = [C.c_void_p]
         lib.prt_last_error.restype = C.c_char_p
         lib.prt_last_error.argtypes = [C.c_void_p]
         lib.prt_abi_version.restype = C.c_int
+        lib.prt_build_flags.restype = C.c_int
+        lib.prt_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p]
         lib.prt_upload_scene.argtypes = [C.c_void_p, C.POINTER(PrtSceneDesc)]
         lib.prt_render.argtypes = [C.c_void_p, C.POINTER(PrtCamera), C.POINTER(PrtParams), C.c_uint32, C.c_uint32,
                                    C.c_uint32, C.c_uint32, C.c_void_p, C.POINTER(PrtCounters)]

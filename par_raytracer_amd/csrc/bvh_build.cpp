@@ -1,5 +1,6 @@
 // bvh_build.cpp - binned surface-area-heuristic BVH2 builder (host, multi-threaded over subtrees).
 #include "bvh_build.h"
+#include "prt_options.h"
 
 #include <algorithm>
 #include <atomic>
@@ -51,6 +52,12 @@ struct Builder {
     float trav_cost = 1.0f;     // SAH: cost of one traversal step relative to one triangle test
     int BINS = 16;              // SAH bins per axis (PRT_SAH_BINS, <= MAX_BINS)
     uint32_t sweep_max = 0;     // nodes of at most this many triangles try every split position of every axis (PRT_SAH_SWEEP)
+    BvhBuildOptions opt;        // how the caller wants the tree built (prt_options.h); defaults when it said nothing
+    void configure(const BvhBuildOptions * o) {
+        if (o) opt = *o;
+        if (opt.sah_bins >= 0) BINS = std::max(4, std::min((int)MAX_BINS, (int)opt.sah_bins));
+        if (opt.sah_sweep >= 0) sweep_max = (uint32_t)opt.sah_sweep;
+    }
 
     uint32_t alloc() { return next_node.fetch_add(1); }
 
@@ -321,7 +328,7 @@ void finish_bvh4q_impl(Builder & b, uint32_t n_tris, Bvh4Result * out);
 void finish_bvh4q(Builder & b, uint32_t n_tris, Bvh4Result * out) {
     const auto t0 = std::chrono::steady_clock::now();
     finish_bvh4q_impl(b, n_tris, out);
-    if (getenv("PRT_DEBUG_UTIL")) fprintf(stderr, "[prt] BVH back end (collapse to 4-wide, quantise, reorder): %.1f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+    if (b.opt.debug) fprintf(stderr, "[prt] BVH back end (collapse to 4-wide, quantise, reorder): %.1f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
 }
 void finish_bvh4q_impl(Builder & b, uint32_t n_tris, Bvh4Result * out) {
     out->tri_order.resize(n_tris);
@@ -341,12 +348,11 @@ void finish_bvh4q_impl(Builder & b, uint32_t n_tris, Bvh4Result * out) {
     // Measured on MI355X: 18-20 % fewer wide nodes, but only 1-2 % fewer node visits per frame and 2.5 % MORE triangle
     // tests on C4 (the rays of a terrain seen from above are far from the uniform distribution the heuristic assumes):
     // frame time unchanged within noise.  So the default stays the first version - open the child with the largest box
-    // until four are there - and PRT_BVH_COLLAPSE=dp selects this one.
+    // until four are there - and the BVH_COLLAPSE=dp option selects this one.
     struct Item { uint32_t tmp; uint32_t slot; uint32_t depth; };
     std::vector<Wide> wide;
     std::vector<Item> work;
-    const char * collapse_env = getenv("PRT_BVH_COLLAPSE");
-    const bool greedy = !(collapse_env && !strcmp(collapse_env, "dp"));
+    const bool greedy = b.opt.collapse != 1;                 // 4-wide default: greedy
     const uint32_t n_tmp = b.next_node.load();
     struct Dp { float f[3]; uint8_t root_split, split[2]; };   // f[k-1] = F(m, k); split: i of the best distribution, 0 = "use k - 1"
     std::vector<Dp> dp;
@@ -503,17 +509,242 @@ void finish_bvh4q_impl(Builder & b, uint32_t n_tris, Bvh4Result * out) {
     out->stack_bound = 3 * max_depth + 2;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// 8-wide, quantised, octant-ordered (layout: bvh_build.h Bvh8Result)
+// ---------------------------------------------------------------------------------------------------------
+void finish_bvh8q_impl(Builder & b, uint32_t n_tris, Bvh8Result * out);
+void finish_bvh8q(Builder & b, uint32_t n_tris, Bvh8Result * out) {
+    const auto t0 = std::chrono::steady_clock::now();
+    finish_bvh8q_impl(b, n_tris, out);
+    if (b.opt.debug) fprintf(stderr, "[prt] BVH back end (collapse to 8-wide, slot assignment, quantise, reorder): %.1f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+}
+void finish_bvh8q_impl(Builder & b, uint32_t n_tris, Bvh8Result * out) {
+    auto is_leaf = [&](uint32_t t) { return b.pool[t].left < 0; };
+    enum : uint32_t { EMPTY = 0xFFFFFFFFu };
+    struct Wide8 { uint32_t slot[8]; };                     // TmpNode index per slot, EMPTY for none
+
+    // ---- collapse (below), then give every child a slot: slot s stands for the
+    // octant direction ((s & 1) ? +x : -x, (s & 2) ? +y : -y, (s & 4) ? +z : -z) as seen from the node's centre, and a ray
+    // whose direction signs are o = (dx < 0) | (dy < 0) << 1 | (dz < 0) << 2 visits the hit slots in ascending order of
+    // (s XOR o): the child on the side the ray comes from first, on every axis.  Children are matched to slots greedily by
+    // how far their centres lie in the slot's direction (Ylitie et al. 2017, section 3.2, solve it with an auction; the
+    // greedy matching is within a few per cent of it and this runs 150,000 times per upload).
+    // The collapse itself is the small dynamic programme of Ylitie et al. (section 3.1) over the binary tree, leaves fixed:
+    //   F(m, k) = least total area of wide nodes below binary node m if m may occupy up to k slots of its parent
+    //   F(m, 1) = area(m) + min over i of F(left, i) + F(right, 8 - i)          (m becomes a wide node; 0 for a leaf)
+    //   F(m, k) = min(F(m, k - 1), min over i of F(left, i) + F(right, k - i))  (m is dissolved into its parent)
+    // Every visit of a wide node costs the same (all eight boxes are tested) and a node is visited in proportion to its
+    // area.  The greedy rule of the 4-wide back end (open the largest child until the node is full) leaves the 8-wide
+    // tree of the 1M-triangle terrain at 3.6 children per node; the programme fills it (tools/bvh_price.cpp).
+    // The option BVH_COLLAPSE=greedy selects the greedy rule.
+    const bool greedy = b.opt.collapse == 0;                 // 8-wide default: the dynamic programme
+    const uint32_t n_tmp = b.next_node.load();
+    struct Dp8 { float f[7]; uint8_t root_split, split[6]; };   // f[k-1] = F(m, k); split[k-2]: i of the best distribution, 0 = "use k - 1"
+    std::vector<Dp8> dp;
+    if (!greedy) {
+        dp.resize(n_tmp);
+        for (uint32_t t = n_tmp; t-- > 0;) {                  // children are allocated after their parent: bottom-up
+            Dp8 & d = dp[t];
+            if (is_leaf(t)) { memset(&d, 0, sizeof(d)); continue; }
+            const Dp8 & l = dp[(uint32_t)b.pool[t].left], & r = dp[(uint32_t)b.pool[t].right];
+            float best = FLT_MAX;
+            d.root_split = 1;
+            for (int i = 1; i <= 7; ++i) {
+                const float c = l.f[i - 1] + r.f[7 - i];
+                if (c < best) { best = c; d.root_split = (uint8_t)i; }
+            }
+            d.f[0] = b.pool[t].box.half_area() + best;
+            for (int k = 2; k <= 7; ++k) {
+                float bk = d.f[k - 2];
+                uint8_t sk = 0;
+                for (int i = 1; i < k; ++i) {
+                    const float c = l.f[i - 1] + r.f[k - i - 1];
+                    if (c < bk) { bk = c; sk = (uint8_t)i; }
+                }
+                d.f[k - 1] = bk;
+                d.split[k - 2] = sk;
+            }
+        }
+    }
+    auto make_wide = [&](uint32_t root_tmp) -> Wide8 {
+        uint32_t kids[8];
+        uint32_t n = 0;
+        if (is_leaf(root_tmp)) {
+            kids[n++] = root_tmp;
+        } else if (!greedy) {
+            // unfold the stored decisions: (node, slots it may occupy)
+            struct Todo { uint32_t t; int k; };
+            Todo stack[16];
+            int sp = 0;
+            const int i0 = dp[root_tmp].root_split;
+            stack[sp++] = Todo{ (uint32_t)b.pool[root_tmp].right, 8 - i0 };
+            stack[sp++] = Todo{ (uint32_t)b.pool[root_tmp].left, i0 };
+            while (sp > 0) {
+                Todo cur = stack[--sp];
+                while (cur.k > 1 && !is_leaf(cur.t) && dp[cur.t].split[cur.k - 2] == 0) cur.k--;      // "use k - 1 slots"
+                if (cur.k == 1 || is_leaf(cur.t)) { kids[n++] = cur.t; continue; }
+                const int i = dp[cur.t].split[cur.k - 2];
+                stack[sp++] = Todo{ (uint32_t)b.pool[cur.t].right, cur.k - i };
+                stack[sp++] = Todo{ (uint32_t)b.pool[cur.t].left, i };
+            }
+        } else {
+            kids[n++] = (uint32_t)b.pool[root_tmp].left;
+            kids[n++] = (uint32_t)b.pool[root_tmp].right;
+            while (n < 8) {
+                int best = -1;
+                float best_area = -1.0f;
+                for (uint32_t k = 0; k < n; ++k) {
+                    if (is_leaf(kids[k])) continue;
+                    const float a = b.pool[kids[k]].box.half_area();
+                    if (a > best_area) { best_area = a; best = (int)k; }
+                }
+                if (best < 0) break;
+                const uint32_t t = kids[best];
+                kids[best] = (uint32_t)b.pool[t].left;
+                kids[n++] = (uint32_t)b.pool[t].right;
+            }
+        }
+        Box u;
+        u.reset();
+        for (uint32_t k = 0; k < n; ++k) u.grow(b.pool[kids[k]].box);
+        float cost[8][8];
+        for (uint32_t k = 0; k < n; ++k) {
+            const Box & cb = b.pool[kids[k]].box;
+            float rel[3];
+            for (int a = 0; a < 3; ++a) rel[a] = (0.5f * cb.lo[a] + 0.5f * cb.hi[a]) - (0.5f * u.lo[a] + 0.5f * u.hi[a]);
+            for (uint32_t s = 0; s < 8; ++s)
+                cost[k][s] = ((s & 1u) ? rel[0] : -rel[0]) + ((s & 2u) ? rel[1] : -rel[1]) + ((s & 4u) ? rel[2] : -rel[2]);
+        }
+        Wide8 w;
+        for (uint32_t s = 0; s < 8; ++s) w.slot[s] = EMPTY;
+        bool placed[8] = { false, false, false, false, false, false, false, false };
+        for (uint32_t round = 0; round < n; ++round) {
+            int bk = -1, bs = -1;
+            float bc = -FLT_MAX;
+            for (uint32_t k = 0; k < n; ++k) {
+                if (placed[k]) continue;
+                for (uint32_t s = 0; s < 8; ++s) {
+                    if (w.slot[s] != EMPTY) continue;
+                    if (cost[k][s] > bc) { bc = cost[k][s]; bk = (int)k; bs = (int)s; }
+                }
+            }
+            if (bk < 0) {                                   // NaN / inf boxes: any free slot will do
+                for (uint32_t k = 0; k < n && bk < 0; ++k) if (!placed[k]) bk = (int)k;
+                for (uint32_t s = 0; s < 8 && bs < 0; ++s) if (w.slot[s] == EMPTY) bs = (int)s;
+            }
+            placed[bk] = true;
+            w.slot[bs] = kids[bk];
+        }
+        return w;
+    };
+
+    // ---- number the nodes breadth-first - the internal children of a node get consecutive indices in slot order - and lay
+    // the triangles out so that the leaves of a node are consecutive in slot order too: a child is then addressed by the
+    // node's base index plus the number of like children in lower slots, and the node needs no links.
+    struct Item { uint32_t tmp, depth; };
+    std::vector<Wide8> wide;
+    std::vector<Item> work;
+    std::vector<uint32_t> child_base, tri_base;
+    out->tri_order.clear();
+    out->tri_order.reserve(n_tris);
+    work.push_back(Item{ 0u, 1u });
+    uint32_t max_depth = 1;
+    for (size_t head = 0; head < work.size(); ++head) {
+        const Item it = work[head];
+        const Wide8 w = make_wide(it.tmp);
+        wide.push_back(w);
+        child_base.push_back((uint32_t)work.size());
+        tri_base.push_back((uint32_t)out->tri_order.size());
+        for (uint32_t s = 0; s < 8; ++s) {
+            const uint32_t t = w.slot[s];
+            if (t == EMPTY) continue;
+            if (is_leaf(t)) {
+                // (an empty scene's root leaf names the all-zero dummy record the uploader appends at slot n_tris = 0)
+                for (uint32_t i = 0; i < b.pool[t].count && b.pool[t].first + i < n_tris; ++i)
+                    out->tri_order.push_back(b.prims[b.pool[t].first + i].id);
+            } else {
+                work.push_back(Item{ t, it.depth + 1 });
+                if (it.depth + 1 > max_depth) max_depth = it.depth + 1;
+            }
+        }
+    }
+
+    // ---- quantise
+    const uint32_t n_nodes = (uint32_t)wide.size();
+    out->nodes.assign((size_t)n_nodes * BVH8_NODE_DWORDS, 0u);
+    for (uint32_t ni = 0; ni < n_nodes; ++ni) {
+        const Wide8 & w = wide[ni];
+        Box u;
+        u.reset();
+        for (uint32_t s = 0; s < 8; ++s) if (w.slot[s] != EMPTY) u.grow(b.pool[w.slot[s]].box);
+        uint32_t * d = &out->nodes[(size_t)ni * BVH8_NODE_DWORDS];
+        uint32_t ebyte[3];
+        double scale[3];
+        for (int a = 0; a < 3; ++a) {
+            double ext = (double)u.hi[a] - (double)u.lo[a];
+            int e = -100;
+            if (ext > 0.0) {
+                e = (int)std::ceil(std::log2(ext / 255.0));
+                while (std::ldexp(255.0, e) < ext) ++e;
+                if (e < -100) e = -100;
+            }
+            if (e > 100) e = 100;
+            ebyte[a] = (uint32_t)(e + 127);
+            scale[a] = std::ldexp(1.0, e);
+            d[a] = float_bits(u.lo[a]);
+        }
+        uint32_t imask = 0, lmask = 0, c0 = 0, c1 = 0;
+        for (uint32_t s = 0; s < 8; ++s) {
+            uint32_t qlo[3] = { 255, 255, 255 }, qhi[3] = { 0, 0, 0 };      // empty slot: inverted, can never be hit
+            const uint32_t t = w.slot[s];
+            if (t != EMPTY) {
+                const Box & cb = b.pool[t].box;
+                for (int a = 0; a < 3; ++a) {
+                    double lo = std::floor(((double)cb.lo[a] - (double)u.lo[a]) / scale[a]);
+                    double hi = std::ceil(((double)cb.hi[a] - (double)u.lo[a]) / scale[a]);
+                    if (lo < 0.0) lo = 0.0;
+                    if (lo > 255.0) lo = 255.0;
+                    if (hi < 0.0) hi = 0.0;
+                    if (hi > 255.0) hi = 255.0;
+                    qlo[a] = (uint32_t)lo;
+                    qhi[a] = (uint32_t)hi;
+                }
+                if (is_leaf(t)) {
+                    const uint32_t extra = b.pool[t].count - 1u;             // 0..3
+                    lmask |= 1u << s;
+                    c0 |= (extra & 1u) << s;
+                    c1 |= (extra >> 1) << s;
+                } else {
+                    imask |= 1u << s;
+                }
+            }
+            for (int a = 0; a < 3; ++a) {
+                d[8 + 2 * a + (s >> 2)] |= qlo[a] << (8 * (s & 3u));
+                d[14 + 2 * a + (s >> 2)] |= qhi[a] << (8 * (s & 3u));
+            }
+        }
+        d[3] = ebyte[0] << 23 | imask | lmask << 8;
+        d[4] = child_base[ni];
+        d[5] = tri_base[ni];
+        d[6] = ebyte[1] << 23 | c0 | c1 << 8;
+        d[7] = ebyte[2] << 23;
+    }
+    out->node_count = n_nodes;
+    out->max_depth = max_depth;
+    out->stack_bound = max_depth + 2;       // one group of unvisited siblings per level, the bottom marker, one to spare
+}
+
 }  // namespace
 
-void build_bvh4q(const float * verts, uint32_t n_tris, uint32_t leaf_max, uint32_t threads, Bvh4Result * out, float trav_cost) {
-    *out = Bvh4Result();
+namespace {
+
+// Front end shared by the 4- and 8-wide builds: binned-SAH binary tree over the triangles into b.pool (root 0).
+void build_sah_binary(Builder & b, const float * verts, uint32_t n_tris, uint32_t leaf_max, uint32_t threads, float trav_cost,
+                      float * scene_lo, float * scene_hi) {
     if (leaf_max < 1) leaf_max = 1;
     if (leaf_max > 4) leaf_max = 4;
-    Builder b;
     b.leaf_max = leaf_max;
     b.trav_cost = trav_cost;
-    if (const char * e = getenv("PRT_SAH_BINS")) b.BINS = std::max(4, std::min((int)MAX_BINS, atoi(e)));
-    if (const char * e = getenv("PRT_SAH_SWEEP")) b.sweep_max = (uint32_t)std::max(0, atoi(e));
     b.prims.resize(n_tris);
     Box scene;
     scene.reset();
@@ -527,7 +758,7 @@ void build_bvh4q(const float * verts, uint32_t n_tris, uint32_t leaf_max, uint32
         p.id = i;
         scene.grow(p.box);
     }
-    for (int a = 0; a < 3; ++a) { out->scene_lo[a] = n_tris ? scene.lo[a] : 0.0f; out->scene_hi[a] = n_tris ? scene.hi[a] : 0.0f; }
+    for (int a = 0; a < 3; ++a) { scene_lo[a] = n_tris ? scene.lo[a] : 0.0f; scene_hi[a] = n_tris ? scene.hi[a] : 0.0f; }
     b.pool.resize(n_tris ? 2 * (size_t)n_tris : 1);
     b.next_node = 1;
     b.max_depth = 0;
@@ -544,21 +775,37 @@ void build_bvh4q(const float * verts, uint32_t n_tris, uint32_t leaf_max, uint32
         n.count = 1;          // the all-zero dummy triangle the uploader always allocates
         n.depth = 0;
     }
-    if (getenv("PRT_DEBUG_UTIL")) fprintf(stderr, "[prt] binned-SAH binary build, %u triangles, %u threads: %.1f ms\n", n_tris, threads, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_build).count());
+    if (b.opt.debug) fprintf(stderr, "[prt] binned-SAH binary build, %u triangles, %u threads: %.1f ms\n", n_tris, threads, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_build).count());
+}
+
+}  // namespace
+
+void build_bvh4q(const float * verts, uint32_t n_tris, uint32_t leaf_max, uint32_t threads, Bvh4Result * out, float trav_cost, const BvhBuildOptions * opt) {
+    *out = Bvh4Result();
+    Builder b;
+    b.configure(opt);
+    build_sah_binary(b, verts, n_tris, leaf_max, threads, trav_cost, out->scene_lo, out->scene_hi);
     finish_bvh4q(b, n_tris, out);
+}
+
+void build_bvh8q(const float * verts, uint32_t n_tris, uint32_t leaf_max, uint32_t threads, Bvh8Result * out, float trav_cost, const BvhBuildOptions * opt) {
+    *out = Bvh8Result();
+    Builder b;
+    b.configure(opt);
+    build_sah_binary(b, verts, n_tris, leaf_max, threads, trav_cost, out->scene_lo, out->scene_hi);
+    finish_bvh8q(b, n_tris, out);
 }
 
 // Back end for a tree built elsewhere (the GPU LBVH builder, bvh_lbvh.hip): a binary radix tree over the triangles in
 // sorted order.  Internal node i has children left[i] / right[i] (>= 0: internal node, < 0: ~sorted position of a
 // single triangle), covers sorted positions [first[i], last[i]] and has box node_box[6 i .. 6 i + 5] (lo xyz, hi xyz);
 // leaf_box holds the triangles' own boxes in sorted order.  Subtrees of at most leaf_max triangles become leaves.
-void build_bvh4q_from_radix_tree(uint32_t n_tris, uint32_t leaf_max, const int32_t * left, const int32_t * right,
-                                 const uint32_t * first, const uint32_t * last, const float * node_box, const float * leaf_box,
-                                 const uint32_t * sorted_ids, Bvh4Result * out) {
-    *out = Bvh4Result();
+namespace {
+void radix_tree_to_binary(Builder & b, uint32_t n_tris, uint32_t leaf_max, const int32_t * left, const int32_t * right,
+                          const uint32_t * first, const uint32_t * last, const float * node_box, const float * leaf_box,
+                          const uint32_t * sorted_ids, float * scene_lo, float * scene_hi) {
     if (leaf_max < 1) leaf_max = 1;
     if (leaf_max > 4) leaf_max = 4;
-    Builder b;
     b.leaf_max = leaf_max;
     b.prims.resize(n_tris);
     Box scene;
@@ -569,7 +816,7 @@ void build_bvh4q_from_radix_tree(uint32_t n_tris, uint32_t leaf_max, const int32
         p.id = sorted_ids[i];
         scene.grow(p.box);
     }
-    for (int a = 0; a < 3; ++a) { out->scene_lo[a] = n_tris ? scene.lo[a] : 0.0f; out->scene_hi[a] = n_tris ? scene.hi[a] : 0.0f; }
+    for (int a = 0; a < 3; ++a) { scene_lo[a] = n_tris ? scene.lo[a] : 0.0f; scene_hi[a] = n_tris ? scene.hi[a] : 0.0f; }
     b.pool.resize(n_tris ? 2 * (size_t)n_tris : 1);
     b.next_node = 1;
     b.max_depth = 0;
@@ -582,7 +829,7 @@ void build_bvh4q_from_radix_tree(uint32_t n_tris, uint32_t leaf_max, const int32
         make_leaf(b.pool[0], zero, 0, 1, 0);            // the all-zero dummy triangle the uploader always allocates
     } else if (n_tris <= leaf_max || n_tris == 1) {
         make_leaf(b.pool[0], scene, 0, n_tris, 0);
-    } else if (getenv("PRT_LBVH_PLAIN") != nullptr) {
+    } else if (b.opt.lbvh_plain) {
         // the radix tree as it is (round 1): fastest back end, 1.6 x slower to traverse than the SAH tree
         struct Todo { uint32_t tmp; int32_t src; uint32_t depth; };
         std::vector<Todo> todo;
@@ -616,8 +863,7 @@ void build_bvh4q_from_radix_tree(uint32_t n_tris, uint32_t leaf_max, const int32
         // each cluster (independent ranges, built by a pool of threads).  What the Morton order costs is then only where the
         // cluster boundaries lie.
         uint32_t cluster_max = 64;
-        if (const char * e = getenv("PRT_LBVH_CLUSTER")) cluster_max = (uint32_t)std::max(4, std::min(1 << 20, atoi(e)));
-        if (const char * e = getenv("PRT_SAH_BINS")) b.BINS = std::max(4, std::min((int)MAX_BINS, atoi(e)));
+        if (b.opt.lbvh_cluster >= 0) cluster_max = (uint32_t)std::max(4ll, std::min(1ll << 20, b.opt.lbvh_cluster));
         for (uint32_t i = 0; i < n_tris; ++i)
             for (int a = 0; a < 3; ++a) b.prims[i].c[a] = 0.5f * b.prims[i].box.lo[a] + 0.5f * b.prims[i].box.hi[a];
         struct Cluster { Box box; float c[3]; uint32_t first, count; };
@@ -698,7 +944,9 @@ void build_bvh4q_from_radix_tree(uint32_t n_tris, uint32_t leaf_max, const int32
                 });
                 mid = rg.lo + (uint32_t)(mp - bp);
             }
-            if (mid == rg.lo || mid == rg.hi) mid = rg.lo + (rg.hi - rg.lo) / 2;       // coincident centres: halve the run
+            // coincident centres - or a run of lopsided splits that has used up the depth budget (the stack bound and the spill
+            // areas are sized from the depth): halve the run
+            if (mid == rg.lo || mid == rg.hi || rg.depth >= MAX_FORCED_DEPTH) mid = rg.lo + (rg.hi - rg.lo) / 2;
             TmpNode & n = b.pool[rg.tmp];
             n.box = bounds; n.depth = rg.depth; n.first = n.count = 0;
             const uint32_t l = b.alloc(), r = b.alloc();
@@ -727,9 +975,29 @@ void build_bvh4q_from_radix_tree(uint32_t n_tris, uint32_t leaf_max, const int32
             for (unsigned int t = 0; t < n_threads; ++t) pool.emplace_back(work);
             for (size_t t = 0; t < pool.size(); ++t) pool[t].join();
         }
-        if (getenv("PRT_DEBUG_UTIL")) fprintf(stderr, "[prt] LBVH hybrid: %zu clusters (<= %u triangles); SAH inside them on %u threads: %.1f ms\n", clusters.size(), cluster_max, n_threads, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_bottom).count());
+        if (b.opt.debug) fprintf(stderr, "[prt] LBVH hybrid: %zu clusters (<= %u triangles); SAH inside them on %u threads: %.1f ms\n", clusters.size(), cluster_max, n_threads, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_bottom).count());
     }
+}
+}  // namespace
+
+void build_bvh4q_from_radix_tree(uint32_t n_tris, uint32_t leaf_max, const int32_t * left, const int32_t * right,
+                                 const uint32_t * first, const uint32_t * last, const float * node_box, const float * leaf_box,
+                                 const uint32_t * sorted_ids, Bvh4Result * out, const BvhBuildOptions * opt) {
+    *out = Bvh4Result();
+    Builder b;
+    b.configure(opt);
+    radix_tree_to_binary(b, n_tris, leaf_max, left, right, first, last, node_box, leaf_box, sorted_ids, out->scene_lo, out->scene_hi);
     finish_bvh4q(b, n_tris, out);
+}
+
+void build_bvh8q_from_radix_tree(uint32_t n_tris, uint32_t leaf_max, const int32_t * left, const int32_t * right,
+                                 const uint32_t * first, const uint32_t * last, const float * node_box, const float * leaf_box,
+                                 const uint32_t * sorted_ids, Bvh8Result * out, const BvhBuildOptions * opt) {
+    *out = Bvh8Result();
+    Builder b;
+    b.configure(opt);
+    radix_tree_to_binary(b, n_tris, leaf_max, left, right, first, last, node_box, leaf_box, sorted_ids, out->scene_lo, out->scene_hi);
+    finish_bvh8q(b, n_tris, out);
 }
 
 }  // namespace prt

@@ -85,6 +85,12 @@ struct DevScene {
     const float * srgb_lut;          // 256 x Color_SRGBToLinear(i / 255), host powf
     const float4 * tri_uv;           // 32 B per triangle: (uv0, uv1) (uv2, -)
     const float4 * tri_tan;          // 48 B per triangle: the three vertex tangents, packed like the normals in `shade`
+    // near-tie resolution only (dev_trace_common.h RefSphereWalk): the reference's sphere tree, 32 B per sphere:
+    // (centre xyz, radius) (c0, c1, visit rank of c0's first triangle, position in the reference's pop order); NULL when the
+    // scene came without a usable tree
+    const float4 * ref_spheres;
+    unsigned int tie_widen_max;                 // resolve_near_ties: widenings of the candidate set before it gives up (8)
+    unsigned long long * near_tie_unresolved;   // ... and counts the event here (the render call then fails)
 };
 
 struct DevCamera {            // Camera (main.cpp:133-143) with the loop invariants of MakeCameraRay hoisted
@@ -165,6 +171,7 @@ struct DevCounters {          // device-side accumulators (atomics, one add per 
     // rays); above the lists' capacities the frame is incomplete and render_pixels renders it again with longer lists
     unsigned long long park_peak[2];
     unsigned long long elided_shadow_rays;     // shadow rays counted (they are in ray_count) but not traced: they could not change the image
+    unsigned long long near_tie_unresolved;    // resolve_near_ties gave up widening its candidate set (the render call fails)
 };
 
 // Per-sample radiance accumulator of the wavefront and pool pipelines: 2^-32 fixed point in 64-bit integers.  A sample's

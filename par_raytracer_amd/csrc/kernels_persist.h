@@ -37,10 +37,9 @@ __global__ __launch_bounds__(BLOCK, 4) void k_render_persistent(DevScene sc, Dev
     const unsigned int slot = blockIdx.x * BLOCK + threadIdx.x;          // persistent lane id
     const unsigned int lane = lane_id();
     LdsSpillStack<BLOCK> stack;
-    stack.col = s_stack + threadIdx.x;
+    stack.attach(s_stack, threadIdx.x);
     stack.cap = P.stack_lds_entries;
-    stack.spill = P.stack_spill;
-    stack.spill_stride = P.stack_spill_stride;
+    stack.set_spill(P.stack_spill, P.stack_spill_stride);
     u64 * ring = RING ? ring_ws + slot : nullptr;
     const size_t ring_stride = (size_t)gridDim.x * BLOCK;
 
@@ -54,7 +53,7 @@ __global__ __launch_bounds__(BLOCK, 4) void k_render_persistent(DevScene sc, Dev
     HitRec hit;
     hit.t = 0.0f; hit.v = hit.w = 0.0f; hit.tri = -1;
     TravRay r;
-    r.node = TRAV_SENTINEL; r.sp = 0; r.kind = 0;
+    trav_idle(r);
     TraceStats st;
     st.nodes = st.tris = st.wnodes = st.wleaves = st.wtris = st.wrefills = st.wrays = st.max_sp = st.culled = 0;
     unsigned int rays = 0, shaded = 0;
@@ -114,16 +113,16 @@ __global__ __launch_bounds__(BLOCK, 4) void k_render_persistent(DevScene sc, Dev
         int leave_below = (n_live * keep_min) >> 6;
         if (leave_below < 1) leave_below = 1;
         while (state == LANE_TRAVERSE) {
-            const int walkers = __popcll(__ballot(r.node >= 0));
+            const int walkers = __popcll(__ballot(trav_walking(r)));
             const int nmin = node_min < (walkers >> 1) ? node_min : (walkers >> 1);
-            while (r.node >= 0) {
-                trav_node_step<LdsSpillStack<BLOCK>, COUNT>(sc, r, stack, st);
-                if (__popcll(__ballot(r.node >= 0)) < nmin) break;
+            while (trav_walking(r)) {
+                trav_node_step<LdsSpillStack<BLOCK>, COUNT>(sc, r, stack, st, P.box_pad);
+                if (__popcll(__ballot(trav_walking(r))) < nmin) break;
             }
-            bool fin = trav_done(r.node);
-            if (!fin && r.node < 0) fin = trav_leaf<LdsSpillStack<BLOCK>, COUNT>(sc, r, stack, st);
+            bool fin = trav_done(r);
+            if (!fin && !trav_walking(r)) fin = trav_leaf<LdsSpillStack<BLOCK>, COUNT>(sc, r, stack, st);
             if (fin) {
-                if (trav_wants_resolve(r)) r.best = resolve_near_ties<LdsSpillStack<BLOCK>, COUNT>(sc, r.o, r.d, P.box_pad, r.best.t, stack, st);
+                if (trav_wants_resolve(r, stack)) r.best = resolve_near_ties<LdsSpillStack<BLOCK>, COUNT>(sc, r.o, r.d, P.box_pad, r.best.t, stack, st);
                 hit = r.best;
                 state = LANE_ADVANCE;
                 break;

@@ -155,8 +155,7 @@ template <int BLOCK, bool EXACT> struct PoolStack { typedef LdsStack<BLOCK> type
 template <int BLOCK> struct PoolStack<BLOCK, true> { typedef LdsSpillStack<BLOCK> type; };
 template <int BLOCK> PRT_D void pool_stack_spill(LdsStack<BLOCK> &, PoolArgsPtr) {}
 template <int BLOCK> PRT_D void pool_stack_spill(LdsSpillStack<BLOCK> & stack, PoolArgsPtr args) {
-    stack.spill = as_global(args->P.stack_spill);
-    stack.spill_stride = args->P.stack_spill_stride;
+    stack.set_spill(as_global(args->P.stack_spill), args->P.stack_spill_stride);
 }
 
 // Puts the arguments where k_pool reads them.  A kernel rather than a hipMemcpyAsync: kernel arguments are captured at
@@ -214,7 +213,7 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_pool(const PoolArgs * args, De
     const unsigned int wave = (unsigned int)__builtin_amdgcn_readfirstlane((int)(slot_id >> 6));      // scalar: the list pointers stay in SGPRs
     typedef typename PoolStack<BLOCK, EXACT>::type Stack;
     Stack stack;
-    stack.col = s_stack + threadIdx.x;
+    stack.attach(s_stack, threadIdx.x);
     stack.cap = ((PoolArgsPtr)args)->P.stack_lds_entries;
     pool_stack_spill(stack, (PoolArgsPtr)args);
 
@@ -356,7 +355,7 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_pool(const PoolArgs * args, De
             PRT_POOL_LISTS(A);
             const DevLight * lights = sc.light_count <= (unsigned int)LDS_LIGHTS ? s_lights : sc.lights;
             TravRay r;
-            r.node = TRAV_SENTINEL; r.sp = 0; r.kind = 0;
+            trav_idle(r);
             int ray = -1;
             float4 payload = make_float4(0, 0, 0, 0);
             int sample = 0;
@@ -446,20 +445,20 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_pool(const PoolArgs * args, De
 
                 const int leave_below = next == total ? 1 : keep_min;
                 while (ray >= 0) {
-                    const int walkers = __popcll(__ballot(r.node >= 0));
+                    const int walkers = __popcll(__ballot(trav_walking(r)));
                     const int wfrac = (walkers * node_frac) >> 3;
                     const int nmin = node_min < wfrac ? node_min : wfrac;
                     const unsigned int with_ray = COUNT ? (unsigned int)__popcll(__ballot(true)) : 0u;
-                    while (r.node >= 0) {
-                        trav_node_step<Stack, COUNT>(sc, r, stack, st);
+                    while (trav_walking(r)) {
+                        trav_node_step<Stack, COUNT>(sc, r, stack, st, P.box_pad);
                         if (COUNT && first_active_lane()) st.wrays += with_ray;
-                        if (__popcll(__ballot(r.node >= 0)) < nmin) break;
+                        if (__popcll(__ballot(trav_walking(r))) < nmin) break;
                     }
-                    bool fin = trav_done(r.node);
-                    if (!fin && r.node < 0) fin = trav_leaf<Stack, COUNT>(sc, r, stack, st);
+                    bool fin = trav_done(r);
+                    if (!fin && !trav_walking(r)) fin = trav_leaf<Stack, COUNT>(sc, r, stack, st);
                     if (fin) {
-                        if (EXACT && trav_wants_resolve(r)) r.best = resolve_near_ties<Stack, COUNT>(sc, r.o, r.d, P.box_pad, r.best.t, stack, st);
-                        if (!EXACT && trav_needs_slow_path(r)) {
+                        if (EXACT && trav_wants_resolve(r, stack)) r.best = resolve_near_ties<Stack, COUNT>(sc, r.o, r.d, P.box_pad, r.best.t, stack, st);
+                        if (!EXACT && trav_needs_slow_path(r, stack)) {
                             // rare: the hit has company within a few ulp and the reference's visit order decides, or a push did
                             // not fit the LDS column (dev_trace.h).  Not here: the ray is parked for the launches that follow.
                             if (ADAPT && (unsigned int)ray < n_c && ((unsigned int)as_i(cd[ray].w) >> 8 & POOL_SPEC_PENDING_BIT)) {
@@ -685,7 +684,7 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_pool(const PoolArgs * args, De
                 }
                 unsigned int shaded = 0;
                 // the frame under construction lives in this lane's (idle) traversal stack column
-                shade_entry_lds<RING, TEX, BLOCK, RINGMEM>(sc, P, B, tb, live && !parked && !cancelled, s, level, pending, ray_o, ray_d, T, hit, emit, shaded, stack.col);
+                shade_entry_lds<RING, TEX, BLOCK, RINGMEM>(sc, P, B, tb, live && !parked && !cancelled, s, level, pending, ray_o, ray_d, T, hit, emit, shaded, stack.frame_col());
                 shaded_w += (unsigned int)__popcll(__ballot(shaded != 0));
             }
             if (ADAPT) {
@@ -807,8 +806,7 @@ __global__ __launch_bounds__(256) void k_pool_parked_shadows(const PoolArgs * ar
     TraceStats st;
     st.nodes = st.tris = st.wnodes = st.wleaves = st.wtris = st.wrefills = st.wrays = st.max_sp = st.culled = 0;
     GlobalStack slow;
-    slow.col = P.exact_stack + gid;
-    slow.stride = P.exact_stack_stride;
+    slow.attach(P.exact_stack, gid, P.exact_stack_stride);
     for (unsigned int i = gid; i < n; i += gridDim.x * blockDim.x) {
         const float4 ro = A.Q.spark[i], pay = A.Q.spark[(size_t)A.Q.spark_cap + i], rd = A.Q.spark[2u * (size_t)A.Q.spark_cap + i];
         const int sample = as_i(ro.w);

@@ -125,7 +125,7 @@ __global__ __launch_bounds__(BLOCK, 6) void k_trace(DevScene sc, DevParams P, Wa
                                                   DevCounters * ctr) {
     extern __shared__ int s_stack[];
     LdsStack<BLOCK> stack;
-    stack.col = s_stack + threadIdx.x;
+    stack.attach(s_stack, threadIdx.x);
     stack.cap = P.stack_lds_entries;
     const unsigned int total = n_closest + n_shadow;
     const unsigned int lane = lane_id();
@@ -134,7 +134,7 @@ __global__ __launch_bounds__(BLOCK, 6) void k_trace(DevScene sc, DevParams P, Wa
     unsigned int * head = B.counts + 2;
 
     TravRay r;
-    r.node = TRAV_SENTINEL; r.sp = 0; r.kind = 0;
+    trav_idle(r);
     int ray = -1;                        // index into the combined [closest | shadow] ray space, -1 = idle
     float4 payload = make_float4(0, 0, 0, 0);
     int sample = 0;
@@ -204,16 +204,16 @@ __global__ __launch_bounds__(BLOCK, 6) void k_trace(DevScene sc, DevParams P, Wa
             // Node phase.  Lanes drop out as they reach a leaf; once fewer than `node_min` lanes are still
             // walking, the stragglers are suspended too (they keep their node) so the wave can run the leaf
             // phase for the majority instead of idling behind the longest walk.
-            const int walkers = __popcll(__ballot(r.node >= 0));
+            const int walkers = __popcll(__ballot(trav_walking(r)));
             const int nmin = node_min < (walkers >> 1) ? node_min : (walkers >> 1);
-            while (r.node >= 0) {
-                trav_node_step<LdsStack<BLOCK>, COUNT>(sc, r, stack, st);
-                if (__popcll(__ballot(r.node >= 0)) < nmin) break;
+            while (trav_walking(r)) {
+                trav_node_step<LdsStack<BLOCK>, COUNT>(sc, r, stack, st, P.box_pad);
+                if (__popcll(__ballot(trav_walking(r))) < nmin) break;
             }
-            bool fin = trav_done(r.node);
-            if (!fin && r.node < 0) fin = trav_leaf<LdsStack<BLOCK>, COUNT>(sc, r, stack, st);
+            bool fin = trav_done(r);
+            if (!fin && !trav_walking(r)) fin = trav_leaf<LdsStack<BLOCK>, COUNT>(sc, r, stack, st);
             if (fin) {
-                if (trav_needs_slow_path(r)) {
+                if (trav_needs_slow_path(r, stack)) {
                     // rare: the hit has company within a few ulp and the reference's visit order decides (dev_trace.h), or
                     // a push did not fit the LDS column (never observed on real scenes): hand the ray to k_trace_exact, which
                     // traces it again on a full-height stack and replays that order, before k_shade runs
@@ -259,8 +259,7 @@ __global__ __launch_bounds__(256) void k_trace_exact(DevScene sc, DevParams P, W
     TraceStats st;
     st.nodes = st.tris = st.wnodes = st.wleaves = st.wtris = st.wrefills = st.wrays = st.max_sp = st.culled = 0;
     GlobalStack slow;
-    slow.col = P.exact_stack + gid;
-    slow.stride = P.exact_stack_stride;
+    slow.attach(P.exact_stack, gid, P.exact_stack_stride);
     for (unsigned int i = gid; i < n_overflow; i += gridDim.x * blockDim.x) {
         const unsigned int idx = B.overflow[i];
         float4 ro, rd, payload = make_float4(0, 0, 0, 0);

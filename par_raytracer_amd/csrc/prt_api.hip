@@ -17,15 +17,35 @@
 
 #include "../../include/prt.h"
 #include "bvh_build.h"
+#include "prt_options.h"
 #include "dev_scene.h"
-#include "kernels_mega.h"
 #include "kernels_wave.h"
-#include "kernels_persist.h"
 #include "kernels_pool.h"
+#include "kernels_resolve.h"
+#if defined(PRT_EXPERIMENTAL)
+// the round-1 megakernel (the exact-association cross-check) and the persistent single-launch experiment: not in the
+// shipped library; `make hip-experimental` builds a library that has them (tests/test_gpu_parity.py uses it when it is there)
+#include "kernels_mega.h"
+#include "kernels_persist.h"
+#endif
 #include "bvh_lbvh.h"
 #include "kernels_debug.h"
 
 using namespace prt;
+
+// The acceleration structure the library is built with (dev_trace.h): 8-wide octant-ordered, or -DPRT_BVH4 the 4-wide
+// sorted one of rounds 1-2.
+#if defined(PRT_BVH4)
+typedef Bvh4Result BvhWide;
+static const int kBvhNodeDwords = 16;
+#define PRT_BUILD_WIDE build_bvh4q
+#define PRT_BUILD_WIDE_FROM_RADIX build_bvh4q_from_radix_tree
+#else
+typedef Bvh8Result BvhWide;
+static const int kBvhNodeDwords = BVH8_NODE_DWORDS;
+#define PRT_BUILD_WIDE build_bvh8q
+#define PRT_BUILD_WIDE_FROM_RADIX build_bvh8q_from_radix_tree
+#endif
 
 namespace {
 
@@ -72,6 +92,7 @@ enum { PRT_MAX_CHAINS = 8 };
 
 struct prt_ctx {
     int device = 0;
+    PrtOptions opt;                       // every knob, read from the environment once at creation (prt_options.h, prt_set_option)
     hipStream_t stream = nullptr;
     hipEvent_t ev[4] = { nullptr, nullptr, nullptr, nullptr };
     std::string error;
@@ -95,6 +116,7 @@ struct prt_ctx {
     DevBuf<unsigned int> texels;
     DevBuf<float> srgb_lut;
     DevBuf<float4> tri_uv, tri_tan;
+    DevBuf<float4> ref_spheres;           // the reference's sphere tree for near-tie resolution (dev_trace_common.h RefSphereWalk)
     std::vector<float> material_ns;      // for rebuilding spec_dirs when spec_samples changes
     unsigned int spec_table_samples = 0;
 
@@ -122,6 +144,7 @@ struct prt_ctx {
     prt_render_stats last_stats;          // of the last render call (prt_get_render_stats)
     DevBuf<float4> pool_park;             // pool pipeline: rays parked for the slow launches (kernels_pool.h PoolBuffers::park)
     size_t pool_park_cap = 1u << 18, pool_spark_cap = 1u << 18;     // entries; enlarged when a frame needed more (render_pixels)
+    size_t park_cap_used = 0, spark_cap_used = 0;                     // what the last launch_pool really gave its lists (<= the worst case)
     DevBuf<unsigned int> pool_fin;        // adaptive mode: per-wave lists of pixels to finalise
     DevBuf<PoolArgs> pool_args;           // k_pool's arguments (read per phase from memory, kernels_pool.h)
     DevBuf<float4> adapt_f4;              // adaptive mode: scratch [max_spp][n] + running sums [n] + final colours [n]
@@ -203,6 +226,7 @@ struct PixelSet {
     const unsigned int * d_pixel_list;         // explicit list (device pointer) or NULL
 };
 
+#if defined(PRT_EXPERIMENTAL)
 template <int MAXLEV, bool RING>
 void launch_mega(prt_ctx * ctx, bool count, unsigned int grid, size_t lds, const DevCamera & cam, const DevParams & P,
                  unsigned int n_samples) {
@@ -242,6 +266,8 @@ int launch_persistent(prt_ctx * ctx, bool count, size_t lds, const DevCamera & c
     return 0;
 }
 
+#endif  // PRT_EXPERIMENTAL
+
 // The wavefront pipeline (kernels_wave.h): raygen, then rounds of {persistent trace, shade} until no ray is
 // left.  Queue sizes come back to the host once per round (8 bytes, pinned): they size the next launches, end
 // the loop and sum to ray_count (every queued ray is one TraceRay call, raytracer.cpp:161).
@@ -279,7 +305,7 @@ int chain_setup(prt_ctx * ctx, Chain & c, int index, const DevParams & P, bool r
     {
         // k_trace_exact's fixed grid: full-height stack columns for the rays k_trace hands over (near ties, overflowed columns)
         const size_t exact_lanes = 64 * 256;
-        HIP_TRY(ctx, w.slow_stack.ensure((size_t)std::max(ctx->stack_bound, 4u) * exact_lanes));
+        HIP_TRY(ctx, w.slow_stack.ensure((size_t)std::max(ctx->stack_bound, 4u) * exact_lanes * STACK_ENTRY_INTS));
         c.P.exact_stack = w.slow_stack.p;
         c.P.exact_stack_stride = (unsigned int)exact_lanes;
     }
@@ -373,7 +399,7 @@ int chain_finish_round(prt_ctx * ctx, Chain & c) {
     float ms = 0.0f;
     HIP_TRY(ctx, hipEventElapsedTime(&ms, c.ws->ev_t0, c.ws->ev_t1));
     c.trace_ms += ms;
-    if (getenv("PRT_DEBUG_ROUNDS")) fprintf(stderr, "[prt] round %u: %u closest + %u shadow rays, k_trace %.3f ms\n", c.round, c.n_closest, c.n_shadow, ms);
+    if (ctx->opt.debug_rounds) fprintf(stderr, "[prt] round %u: %u closest + %u shadow rays, k_trace %.3f ms\n", c.round, c.n_closest, c.n_shadow, ms);
     const unsigned int n_lights = std::max(1u, ctx->scene.light_count);
     const unsigned int next_closest = c.n_closest ? c.ws->host_counts[0] : 0;
     const unsigned int next_shadow = c.n_closest ? c.ws->host_counts[1] : 0;
@@ -404,20 +430,21 @@ int render_wavefront(prt_ctx * ctx, const DevCamera & cam, const DevParams & P, 
     t.keep_min = 40;
     t.node_min = 32;
     t.chunk_min = 128;
-    if (const char * e = getenv("PRT_CHUNK_MIN")) t.chunk_min = (unsigned int)std::max(64, std::min(512, atoi(e)));
+    const PrtOptions & opt = ctx->opt;
+    if (opt.chunk_min >= 0) t.chunk_min = (unsigned int)std::max(64ll, std::min(512ll, opt.chunk_min));
     int n_chains = n_samples >= (1u << 23) ? 2 : 1;          // measured +2 % on 16.6 M samples; small frames: not worth the extra launches
     int split_per_cu = 4;
     // tuning knobs for experiments (not part of the ABI)
-    if (const char * e = getenv("PRT_TRACE_BLOCKS_PER_CU")) { per_cu = std::max(1, std::min(per_cu, atoi(e))); split_per_cu = per_cu; }
-    if (const char * e = getenv("PRT_KEEP_MIN")) t.keep_min = std::max(1, std::min(64, atoi(e)));
-    if (const char * e = getenv("PRT_NODE_MIN")) t.node_min = std::max(0, std::min(64, atoi(e)));
-    if (const char * e = getenv("PRT_CHAINS")) n_chains = std::max(1, std::min((int)PRT_MAX_CHAINS, atoi(e)));
+    if (opt.trace_blocks_per_cu >= 0) { per_cu = std::max(1, std::min(per_cu, (int)opt.trace_blocks_per_cu)); split_per_cu = per_cu; }
+    if (opt.keep_min >= 0) t.keep_min = std::max(1, std::min(64, (int)opt.keep_min));
+    if (opt.node_min >= 0) t.node_min = std::max(0, std::min(64, (int)opt.node_min));
+    if (opt.chains >= 0) n_chains = std::max(1, std::min((int)PRT_MAX_CHAINS, (int)opt.chains));
     // chains start on a pixel and a wave boundary
     const unsigned int unit = P.spp * 64u;
     while (n_chains > 1 && (unsigned long long)unit * n_chains > n_samples) n_chains--;
     t.per_cu = n_chains >= 2 ? std::min(per_cu, split_per_cu) : per_cu;
     t.shade_block = n_chains >= 2 ? 256 : 1024;
-    if (const char * e = getenv("PRT_SHADE_BLOCK")) t.shade_block = atoi(e) == 256 ? 256 : 1024;
+    if (opt.shade_block >= 0) t.shade_block = opt.shade_block == 256 ? 256 : 1024;
     t.multi_light = ctx->scene.light_count > 1 ? 1 : 0;
 
     Chain chain[PRT_MAX_CHAINS];
@@ -488,20 +515,21 @@ int launch_pool_kernel(prt_ctx * ctx, unsigned int grid, size_t lds, const PoolA
 template <int BLOCK, int WAVES, bool LDSTAB, bool RING, bool TEX, bool ADAPT, bool RINGMEM = true>
 int launch_pool(prt_ctx * ctx, bool count, const DevCamera & cam, DevParams P, unsigned int n_samples, unsigned int stack_entries) {
     // the stack columns double as the shading phase's frame storage (WFRAME_LDS_DWORDS per lane)
-    const size_t lds = (size_t)std::max(stack_entries, (unsigned int)WFRAME_LDS_DWORDS) * BLOCK * sizeof(int);
+    const size_t lds = (size_t)std::max(stack_entries * (unsigned int)STACK_ENTRY_INTS, (unsigned int)WFRAME_LDS_DWORDS) * BLOCK * sizeof(int);
+    const PrtOptions & opt = ctx->opt;
     // Three launches (kernels_pool.h PoolBuffers::park): the fast kernel, which parks the rays it cannot finish - a hit with
     // company within a few ulp, a stack column that overflowed -; k_pool_parked_shadows for the parked shadow rays; the EXACT
     // kernel, adopting the parked closest-hit rays.  Normally nothing is parked and the two follow-ups leave at once.
-    // PRT_POOL_EXACT=1 (tests): the EXACT kernel does the whole render.
-    const bool exact_only = getenv("PRT_POOL_EXACT") != nullptr;
+    // Option POOL_EXACT (tests): the EXACT kernel does the whole render.
+    const bool exact_only = opt.pool_exact != 0;
     int per_cu = 0;
     hipError_t oe = exact_only ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_pool<BLOCK, WAVES, LDSTAB, RING, false, TEX, ADAPT, RINGMEM, true>, BLOCK, lds)
                   : count      ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_pool<BLOCK, WAVES, LDSTAB, RING, true, TEX, ADAPT, RINGMEM, false>, BLOCK, lds)
                                : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_pool<BLOCK, WAVES, LDSTAB, RING, false, TEX, ADAPT, RINGMEM, false>, BLOCK, lds);
     if (oe != hipSuccess || per_cu < 1) per_cu = 1;
     per_cu = std::min(per_cu, 8);
-    if (const char * e = getenv("PRT_POOL_BLOCKS_PER_CU")) per_cu = std::max(1, std::min(per_cu, atoi(e)));
-    if (getenv("PRT_DEBUG_UTIL")) fprintf(stderr, "[prt] k_pool<%d,%d,%d>: %d blocks per CU\n", BLOCK, WAVES, (int)LDSTAB, per_cu);
+    if (opt.pool_blocks_per_cu >= 0) per_cu = std::max(1, std::min(per_cu, (int)opt.pool_blocks_per_cu));
+    if (opt.debug_util) fprintf(stderr, "[prt] k_pool<%d,%d,%d>: %d blocks per CU\n", BLOCK, WAVES, (int)LDSTAB, per_cu);
     const unsigned int max_blocks = (unsigned int)per_cu * (unsigned int)ctx->cu_count;
     const unsigned int grid = std::max(1u, std::min(max_blocks, (n_samples + BLOCK - 1) / BLOCK));
     const unsigned int waves = grid * (BLOCK / 64);
@@ -514,7 +542,7 @@ int launch_pool(prt_ctx * ctx, bool count, const DevCamera & cam, DevParams P, u
     // smaller pools leave more of the frame on the counter for the waves whose pixels end early (C4: 512 slots 195 ms,
     // 256 168 ms, 64 - 192 161 - 164 ms, profiles/r02_adaptive_pool_capacity.txt)
     if (ADAPT) cap = std::min(cap, 192u);
-    if (const char * e = getenv("PRT_POOL_CAP")) cap = (unsigned int)std::max(64, std::min(4096, atoi(e) / 64 * 64));
+    if (opt.pool_cap >= 0) cap = (unsigned int)std::max(64ll, std::min(4096ll, opt.pool_cap / 64 * 64));
     const unsigned int n_lights = std::max(1u, ctx->scene.light_count);
     const unsigned int scap = cap * n_lights;
 
@@ -530,14 +558,25 @@ int launch_pool(prt_ctx * ctx, bool count, const DevCamera & cam, DevParams P, u
     // Park lists: sized for what scenes with coincident geometry need in practice, never for the worst case (every sample's
     // ray parked: 48 bytes x samples x (1 + lights)).  The kernels count what they could not store; render_pixels looks at
     // the counts after the frame and, if a list was too short, enlarges it and renders the frame again.
-    const size_t park_cap = std::min<size_t>(ctx->pool_park_cap, N + (ADAPT ? N : 0)), spark_cap = std::min<size_t>(ctx->pool_spark_cap, N * n_lights);
+    // The clamps are the true worst cases: a sample is parked at most once (it leaves the pool) plus, in adaptive mode, one
+    // deferred finalise step per pixel; parked SHADOW rays pile up until the fast kernel has ended, and every shaded hit of a
+    // sample's bounce tree - up to sum over levels of (reflection + specular samples)^level of them - emits one per light.
+    size_t hits_per_sample = 1, level_nodes = 1;
+    for (unsigned int l = 0; l < P.bounce_depth && hits_per_sample < (1u << 20); ++l) {
+        level_nodes *= std::max<size_t>(1, (size_t)P.reflection_samples + P.spec_samples);
+        hits_per_sample += level_nodes;
+    }
+    const size_t worst_spark = N * n_lights * std::min<size_t>(hits_per_sample, 1u << 20);
+    const size_t park_cap = std::min<size_t>(ctx->pool_park_cap, N + (ADAPT ? N : 0)), spark_cap = std::min<size_t>(ctx->pool_spark_cap, worst_spark);
+    ctx->park_cap_used = park_cap;
+    ctx->spark_cap_used = spark_cap;
     HIP_TRY(ctx, ctx->pool_park.ensure(3 * (park_cap + spark_cap)));
     // the EXACT launch's lanes continue their LDS stack columns in memory; k_pool_parked_shadows has full-height columns
     const unsigned int grid2 = exact_only ? grid : std::max(1u, std::min(grid, (unsigned int)ctx->cu_count));
     const size_t exact_lanes = (size_t)POOL_PARKED_SHADOW_BLOCKS * 256, spill_lanes = (size_t)grid2 * BLOCK;
     const size_t spill_entries = ctx->stack_bound > stack_entries ? ctx->stack_bound - stack_entries : 0;
-    const size_t exact_ints = (size_t)std::max(ctx->stack_bound, 4u) * exact_lanes;
-    HIP_TRY(ctx, ctx->stack_spill.ensure(exact_ints + spill_entries * spill_lanes));
+    const size_t exact_ints = (size_t)std::max(ctx->stack_bound, 4u) * exact_lanes * STACK_ENTRY_INTS;
+    HIP_TRY(ctx, ctx->stack_spill.ensure(exact_ints + spill_entries * spill_lanes * STACK_ENTRY_INTS));
     P.exact_stack = ctx->stack_spill.p;
     P.exact_stack_stride = (unsigned int)exact_lanes;
     P.stack_spill = spill_entries ? ctx->stack_spill.p + exact_ints : nullptr;
@@ -579,10 +618,10 @@ int launch_pool(prt_ctx * ctx, bool count, const DevCamera & cam, DevParams P, u
         Q.final_rgb = Q.jobsum + N;
     }
     Q.topup_min = ADAPT ? std::max(64u, cap / 2u) : std::max(64u, cap / 4u);
-    if (const char * e = getenv("PRT_POOL_TOPUP")) Q.topup_min = (unsigned int)std::max(1, std::min((int)cap, atoi(e)));
+    if (opt.pool_topup >= 0) Q.topup_min = (unsigned int)std::max(1ll, std::min((long long)cap, opt.pool_topup));
     int keep_min = 40, node_min = 32;
-    if (const char * e = getenv("PRT_KEEP_MIN")) keep_min = std::max(1, std::min(64, atoi(e)));
-    if (const char * e = getenv("PRT_NODE_MIN")) node_min = std::max(0, std::min(64, atoi(e)));
+    if (opt.keep_min >= 0) keep_min = std::max(1, std::min(64, (int)opt.keep_min));
+    if (opt.node_min >= 0) node_min = std::max(0, std::min(64, (int)opt.node_min));
     const int multi_light = ctx->scene.light_count > 1 ? 1 : 0;
     PoolArgs A;
     memset(&A, 0, sizeof(A));
@@ -594,7 +633,7 @@ int launch_pool(prt_ctx * ctx, bool count, const DevCamera & cam, DevParams P, u
     A.keep_min = keep_min;
     A.node_min = node_min;
     A.node_frac = 4;
-    if (const char * e = getenv("PRT_NODE_FRAC")) A.node_frac = std::max(0, std::min(8, atoi(e)));
+    if (opt.node_frac >= 0) A.node_frac = std::max(0, std::min(8, (int)opt.node_frac));
     A.multi_light = multi_light;
     HIP_TRY(ctx, ctx->pool_args.ensure(2));
     hipLaunchKernelGGL(k_pool_store_args, dim3(1), dim3(64), 0, ctx->stream, A, ctx->pool_args.p, ctx->wf_counts.p, 16u,
@@ -637,7 +676,7 @@ void launch_resolve(hipStream_t stream, const void * samples, bool fixed, float4
 }
 
 // GPU radix-tree build + host collapse / quantise.  verts: 9 floats per triangle.
-int build_bvh_lbvh(prt_ctx * ctx, const float * verts, uint32_t n_tris, uint32_t leaf_max, Bvh4Result * bvh) {
+int build_bvh_lbvh(prt_ctx * ctx, const float * verts, uint32_t n_tris, uint32_t leaf_max, BvhWide * bvh) {
     float lo[3] = { 0, 0, 0 }, hi[3] = { 0, 0, 0 };
     for (uint32_t i = 0; i < n_tris * 3u; ++i)
         for (int a = 0; a < 3; ++a) {
@@ -648,9 +687,9 @@ int build_bvh_lbvh(prt_ctx * ctx, const float * verts, uint32_t n_tris, uint32_t
     LbvhTree tree;
     double device_ms = 0.0;
     HIP_TRY(ctx, build_lbvh_tree(verts, n_tris, lo, hi, ctx->stream, &tree, &device_ms));
-    build_bvh4q_from_radix_tree(n_tris, leaf_max, tree.left.data(), tree.right.data(), tree.first.data(), tree.last.data(),
-                                tree.node_box.data(), tree.leaf_box.data(), tree.sorted_ids.data(), bvh);
-    if (getenv("PRT_DEBUG_UTIL")) fprintf(stderr, "[prt] LBVH: %u triangles, radix tree on the device in %.2f ms\n", n_tris, device_ms);
+    PRT_BUILD_WIDE_FROM_RADIX(n_tris, leaf_max, tree.left.data(), tree.right.data(), tree.first.data(), tree.last.data(),
+                              tree.node_box.data(), tree.leaf_box.data(), tree.sorted_ids.data(), bvh, &ctx->opt.bvh);
+    if (ctx->opt.debug_util) fprintf(stderr, "[prt] LBVH: %u triangles, radix tree on the device in %.2f ms\n", n_tris, device_ms);
     return 0;
 }
 
@@ -709,10 +748,12 @@ int render_pixels_once(prt_ctx * ctx, const prt_camera * cam_in, const prt_param
     P.shard_rank = px.rank;
     P.shard_nranks = std::max(1u, px.nranks);
     P.pixel_list = px.d_pixel_list;
-    P.elide_dead_shadow_rays = getenv("PRT_TRACE_DEAD_SHADOW_RAYS") ? 0u : 1u;
+    const PrtOptions & opt = ctx->opt;
+    ctx->scene.tie_widen_max = (unsigned int)std::max(0ll, std::min(64ll, opt.tie_widen_max));
+    P.elide_dead_shadow_rays = opt.trace_dead_shadow_rays ? 0u : 1u;
     // tiled work order: sets made of full-width rows only (a whole frame or a range that starts at a row, row-block shards)
     P.tile_pixels = 0;
-    if (!px.d_pixel_list && width % 8u == 0u && !getenv("PRT_NO_TILES")) {
+    if (!px.d_pixel_list && width % 8u == 0u && !opt.no_tiles) {
         const bool rows = px.nranks > 1 ? std::max(1u, px.block_rows) % 8u == 0u : px.first_pixel % width == 0u;
         if (rows) P.tile_pixels = px.n_pixels / (8u * width) * (8u * width);
     }
@@ -742,9 +783,8 @@ int render_pixels_once(prt_ctx * ctx, const prt_camera * cam_in, const prt_param
         // that range - and always when PRT_POOL_MAX_SAMPLES is set - the size decides.  (Below 1 M samples: pool.)
         // The try-out is opt-in (PRT_FLAG_TRYOUT): without it DEFAULT is the pool pipeline.
         const unsigned long long ns = (unsigned long long)px.n_pixels * params->spp;
-        const char * forced = getenv("PRT_POOL_MAX_SAMPLES");
-        if (forced) {
-            pipeline = ns <= strtoull(forced, nullptr, 10) ? PRT_PIPELINE_POOL : PRT_PIPELINE_WAVEFRONT;
+        if (opt.pool_max_samples >= 0) {
+            pipeline = ns <= (unsigned long long)opt.pool_max_samples ? PRT_PIPELINE_POOL : PRT_PIPELINE_WAVEFRONT;
         } else if (!(params->pipeline & PRT_FLAG_TRYOUT) || ns <= (1ull << 20)) {
             pipeline = PRT_PIPELINE_POOL;       // no try-out asked for (a one-off render would pay for it five-fold), or too small to matter
         } else {
@@ -777,7 +817,7 @@ int render_pixels_once(prt_ctx * ctx, const prt_camera * cam_in, const prt_param
                 e.pipeline = ms[0] <= 0.97 * ms[1] ? PRT_PIPELINE_POOL : PRT_PIPELINE_WAVEFRONT;
                 if (ctx->tuned.size() >= 64) ctx->tuned.erase(ctx->tuned.begin());
                 ctx->tuned.push_back(e);
-                if (getenv("PRT_DEBUG_UTIL")) fprintf(stderr, "[prt] default pipeline try-out: pool %.3f ms, wavefront %.3f ms\n", ms[0], ms[1]);
+                if (opt.debug_util) fprintf(stderr, "[prt] default pipeline try-out: pool %.3f ms, wavefront %.3f ms\n", ms[0], ms[1]);
                 // the call itself is then served by the winner like every later one, so that the counters (pipeline, kernel
                 // times) describe the pipeline this configuration will keep
                 (void)whole;
@@ -786,6 +826,12 @@ int render_pixels_once(prt_ctx * ctx, const prt_camera * cam_in, const prt_param
         }
     }
     if (pipeline != PRT_PIPELINE_MEGAKERNEL && pipeline != PRT_PIPELINE_WAVEFRONT && pipeline != PRT_PIPELINE_PERSISTENT && pipeline != PRT_PIPELINE_POOL) { ctx->error = "prt_render: unknown pipeline"; return -1; }
+#if !defined(PRT_EXPERIMENTAL)
+    if (pipeline == PRT_PIPELINE_MEGAKERNEL || pipeline == PRT_PIPELINE_PERSISTENT) {
+        ctx->error = "prt_render: the experimental pipelines (MEGAKERNEL, PERSISTENT) are not built into this library (make hip-experimental)";
+        return -1;
+    }
+#endif
     if (ctx->textured && (pipeline == PRT_PIPELINE_MEGAKERNEL || pipeline == PRT_PIPELINE_PERSISTENT)) {
         ctx->error = "prt_render: textured scenes run on PRT_PIPELINE_WAVEFRONT / PRT_PIPELINE_POOL (or DEFAULT) only";
         return -1;
@@ -825,8 +871,8 @@ int render_pixels_once(prt_ctx * ctx, const prt_camera * cam_in, const prt_param
                 max_mb = std::max(1024ull, std::min(max_mb, budget_mb));
             }
         }
-        if (const char * e = getenv("PRT_PASS_SAMPLES")) max_samples = std::max(1ull, strtoull(e, nullptr, 10));
-        if (const char * e = getenv("PRT_PASS_MB")) max_mb = std::max(1ull, strtoull(e, nullptr, 10));
+        if (opt.pass_samples >= 0) max_samples = std::max(1ull, (unsigned long long)opt.pass_samples);
+        if (opt.pass_mb >= 0) max_mb = std::max(1ull, (unsigned long long)opt.pass_mb);
         max_samples = std::min(max_samples, std::max(1ull, (max_mb << 20) / per_sample));
         max_samples = std::min(max_samples, 0x7FFFFFFFull);
         if (total_samples > max_samples) {
@@ -845,10 +891,10 @@ int render_pixels_once(prt_ctx * ctx, const prt_camera * cam_in, const prt_param
     // - 3 pushes per 4-wide level are possible, nothing real comes close - lives in a per-lane global column behind it
     // (dev_trace.h LdsStack).
     constexpr int BLOCK = 256;
-    unsigned int stack_cap = 24;
-    if (const char * e = getenv("PRT_STACK_CAP")) stack_cap = (unsigned int)std::max(2, std::min(40, atoi(e)));   // test hook: force the spill area into use
+    unsigned int stack_cap = STACK_LDS_CAP_DEFAULT;
+    if (opt.stack_cap >= 0) stack_cap = (unsigned int)std::max(2ll, std::min(40ll, opt.stack_cap));   // test hook: force the spill area into use
     const unsigned int stack_entries = std::min(ctx->stack_bound, stack_cap);
-    const size_t lds = (size_t)stack_entries * BLOCK * sizeof(int);
+    const size_t lds = (size_t)stack_entries * BLOCK * sizeof(int) * STACK_ENTRY_INTS;
     P.stack_lds_entries = stack_entries;
     P.stack_spill = nullptr;
     P.stack_spill_stride = 0;
@@ -863,7 +909,7 @@ int render_pixels_once(prt_ctx * ctx, const prt_camera * cam_in, const prt_param
                                                                        : 0;                      // wavefront: per chain, see chain_setup
         if (spill_entries && spill_lanes) {
             if (spill_lanes >= (1ull << 32)) { ctx->error = "prt_render: too many lanes for the stack spill area"; return -1; }
-            HIP_TRY(ctx, ctx->stack_spill.ensure((size_t)spill_entries * spill_lanes));
+            HIP_TRY(ctx, ctx->stack_spill.ensure((size_t)spill_entries * spill_lanes * STACK_ENTRY_INTS));
             P.stack_spill = ctx->stack_spill.p;
             P.stack_spill_stride = (unsigned int)spill_lanes;
         }
@@ -882,6 +928,7 @@ int render_pixels_once(prt_ctx * ctx, const prt_camera * cam_in, const prt_param
         P.local_base = p0;
         if (single_launch) HIP_TRY(ctx, hipEventRecord(ctx->ev[2], stream));
         int rc = 0;
+#if defined(PRT_EXPERIMENTAL)
         if (pipeline == PRT_PIPELINE_MEGAKERNEL) {
             const unsigned int grid = (n_samples + BLOCK - 1) / BLOCK;
             if (!ring && levels <= 3) launch_mega<3, false>(ctx, count_visits, grid, lds, cam, P, n_samples);
@@ -892,15 +939,17 @@ int render_pixels_once(prt_ctx * ctx, const prt_camera * cam_in, const prt_param
             HIP_TRY(ctx, ctx->wf_counts.ensure(16));
             HIP_TRY(ctx, hipMemsetAsync(ctx->wf_counts.p, 0, 16, stream));
             int keep_min = 40, node_min = 32;
-            if (const char * e = getenv("PRT_KEEP_MIN")) keep_min = std::max(1, std::min(64, atoi(e)));
-            if (const char * e = getenv("PRT_NODE_MIN")) node_min = std::max(0, std::min(64, atoi(e)));
+            if (opt.keep_min >= 0) keep_min = std::max(1, std::min(64, (int)opt.keep_min));
+            if (opt.node_min >= 0) node_min = std::max(0, std::min(64, (int)opt.node_min));
             int blocks_cap = 8;
-            if (const char * e = getenv("PRT_TRACE_BLOCKS_PER_CU")) blocks_cap = std::max(1, std::min(8, atoi(e)));
+            if (opt.trace_blocks_per_cu >= 0) blocks_cap = std::max(1, std::min(8, (int)opt.trace_blocks_per_cu));
             if (!ring && levels <= 3) rc = launch_persistent<3, false>(ctx, count_visits, lds, cam, P, n_samples, keep_min, node_min, blocks_cap);
             else if (levels <= 9) rc = launch_persistent<9, true>(ctx, count_visits, lds, cam, P, n_samples, keep_min, node_min, blocks_cap);
             else rc = launch_persistent<17, true>(ctx, count_visits, lds, cam, P, n_samples, keep_min, node_min, blocks_cap);
             launches += 1;
-        } else if (pipeline == PRT_PIPELINE_POOL) {
+        } else
+#endif
+        if (pipeline == PRT_PIPELINE_POOL) {
             // 256-thread blocks, the Hammersley direction table in global memory (staging it in LDS measured 17.04 vs 17.15 ms:
             // nothing).  Small blocks retire - and let the blocks of the next frame's kernel in - at a finer grain: with two
             // frames in flight a 1/8-frame shard takes 2.24 ms per frame instead of 2.59 with 512-thread blocks.
@@ -948,23 +997,29 @@ int render_pixels_once(prt_ctx * ctx, const prt_camera * cam_in, const prt_param
     HIP_TRY(ctx, hipEventSynchronize(ctx->ev[1]));
 
     *park_overflow = false;
-    if (counters || pipeline == PRT_PIPELINE_POOL) {
-        DevCounters h;
-        HIP_TRY(ctx, hipMemcpy(&h, ctx->counters.p, sizeof(h), hipMemcpyDeviceToHost));
-        if (pipeline == PRT_PIPELINE_POOL && (h.park_peak[0] > ctx->pool_park_cap || h.park_peak[1] > ctx->pool_spark_cap)) {
-            // a park list was too short for this frame (kernels_pool.h PoolBuffers::park): rays were dropped.  Longer lists,
-            // then the caller renders the frame again.  The lists are never longer than launch_pool's worst-case clamp.
-            if (getenv("PRT_DEBUG_UTIL")) fprintf(stderr, "[prt] park lists too short (%llu of %zu rays, %llu of %zu shadow rays): enlarging\n",
-                                                    (unsigned long long)h.park_peak[0], ctx->pool_park_cap, (unsigned long long)h.park_peak[1], ctx->pool_spark_cap);
-            ctx->pool_park_cap = std::max<size_t>(ctx->pool_park_cap, (size_t)h.park_peak[0] + (size_t)h.park_peak[0] / 2);
-            ctx->pool_spark_cap = std::max<size_t>(ctx->pool_spark_cap, (size_t)h.park_peak[1] + (size_t)h.park_peak[1] / 2);
-            *park_overflow = true;
-            return 0;
-        }
+    DevCounters h;
+    HIP_TRY(ctx, hipMemcpy(&h, ctx->counters.p, sizeof(h), hipMemcpyDeviceToHost));
+    if (pipeline == PRT_PIPELINE_POOL && (h.park_peak[0] > ctx->park_cap_used || h.park_peak[1] > ctx->spark_cap_used)) {
+        // a park list was too short for this frame (kernels_pool.h PoolBuffers::park): rays were dropped.  Longer lists, then
+        // the caller renders the frame again.  The peaks are compared with what launch_pool really gave the lists - the
+        // context's capacity clamped to the frame's worst case - so a peak above them always finds room the next time.
+        if (opt.debug_util) fprintf(stderr, "[prt] park lists too short (%llu of %zu rays, %llu of %zu shadow rays): enlarging\n",
+                                    (unsigned long long)h.park_peak[0], ctx->park_cap_used, (unsigned long long)h.park_peak[1], ctx->spark_cap_used);
+        ctx->pool_park_cap = std::max<size_t>(ctx->pool_park_cap, (size_t)h.park_peak[0] + (size_t)h.park_peak[0] / 2);
+        ctx->pool_spark_cap = std::max<size_t>(ctx->pool_spark_cap, (size_t)h.park_peak[1] + (size_t)h.park_peak[1] / 2);
+        *park_overflow = true;
+        return 0;
+    }
+    if (h.near_tie_unresolved) {
+        // resolve_near_ties ran out of widenings (dev_trace8.h): some hit among near-coincident candidates was decided over an
+        // incomplete candidate set.  Never seen on real geometry; reported, not hidden.
+        char msg[160];
+        snprintf(msg, sizeof(msg), "prt_render: %llu near-tied hits could not be resolved within %lld widenings of the candidate set",
+                 (unsigned long long)h.near_tie_unresolved, opt.tie_widen_max);
+        ctx->error = msg;
+        return -8;
     }
     if (counters) {
-        DevCounters h;
-        HIP_TRY(ctx, hipMemcpy(&h, ctx->counters.p, sizeof(h), hipMemcpyDeviceToHost));
         {
             prt_render_stats & rs = ctx->last_stats;
             memset(&rs, 0, sizeof(rs));
@@ -981,29 +1036,29 @@ int render_pixels_once(prt_ctx * ctx, const prt_camera * cam_in, const prt_param
         HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
         if (pipeline == PRT_PIPELINE_WAVEFRONT) h.ray_count = host_ray_count;      // every queued ray is one TraceRay call
         else host_ray_count = h.ray_count;
-        if (getenv("PRT_DEBUG_UTIL") && h.wave_node_steps)
+        if (opt.debug_util && h.wave_node_steps)
             fprintf(stderr, "[prt] lane utilisation: node loop %.1f%% (%llu wave steps), triangle tests %.1f%% (%llu wave steps, %llu leaf visits), %llu refills (%.1f rays each)\n",
                     100.0 * (double)h.node_visits / (64.0 * (double)h.wave_node_steps), (unsigned long long)h.wave_node_steps,
                     100.0 * (double)h.tri_tests / (64.0 * (double)h.wave_tri_steps), (unsigned long long)h.wave_tri_steps,
                     (unsigned long long)h.wave_leaf_steps, (unsigned long long)h.wave_refills,
                     h.wave_refills ? (double)host_ray_count / (double)h.wave_refills : 0.0);
-        if (getenv("PRT_DEBUG_UTIL") && h.wave_node_step_rays)
+        if (opt.debug_util && h.wave_node_step_rays)
             fprintf(stderr, "[prt] k_pool node loop, lane slots per wave step: %.1f%% walking, %.1f%% holding a ray but not walking (at a leaf, or done), %.1f%% without a ray\n",
                     100.0 * (double)h.node_visits / (64.0 * (double)h.wave_node_steps),
                     100.0 * ((double)h.wave_node_step_rays - (double)h.node_visits) / (64.0 * (double)h.wave_node_steps),
                     100.0 * (64.0 * (double)h.wave_node_steps - (double)h.wave_node_step_rays) / (64.0 * (double)h.wave_node_steps));
-        if (getenv("PRT_DEBUG_UTIL") && h.phase_cycles[3])
+        if (opt.debug_util && h.phase_cycles[3])
             fprintf(stderr, "[prt] k_pool wave time by phase: top-up %.1f%%, trace %.1f%%, shade %.1f%% of the main loop\n",
                     100.0 * (double)h.phase_cycles[0] / (double)h.phase_cycles[3], 100.0 * (double)h.phase_cycles[1] / (double)h.phase_cycles[3],
                     100.0 * (double)h.phase_cycles[2] / (double)h.phase_cycles[3]);
-        if (getenv("PRT_DEBUG_UTIL") && h.wave_count)
+        if (opt.debug_util && h.wave_count)
             fprintf(stderr, "[prt] k_pool waves: %llu, main loop mean %.3f of the longest wave's (what the others idle at the end of the frame: %.1f%%)\n",
                     (unsigned long long)h.wave_count, (double)h.wave_cycles_sum / (double)h.wave_count / (double)h.wave_cycles_max,
                     100.0 * (1.0 - (double)h.wave_cycles_sum / (double)h.wave_count / (double)h.wave_cycles_max));
-        if (getenv("PRT_DEBUG_UTIL") && h.phase_cycles[3] && h.phase_cycles[4])
+        if (opt.debug_util && h.phase_cycles[3] && h.phase_cycles[4])
             fprintf(stderr, "[prt] k_pool adaptive finalise step (store the sample, variance rule, next camera ray): %.1f%% of the main loop\n",
                     100.0 * (double)h.phase_cycles[4] / (double)h.phase_cycles[3]);
-        if (getenv("PRT_DEBUG_UTIL") && h.wave_node_steps)
+        if (opt.debug_util && h.wave_node_steps)
             fprintf(stderr, "[prt] deepest stack %llu entries (LDS column %u, bound %u); %llu of %llu node visits (%.1f%%) hit no child after a hit was known\n",
                     (unsigned long long)h.max_sp, stack_entries, ctx->stack_bound, (unsigned long long)h.culled,
                     (unsigned long long)h.node_visits, 100.0 * (double)h.culled / (double)h.node_visits);
@@ -1038,6 +1093,17 @@ extern "C" {
 
 int prt_abi_version(void) { return PRT_ABI_VERSION; }
 
+int prt_build_flags(void) {
+    int f = 0;
+#if defined(PRT_EXPERIMENTAL)
+    f |= PRT_BUILD_EXPERIMENTAL;
+#endif
+#if defined(PRT_BVH4)
+    f |= PRT_BUILD_BVH4;
+#endif
+    return f;
+}
+
 const char * prt_last_error(const prt_ctx * ctx) { return ctx ? ctx->error.c_str() : g_create_error.c_str(); }
 
 prt_ctx * prt_create(int device_id) {
@@ -1065,14 +1131,14 @@ prt_ctx * prt_create(int device_id) {
     memset(&ctx->scene, 0, sizeof(ctx->scene));
     memset(&ctx->info, 0, sizeof(ctx->info));
     memset(&ctx->last_stats, 0, sizeof(ctx->last_stats));
+    prt_options_from_env(ctx->opt);       // the environment is read here and nowhere else
     // PRT_RESERVE_CUS=k (multi-GPU callers): the context's streams are created with a CU mask that leaves the last k compute
     // units to others - the RCCL gather of the previous frame must not wait for a wave slot while this context's persistent
     // kernels hold every one of theirs (bench.py sets it for N > 1 with frames in flight).  The persistent grids are sized
     // for the CUs that are left.
     std::vector<uint32_t> cu_mask;
     {
-        const char * rs = getenv("PRT_RESERVE_CUS");
-        const int reserve = rs ? atoi(rs) : 0;
+        const int reserve = (int)ctx->opt.reserve_cus;
         if (reserve > 0 && reserve < ctx->cu_count) {
             cu_mask.assign((size_t)(ctx->cu_count + 31) / 32, 0u);
             for (int cu = 0; cu < ctx->cu_count - reserve; ++cu) cu_mask[(size_t)cu >> 5] |= 1u << (cu & 31);
@@ -1087,7 +1153,8 @@ prt_ctx * prt_create(int device_id) {
     e = make_stream(&ctx->stream);
     for (int i = 0; i < 4 && e == hipSuccess; ++i) e = hipEventCreate(&ctx->ev[i]);
     ctx->chain[0].stream = ctx->stream;
-    if (const char * pc = getenv("PRT_POOL_PARK_CAP")) ctx->pool_park_cap = ctx->pool_spark_cap = (size_t)std::max(1, atoi(pc));   // tests: start tiny, grow
+    if (ctx->opt.pool_park_cap >= 0) ctx->pool_park_cap = ctx->pool_spark_cap = (size_t)std::max(1ll, ctx->opt.pool_park_cap);   // tests: start tiny, grow
+    if (e == hipSuccess) e = ctx->counters.ensure(1);          // DevScene::near_tie_unresolved points into it
     for (int c = 1; c < PRT_MAX_CHAINS && e == hipSuccess; ++c) e = make_stream(&ctx->chain[c].stream);
     for (int c = 0; c < PRT_MAX_CHAINS && e == hipSuccess; ++c) {
         prt_ctx::ChainWs & w = ctx->chain[c];
@@ -1113,6 +1180,7 @@ void prt_destroy(prt_ctx * ctx) {
     ctx->tri_rank.release(); ctx->materials.release(); ctx->lights.release();
     ctx->sample_rgb.release(); ctx->frame_out.release(); ctx->counters.release(); ctx->ring_ws.release(); ctx->pixel_list.release(); ctx->wf_counts.release(); ctx->stack_spill.release(); ctx->pool_f4.release(); ctx->pool_park.release(); ctx->pool_fin.release(); ctx->pool_args.release(); ctx->adapt_f4.release();
     ctx->textures.release(); ctx->texels.release(); ctx->srgb_lut.release(); ctx->tri_uv.release(); ctx->tri_tan.release();
+    ctx->ref_spheres.release();
     for (int c = 0; c < PRT_MAX_CHAINS; ++c) {
         prt_ctx::ChainWs & w = ctx->chain[c];
         w.f4.release(); w.rng.release(); w.counts.release(); w.overflow.release(); w.slow_stack.release();
@@ -1126,6 +1194,19 @@ void prt_destroy(prt_ctx * ctx) {
     for (int i = 0; i < 4; ++i) if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
+}
+
+int prt_set_option(prt_ctx * ctx, const char * name, const char * value) {
+    if (!ctx || !name) return -1;
+    const char * bare = !strncasecmp(name, "PRT_", 4) ? name + 4 : name;
+    if (!strcasecmp(bare, "RESERVE_CUS")) { ctx->error = "prt_set_option: RESERVE_CUS shapes the context's streams and is read at creation only (environment PRT_RESERVE_CUS)"; return -1; }
+    if (prt_option_set(ctx->opt, bare, value)) { ctx->error = std::string("prt_set_option: unknown option or bad value: ") + name; return -1; }
+    ctx->opt.bvh.debug = ctx->opt.debug_util;
+    if (!strcasecmp(bare, "POOL_PARK_CAP")) {
+        ctx->pool_park_cap = ctx->pool_spark_cap = ctx->opt.pool_park_cap >= 0 ? (size_t)std::max(1ll, ctx->opt.pool_park_cap) : (size_t)1 << 18;
+    }
+    ctx->tuned.clear();                 // a knob may change which pipeline wins the try-out
+    return 0;
 }
 
 int prt_get_render_stats(const prt_ctx * ctx, prt_render_stats * stats) {
@@ -1192,36 +1273,40 @@ int prt_upload_scene(prt_ctx * ctx, const prt_scene_desc * s) {
         for (int c = 0; c < 3; ++c) memcpy(&verts[(size_t)t * 9 + 3 * c], s->positions + 3 * (size_t)s->idx_positions[3 * t + c], 12);
     for (size_t i = 0; i < verts.size(); ++i)
         if (!(fabsf(verts[i]) < 1e18f)) { ctx->error = "prt_upload_scene: vertex coordinate is not finite or exceeds 1e18"; return -1; }
-    Bvh4Result bvh;
+    BvhWide bvh;
     unsigned int hw = std::max(1u, std::thread::hardware_concurrency());
     unsigned int leaf_max = BVH_LEAF_MAX;
-    if (const char * e = getenv("PRT_LEAF_MAX")) leaf_max = (unsigned int)std::max(1, std::min(4, atoi(e)));   // experiment knob
-    float trav_cost = 1.0f;
-    if (const char * e = getenv("PRT_SAH_TRAV_COST")) trav_cost = (float)atof(e);                             // experiment knob
-    const char * builder = getenv("PRT_BVH_BUILDER");
-    if (builder && !strcmp(builder, "lbvh")) {
-        // fast build for scenes that change every frame: radix tree on the GPU (bvh_lbvh.h), same 4-wide quantised back end
+    if (ctx->opt.leaf_max >= 0) leaf_max = (unsigned int)std::max(1ll, std::min(4ll, ctx->opt.leaf_max));   // experiment knob
+    const float trav_cost = (float)ctx->opt.sah_trav_cost;                                                  // experiment knob
+    if (ctx->opt.bvh_builder_lbvh) {
+        // fast build for scenes that change every frame: radix tree on the GPU (bvh_lbvh.h), same quantised wide back end
         int rc = build_bvh_lbvh(ctx, verts.data(), n_tris, leaf_max, &bvh);
         if (rc) return rc;
     } else {
-        build_bvh4q(verts.data(), n_tris, leaf_max, std::min(hw, 16u), &bvh, trav_cost);
+        PRT_BUILD_WIDE(verts.data(), n_tris, leaf_max, std::min(hw, 16u), &bvh, trav_cost, &ctx->opt.bvh);
     }
     double build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
 
     // ---- reference visit rank: leaves of the sphere tree in the order TraceRay pops them (c1 first)
     std::vector<uint32_t> rank_of_input(n_tris);
+    std::vector<float4> ref_spheres;                          // (centre, radius) (c0, c1, first rank of c0's triangles, pop order)
     {
         std::vector<uint32_t> group_base(s->group_count, 0);
         bool ranked = false;
         if (s->spheres && s->sphere_group && s->sphere_count) {
             std::vector<uint32_t> stack(1, 0u);
             std::vector<uint8_t> seen(s->group_count, 0);
+            std::vector<uint32_t> first_rank(s->sphere_count, 0), pop_order(s->sphere_count, 0);
+            std::vector<uint8_t> popped(s->sphere_count, 0);
             uint32_t next = 0, visited = 0;
             bool ok = true;
             while (!stack.empty() && ok) {
                 uint32_t i = stack.back();
                 stack.pop_back();
-                if (i >= s->sphere_count || ++visited > 2 * s->sphere_count) { ok = false; break; }
+                if (i >= s->sphere_count || ++visited > 2 * s->sphere_count || popped[i]) { ok = false; break; }
+                popped[i] = 1;
+                pop_order[i] = visited - 1;
+                first_rank[i] = next;                         // the first triangle the reference meets below this sphere
                 const prt_bsphere & bs = s->spheres[i];
                 if (bs.c0 && bs.c1) {
                     stack.push_back(bs.c0);
@@ -1235,6 +1320,18 @@ int prt_upload_scene(prt_ctx * ctx, const prt_scene_desc * s) {
                 }
             }
             ranked = ok && next == n_tris;
+            if (ranked) {
+                ref_spheres.resize(2 * (size_t)s->sphere_count, make_float4(0, 0, 0, 0));
+                for (uint32_t i = 0; i < s->sphere_count; ++i) {
+                    const prt_bsphere & bs = s->spheres[i];
+                    ref_spheres[2 * (size_t)i] = make_float4(bs.center[0], bs.center[1], bs.center[2], bs.radius);
+                    const bool inner = bs.c0 && bs.c1 && popped[i];
+                    const uint32_t w[4] = { inner ? bs.c0 : 0u, inner ? bs.c1 : 0u, inner ? first_rank[bs.c0] : 0u, pop_order[i] };
+                    float4 f;
+                    memcpy(&f, w, 16);
+                    ref_spheres[2 * (size_t)i + 1] = f;
+                }
+            }
         }
         if (ranked) {
             for (uint32_t g = 0; g < s->group_count; ++g) {
@@ -1367,6 +1464,7 @@ int prt_upload_scene(prt_ctx * ctx, const prt_scene_desc * s) {
     HIP_TRY(ctx, ctx->materials.upload(mats));
     HIP_TRY(ctx, ctx->lights.upload(lights));
     HIP_TRY(ctx, ctx->diffuse_dirs.upload(ddirs));
+    if (!ref_spheres.empty()) HIP_TRY(ctx, ctx->ref_spheres.upload(ref_spheres));
     ctx->textured = textured;
     if (textured) {
         HIP_TRY(ctx, ctx->textures.upload(dev_tex));
@@ -1393,6 +1491,9 @@ int prt_upload_scene(prt_ctx * ctx, const prt_scene_desc * s) {
     sc.srgb_lut = textured ? ctx->srgb_lut.p : nullptr;
     sc.tri_uv = textured ? ctx->tri_uv.p : nullptr;
     sc.tri_tan = bumped ? ctx->tri_tan.p : nullptr;
+    sc.ref_spheres = ref_spheres.empty() ? nullptr : ctx->ref_spheres.p;
+    sc.tie_widen_max = 8;                                     // render_pixels_once sets the option's value per call
+    sc.near_tie_unresolved = &ctx->counters.p->near_tie_unresolved;
     ctx->spec_table_samples = 0;
     int rc = build_spec_table(ctx, 1);
     if (rc) return rc;
@@ -1402,13 +1503,13 @@ int prt_upload_scene(prt_ctx * ctx, const prt_scene_desc * s) {
     info.triangle_count = n_tris;
     info.bvh_node_count = bvh.node_count;
     info.bvh_max_depth = bvh.max_depth;
-    info.bvh_node_bytes = 64;
+    info.bvh_node_bytes = BVH_NODE_BYTES;
     info.tri_record_bytes = 48;
     info.shade_record_bytes = 64;
     info.device_bytes = ctx->nodes.bytes() + ctx->tris.bytes() + ctx->shade.bytes() + ctx->tri_rank.bytes() +
                         ctx->materials.bytes() + ctx->lights.bytes() + ctx->diffuse_dirs.bytes() + ctx->spec_dirs.bytes() +
                         (textured ? ctx->textures.bytes() + ctx->texels.bytes() + ctx->srgb_lut.bytes() + ctx->tri_uv.bytes() : 0) +
-                        (bumped ? ctx->tri_tan.bytes() : 0);
+                        (bumped ? ctx->tri_tan.bytes() : 0) + (ref_spheres.empty() ? 0 : ctx->ref_spheres.bytes());
     info.bvh_build_ms = build_ms;
     HIP_TRY(ctx, hipDeviceSynchronize());      // uploads went through the null stream; renders use the context's non-blocking streams
     ctx->has_scene = true;
@@ -1606,15 +1707,98 @@ static int check_bvh4q(const std::vector<float> & verts, uint32_t n_tris, const 
     return 0;
 }
 
+// The same for the 8-wide tree (bvh_build.h Bvh8Result): masks disjoint, empty slots inverted, scales positive powers of two,
+// implicit child / triangle addresses in range, every triangle inside every ancestor's box and in exactly one leaf.
+static int check_bvh8q(const std::vector<float> & verts, uint32_t n_tris, const Bvh8Result & bvh, uint64_t * out) {
+    uint64_t violations = 0, leaves = 0, refs = 0;
+    std::vector<uint8_t> seen(std::max(1u, n_tris), 0);
+    std::vector<uint8_t> node_seen(std::max(1u, bvh.node_count), 0);
+    struct Item { uint32_t node; float lo[3], hi[3]; };
+    std::vector<Item> stack;
+    Item root;
+    root.node = 0;
+    for (int a = 0; a < 3; ++a) { root.lo[a] = -3.0e38f; root.hi[a] = 3.0e38f; }
+    stack.push_back(root);
+    while (!stack.empty()) {
+        Item it = stack.back();
+        stack.pop_back();
+        if (it.node >= bvh.node_count) { violations++; continue; }
+        if (node_seen[it.node]++) { violations++; continue; }
+        const uint32_t * d = &bvh.nodes[(size_t)it.node * BVH8_NODE_DWORDS];
+        float org[3], scale[3];
+        const int scale_dword[3] = { 3, 6, 7 };
+        for (int a = 0; a < 3; ++a) {
+            memcpy(&org[a], &d[a], 4);
+            const uint32_t sb = d[scale_dword[a]] & 0x7F800000u;
+            memcpy(&scale[a], &sb, 4);
+            if (sb == 0u || (d[scale_dword[a]] & 0x80000000u)) violations++;      // a positive power of two
+        }
+        const uint32_t imask = d[3] & 0xFFu, lmask = d[3] >> 8 & 0xFFu, c0 = d[6] & 0xFFu, c1 = d[6] >> 8 & 0xFFu;
+        if (imask & lmask) violations++;
+        if ((c0 | c1) & ~lmask) violations++;
+        if (!(imask | lmask)) violations++;
+        uint32_t next_child = d[4], next_tri = d[5];
+        for (uint32_t sl = 0; sl < 8; ++sl) {
+            uint32_t qlo[3], qhi[3];
+            for (int a = 0; a < 3; ++a) {
+                qlo[a] = d[8 + 2 * a + (sl >> 2)] >> (8 * (sl & 3u)) & 0xFFu;
+                qhi[a] = d[14 + 2 * a + (sl >> 2)] >> (8 * (sl & 3u)) & 0xFFu;
+            }
+            if (!((imask | lmask) >> sl & 1u)) {
+                for (int a = 0; a < 3; ++a) if (qlo[a] != 255u || qhi[a] != 0u) violations++;
+                continue;
+            }
+            Item ch;
+            for (int a = 0; a < 3; ++a) {
+                ch.lo[a] = std::max(it.lo[a], org[a] + (float)qlo[a] * scale[a]);
+                ch.hi[a] = std::min(it.hi[a], org[a] + (float)qhi[a] * scale[a]);
+            }
+            if (imask >> sl & 1u) {
+                ch.node = next_child++;
+                stack.push_back(ch);
+            } else {
+                const uint32_t cnt = 1u + (c0 >> sl & 1u) + 2u * (c1 >> sl & 1u);
+                leaves++;
+                for (uint32_t i = 0; i < cnt; ++i) {
+                    const uint32_t slot = next_tri++;
+                    if (slot == n_tris && n_tris == 0) continue;        // the dummy triangle of an empty scene
+                    if (slot >= n_tris) { violations++; continue; }
+                    refs++;
+                    if (seen[slot]++) violations++;
+                    const uint32_t t = bvh.tri_order[slot];
+                    for (int c = 0; c < 3; ++c)
+                        for (int a = 0; a < 3; ++a) {
+                            const float v = verts[(size_t)t * 9 + 3 * c + a];
+                            const float tol = 4.0f * 1.1920929e-7f * std::max(1.0f, fabsf(v));
+                            if (v < ch.lo[a] - tol || v > ch.hi[a] + tol) violations++;
+                        }
+                }
+            }
+        }
+    }
+    for (uint32_t t = 0; t < n_tris; ++t) if (!seen[t]) violations++;
+    for (uint32_t n = 0; n < bvh.node_count; ++n) if (!node_seen[n]) violations++;
+    out[0] = violations; out[1] = bvh.node_count; out[2] = bvh.max_depth; out[3] = bvh.stack_bound; out[4] = leaves; out[5] = refs;
+    return 0;
+}
+
+#if defined(PRT_BVH4)
+static int check_bvh_wide(const std::vector<float> & verts, uint32_t n_tris, const BvhWide & bvh, uint64_t * out) { return check_bvh4q(verts, n_tris, bvh, out); }
+#else
+static int check_bvh_wide(const std::vector<float> & verts, uint32_t n_tris, const BvhWide & bvh, uint64_t * out) { return check_bvh8q(verts, n_tris, bvh, out); }
+#endif
+
 int prt_debug_check_bvh(const prt_scene_desc * s, uint64_t * out) {
     if (!s || !out || s->index_count % 3) return -1;
     const uint32_t n_tris = s->index_count / 3;
     std::vector<float> verts((size_t)n_tris * 9);
     for (uint32_t t = 0; t < n_tris; ++t)
         for (int c = 0; c < 3; ++c) memcpy(&verts[(size_t)t * 9 + 3 * c], s->positions + 3 * (size_t)s->idx_positions[3 * t + c], 12);
-    Bvh4Result bvh;
-    build_bvh4q(verts.data(), n_tris, BVH_LEAF_MAX, 4, &bvh);
-    return check_bvh4q(verts, n_tris, bvh, out);
+    PrtOptions opt;
+    prt_options_from_env(opt);                  // the test-suite selects the collapse rule through the environment
+    BvhWide bvh;
+    PRT_BUILD_WIDE(verts.data(), n_tris, BVH_LEAF_MAX, 4, &bvh, 1.0f, &opt.bvh);
+    return check_bvh_wide(verts, n_tris, bvh, out);
 }
 
 // The same check on the tree of the GPU LBVH builder (needs a context: the radix tree is built on its device).
@@ -1625,10 +1809,10 @@ int prt_debug_check_bvh_lbvh(prt_ctx * ctx, const prt_scene_desc * s, uint64_t *
     for (uint32_t t = 0; t < n_tris; ++t)
         for (int c = 0; c < 3; ++c) memcpy(&verts[(size_t)t * 9 + 3 * c], s->positions + 3 * (size_t)s->idx_positions[3 * t + c], 12);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    Bvh4Result bvh;
+    BvhWide bvh;
     int rc = build_bvh_lbvh(ctx, verts.data(), n_tris, BVH_LEAF_MAX, &bvh);
     if (rc) return rc;
-    return check_bvh4q(verts, n_tris, bvh, out);
+    return check_bvh_wide(verts, n_tris, bvh, out);
 }
 
 }  // extern "C"

@@ -1,0 +1,134 @@
+// trace_host_harness.cpp - the DEVICE traversal code (par_raytracer_amd/csrc/dev_trace*.h), compiled for the host with
+// tests/hip_shim and run one lane at a time against a brute-force restatement of the reference's hit filter.
+//
+// What it checks, with no GPU: that trace_ray() over the BVH the library builds (8-wide octant-ordered by default, 4-wide
+// sorted with -DPRT_BVH4) returns, for every ray, exactly the hit the reference's sequential filter returns over ALL triangles
+// in visit order (raytracer.cpp:104, 149, 208-220) - t, barycentrics and triangle bit for bit, near ties included - and
+// that any-hit rays agree on occluded / not occluded.  Scene: a wavy height field plus floating, doubled and coplanar
+// triangles.  Built and run by tests/test_trace_host.py.
+//
+//   g++ -O1 -std=c++17 -ffp-contract=off -Itests/hip_shim -Ipar_raytracer_amd/csrc tests/trace_host_harness.cpp \
+//       par_raytracer_amd/csrc/bvh_build.cpp -pthread -o /tmp/trace_host && /tmp/trace_host
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "dev_trace.h"
+#include "bvh_build.h"
+
+using namespace prt;
+
+static uint64_t g_rng = 0x243F6A8885A308D3ull;
+static double rnd() { g_rng ^= g_rng << 13; g_rng ^= g_rng >> 7; g_rng ^= g_rng << 17; return (double)(g_rng >> 11) / 9007199254740992.0; }
+
+int main(int argc, char ** argv) {
+    const int grid = argc > 1 ? atoi(argv[1]) : 48;
+    const int n_rays = argc > 2 ? atoi(argv[2]) : 20000;
+    std::vector<float> verts;
+    auto tri = [&](float ax, float ay, float az, float bx, float by, float bz, float cx, float cy, float cz) {
+        const float v[9] = { ax, ay, az, bx, by, bz, cx, cy, cz };
+        verts.insert(verts.end(), v, v + 9);
+    };
+    auto height = [](float x, float z) { return 0.35f * sinf(x * 0.9f) * cosf(z * 0.7f) + 0.1f * sinf(x * 3.1f + z * 2.3f); };
+    for (int i = 0; i < grid; ++i)
+        for (int j = 0; j < grid; ++j) {
+            const float x0 = i * 0.25f - grid * 0.125f, x1 = x0 + 0.25f, z0 = j * 0.25f - grid * 0.125f, z1 = z0 + 0.25f;
+            tri(x0, height(x0, z0), z0, x0, height(x0, z1), z1, x1, height(x1, z0), z0);            // counter-clockwise seen from +y
+            tri(x1, height(x1, z0), z0, x0, height(x0, z1), z1, x1, height(x1, z1), z1);
+        }
+    for (int k = 0; k < 300; ++k) {                          // floating triangles, some of them twice (coincident copies)
+        const float cx = (float)(rnd() * 8 - 4), cy = (float)(rnd() * 2 + 0.3), cz = (float)(rnd() * 8 - 4);
+        float p[9];
+        for (int q = 0; q < 9; ++q) p[q] = (float)(rnd() - 0.5) * 0.8f;
+        tri(cx + p[0], cy + p[1], cz + p[2], cx + p[3], cy + p[4], cz + p[5], cx + p[6], cy + p[7], cz + p[8]);
+        if (k % 5 == 0) tri(cx + p[0], cy + p[1], cz + p[2], cx + p[3], cy + p[4], cz + p[5], cx + p[6], cy + p[7], cz + p[8]);
+    }
+    for (int k = 0; k < 40; ++k) {                           // coplanar overlapping patches at y = 1.5 (decals)
+        const float cx = (float)(rnd() * 6 - 3), cz = (float)(rnd() * 6 - 3), s = (float)(rnd() * 0.8 + 0.2);
+        tri(cx, 1.5f, cz, cx, 1.5f, cz + s, cx + s, 1.5f, cz);
+    }
+    const uint32_t n_tris = (uint32_t)(verts.size() / 9);
+
+#if defined(PRT_BVH4)
+    Bvh4Result bvh;
+    build_bvh4q(verts.data(), n_tris, 4, 2, &bvh);
+#else
+    Bvh8Result bvh;
+    build_bvh8q(verts.data(), n_tris, 4, 2, &bvh);
+#endif
+    // device records, as prt_upload_scene lays them out
+    std::vector<float4> tris((size_t)(n_tris + 1) * 3, make_float4(0, 0, 0, 0));
+    std::vector<unsigned int> rank(n_tris + 1, 0);
+    for (uint32_t slot = 0; slot < n_tris; ++slot) {
+        const float * v = &verts[(size_t)bvh.tri_order[slot] * 9];
+        const f3 a = mk3(v[0], v[1], v[2]), b = mk3(v[3], v[4], v[5]), c = mk3(v[6], v[7], v[8]);
+        const f3 ab = b - a, ac = c - a, n = cross3(ab, ac);
+        tris[(size_t)slot * 3 + 0] = make_float4(a.x, a.y, a.z, ab.x);
+        tris[(size_t)slot * 3 + 1] = make_float4(ab.y, ab.z, ac.x, ac.y);
+        tris[(size_t)slot * 3 + 2] = make_float4(ac.z, n.x, n.y, n.z);
+        rank[slot] = bvh.tri_order[slot];                   // the "reference visit order": input order
+    }
+    std::vector<uint32_t> slot_of_rank(n_tris);
+    for (uint32_t slot = 0; slot < n_tris; ++slot) slot_of_rank[rank[slot]] = slot;
+    unsigned long long unresolved = 0;
+    DevScene sc;
+    memset(&sc, 0, sizeof(sc));
+    sc.nodes = reinterpret_cast<const float4 *>(bvh.nodes.data());
+    sc.tris = tris.data();
+    sc.tri_rank = rank.data();
+    sc.tri_count = n_tris;
+    sc.node_count = bvh.node_count;
+    sc.tie_widen_max = 8;
+    sc.near_tie_unresolved = &unresolved;
+
+    std::vector<int> stack_mem((size_t)(bvh.stack_bound + 2) * STACK_ENTRY_INTS, 0);
+    GlobalStack stk;
+    stk.attach(stack_mem.data(), 0, 1);
+    TraceStats st;
+    memset(&st, 0, sizeof(st));
+
+    const float pad = 16.0f / 65536.0f;
+    unsigned long long mismatches = 0, hits = 0, any_mismatches = 0, near = 0;
+    for (int k = 0; k < n_rays; ++k) {
+        f3 o, d;
+        if (k % 3 == 0) {                                    // from above, downwards: terrain and decals head-on
+            o = mk3((float)(rnd() * 10 - 5), 3.0f, (float)(rnd() * 10 - 5));
+            d = normalize3(mk3((float)(rnd() - 0.5) * 0.6f, -1.0f, (float)(rnd() - 0.5) * 0.6f));
+        } else if (k % 3 == 1) {                             // grazing
+            o = mk3((float)(rnd() * 10 - 5), (float)(rnd() * 1.5), (float)(rnd() * 10 - 5));
+            d = normalize3(mk3((float)(rnd() - 0.5), (float)(rnd() - 0.5) * 0.2f, (float)(rnd() - 0.5)));
+        } else {                                             // anything, axis-parallel now and then
+            o = mk3((float)(rnd() * 10 - 5), (float)(rnd() * 3), (float)(rnd() * 10 - 5));
+            d = mk3((float)(rnd() - 0.5), (float)(rnd() - 0.5), (float)(rnd() - 0.5));
+            if (k % 30 == 2) d = mk3(0.0f, -1.0f, 0.0f);
+            if (k % 30 == 5) d = mk3(1.0f, 0.0f, 0.0f);
+            d = normalize3(d);
+        }
+        // the reference: its sequential filter over every triangle in visit (= input) order
+        const f3 qp = o - (o + d);
+        float best = 3.402823466e+38f, bv = 0, bw = 0;
+        int btri = -1;
+        for (uint32_t r = 0; r < n_tris; ++r) {
+            const uint32_t slot = slot_of_rank[r];
+            const float4 r0 = tris[(size_t)slot * 3], r1 = tris[(size_t)slot * 3 + 1], r2 = tris[(size_t)slot * 3 + 2];
+            float t, v, w;
+            if (tri_test_ref(o, qp, mk3(r0.x, r0.y, r0.z), mk3(r0.w, r1.x, r1.y), mk3(r1.z, r1.w, r2.x), mk3(r2.y, r2.z, r2.w), best, t, v, w)) {
+                best = t; bv = v; bw = w; btri = (int)slot;
+            }
+        }
+        const HitRec h = trace_ray<GlobalStack, true>(sc, o, d, TRACE_CLOSEST, pad, stk, st);
+        if (stk.marker() & TRAV_FLAG_NEAR) near++;
+        if (btri >= 0) hits++;
+        if (h.tri != btri || (btri >= 0 && (memcmp(&h.t, &best, 4) || memcmp(&h.v, &bv, 4) || memcmp(&h.w, &bw, 4)))) {
+            if (mismatches < 10) fprintf(stderr, "ray %d: traversal (t %.9g tri %d) reference (t %.9g tri %d)\n", k, h.t, h.tri, best, btri);
+            mismatches++;
+        }
+        const HitRec a = trace_ray<GlobalStack, true>(sc, o, d, TRACE_ANY, pad, stk, st);
+        if ((a.tri >= 0) != (btri >= 0)) any_mismatches++;
+    }
+    printf("%u triangles, %u nodes, depth %u, stack bound %u; %d rays, %llu hits, %llu with a near tie; "
+           "closest-hit mismatches %llu, any-hit mismatches %llu, unresolved near ties %llu; %.2f node visits and %.2f triangle tests per traversal\n",
+           n_tris, bvh.node_count, bvh.max_depth, bvh.stack_bound, n_rays, hits, near, mismatches, any_mismatches, unresolved,
+           (double)st.nodes / (2.0 * n_rays), (double)st.tris / (2.0 * n_rays));
+    return (mismatches || any_mismatches || unresolved) ? 1 : 0;
+}
