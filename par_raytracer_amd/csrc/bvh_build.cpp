@@ -521,7 +521,7 @@ void finish_bvh8q(Builder & b, uint32_t n_tris, Bvh8Result * out) {
 void finish_bvh8q_impl(Builder & b, uint32_t n_tris, Bvh8Result * out) {
     auto is_leaf = [&](uint32_t t) { return b.pool[t].left < 0; };
     enum : uint32_t { EMPTY = 0xFFFFFFFFu };
-    struct Wide8 { uint32_t slot[8]; };                     // TmpNode index per slot, EMPTY for none
+    struct Wide8 { uint32_t slot[8]; uint32_t axis = 0; };  // TmpNode index per slot, EMPTY for none; (experiment) the ordering axis
 
     // ---- collapse (below), then give every child a slot: slot s stands for the
     // octant direction ((s & 1) ? +x : -x, (s & 2) ? +y : -y, (s & 4) ? +z : -z) as seen from the node's centre, and a ray
@@ -538,6 +538,7 @@ void finish_bvh8q_impl(Builder & b, uint32_t n_tris, Bvh8Result * out) {
     // tree of the 1M-triangle terrain at 3.6 children per node; the programme fills it (tools/bvh_price.cpp).
     // The option BVH_COLLAPSE=greedy selects the greedy rule.
     const bool greedy = b.opt.collapse == 0;                 // 8-wide default: the dynamic programme
+    const int W = b.opt.width >= 2 && b.opt.width <= 8 ? (int)b.opt.width : 8;      // children per node (experiments: 6)
     const uint32_t n_tmp = b.next_node.load();
     struct Dp8 { float f[7]; uint8_t root_split, split[6]; };   // f[k-1] = F(m, k); split[k-2]: i of the best distribution, 0 = "use k - 1"
     std::vector<Dp8> dp;
@@ -549,12 +550,12 @@ void finish_bvh8q_impl(Builder & b, uint32_t n_tris, Bvh8Result * out) {
             const Dp8 & l = dp[(uint32_t)b.pool[t].left], & r = dp[(uint32_t)b.pool[t].right];
             float best = FLT_MAX;
             d.root_split = 1;
-            for (int i = 1; i <= 7; ++i) {
-                const float c = l.f[i - 1] + r.f[7 - i];
+            for (int i = 1; i <= W - 1; ++i) {
+                const float c = l.f[i - 1] + r.f[W - 1 - i];
                 if (c < best) { best = c; d.root_split = (uint8_t)i; }
             }
             d.f[0] = b.pool[t].box.half_area() + best;
-            for (int k = 2; k <= 7; ++k) {
+            for (int k = 2; k <= W - 1; ++k) {
                 float bk = d.f[k - 2];
                 uint8_t sk = 0;
                 for (int i = 1; i < k; ++i) {
@@ -577,7 +578,7 @@ void finish_bvh8q_impl(Builder & b, uint32_t n_tris, Bvh8Result * out) {
             Todo stack[16];
             int sp = 0;
             const int i0 = dp[root_tmp].root_split;
-            stack[sp++] = Todo{ (uint32_t)b.pool[root_tmp].right, 8 - i0 };
+            stack[sp++] = Todo{ (uint32_t)b.pool[root_tmp].right, W - i0 };
             stack[sp++] = Todo{ (uint32_t)b.pool[root_tmp].left, i0 };
             while (sp > 0) {
                 Todo cur = stack[--sp];
@@ -590,7 +591,7 @@ void finish_bvh8q_impl(Builder & b, uint32_t n_tris, Bvh8Result * out) {
         } else {
             kids[n++] = (uint32_t)b.pool[root_tmp].left;
             kids[n++] = (uint32_t)b.pool[root_tmp].right;
-            while (n < 8) {
+            while (n < (uint32_t)W) {
                 int best = -1;
                 float best_area = -1.0f;
                 for (uint32_t k = 0; k < n; ++k) {
@@ -617,6 +618,25 @@ void finish_bvh8q_impl(Builder & b, uint32_t n_tris, Bvh8Result * out) {
         }
         Wide8 w;
         for (uint32_t s = 0; s < 8; ++s) w.slot[s] = EMPTY;
+        if (b.opt.slot_order == 1) {
+            // experiment: children in ascending order of their centres along the axis on which the centres spread most; a ray
+            // takes the hit slots in ascending or descending order by the sign of its direction on that axis (axis in w.axis)
+            float lo[3] = { FLT_MAX, FLT_MAX, FLT_MAX }, hi[3] = { -FLT_MAX, -FLT_MAX, -FLT_MAX };
+            float c[8][3];
+            for (uint32_t k = 0; k < n; ++k)
+                for (int a = 0; a < 3; ++a) {
+                    c[k][a] = 0.5f * b.pool[kids[k]].box.lo[a] + 0.5f * b.pool[kids[k]].box.hi[a];
+                    lo[a] = std::min(lo[a], c[k][a]); hi[a] = std::max(hi[a], c[k][a]);
+                }
+            int axis = 0;
+            for (int a = 1; a < 3; ++a) if (hi[a] - lo[a] > hi[axis] - lo[axis]) axis = a;
+            uint32_t order[8];
+            for (uint32_t k = 0; k < n; ++k) order[k] = k;
+            std::sort(order, order + n, [&](uint32_t x, uint32_t y) { return c[x][axis] < c[y][axis]; });
+            for (uint32_t k = 0; k < n; ++k) w.slot[k] = kids[order[k]];
+            w.axis = (uint32_t)axis;
+            return w;
+        }
         bool placed[8] = { false, false, false, false, false, false, false, false };
         for (uint32_t round = 0; round < n; ++round) {
             int bk = -1, bs = -1;
@@ -727,7 +747,7 @@ void finish_bvh8q_impl(Builder & b, uint32_t n_tris, Bvh8Result * out) {
         d[4] = child_base[ni];
         d[5] = tri_base[ni];
         d[6] = ebyte[1] << 23 | c0 | c1 << 8;
-        d[7] = ebyte[2] << 23;
+        d[7] = ebyte[2] << 23 | w.axis;
     }
     out->node_count = n_nodes;
     out->max_depth = max_depth;

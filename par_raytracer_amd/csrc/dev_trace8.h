@@ -3,21 +3,24 @@
 // Replaces TraceRay / IntersectRaySphere / IntersectRayMesh (raytracer.cpp:32-60, 127-232); the triangle test and what has to
 // be preserved about the reference's result are in dev_trace_common.h.
 //
-// Why 8-wide.  The 4-wide traversal (dev_trace4.h) is bound by the latency of its node-to-node chain (a wave waits on it 58 %
-// of its cycles, profiles/r02_experiments.txt items 12, 14): 16.3 node steps + 2.1 leaf visits per ray on the 1M-triangle
-// scene, each a dependent memory round trip.  An 8-wide node decides about eight subtrees per round trip: 11.4 + 2.5
-// (tools/bvh_price.cpp).  What makes it affordable:
-//   * no sort.  The builder puts every child into the slot whose octant direction ((s & 1) ? +x : -x, ...) points from the
-//     node's centre to the child; a ray with direction signs o = (dx < 0) | (dy < 0) << 1 | (dz < 0) << 2 then visits the hit
-//     slots in ascending (s XOR o) - near side first on every axis - so "which child next" is a table lookup on the 8-bit
-//     hit mask, not a 5-comparator network with 30 selects (Ylitie, Karras, Laine 2017);
+// Why 8-wide.  An 8-wide node decides about eight subtrees per memory round trip: 9.6 node steps + 2.2 leaf visits per traced
+// ray on the 1M-triangle scene where the 4-wide tree (dev_trace4.h) takes 14.0 + 1.9 (tools/bvh_price.cpp; the frame's counters
+// agree).  What makes it affordable:
+//   * no sort.  The builder stores a node's children in ascending order of their centres along the axis on which those centres
+//     spread most (2 bits per node); a ray visits the hit slots in ascending or descending slot order by the sign of its
+//     direction on that axis, so "which child next" is a find-first-bit on the 8-bit hit mask, not a 5-comparator network with
+//     30 selects.  (-DPRT_BVH8_OCTANT: the slot-per-octant order of Ylitie, Karras, Laine 2017, three conditional bit swaps
+//     per pick; measured 1.7 % more node visits and 0.9 % more triangle tests on the frame, profiles/r03_ab_bvh8.txt.)
 //   * no links.  Internal children are consecutive from child_base and the triangles of the node's leaves consecutive from
 //     tri_base, both in slot order: a child's address is a base plus a population count, and the node is 5 dwordx4 loads
 //     for eight children where the 4-wide node is 4 loads for four;
-//   * one stack entry per NODE, not per child: (child_base, imask | unvisited hit slots << 8).  The stack is as deep as the
-//     tree (9 levels for a million triangles), so the 8-byte entries need no more LDS than the 4-wide tree's 24 links.
-// A node's hit LEAF slots are tested first, in slot order, then its internal children in octant order (a leaf that lies behind
-// an internal child is tested a little early: +0.9 triangle tests per ray, priced in tools/bvh_price.cpp).
+//   * one stack entry per NODE, not per child: (child_base, imask | unvisited hit slots << 8 | axis << 16).  The stack is as
+//     deep as the tree (9 levels for a million triangles), so the 8-byte entries need no more LDS than the 4-wide tree's 24 links.
+// A node's hit LEAF slots are tested first, in slot order, then its internal children in ray order (a leaf that lies behind
+// an internal child is tested a little early: +0.5 triangle tests per ray).
+// What it buys on MI355X (profiles/r03_ab_bvh8.txt, same box): the frame of the headline config takes what it took - 30 % fewer
+// node steps but 17 % more vector instructions, and the kernel turns out to sit on a plateau where neither matters much - ;
+// deep bounce trees (C5, incoherent rays) render 8.5 % faster; the node array halves (8.2 MB instead of 16.6 MB).
 #pragma once
 
 #include "dev_trace_common.h"
@@ -175,6 +178,13 @@ PRT_D void trav_node_step(const DevScene & sc, TravRay & r, const STK & stk, Tra
     const uint4 * np = reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(sc.nodes) + (unsigned int)r.node * 80u);
     const uint4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3], q4 = np[4];
     if (COUNT) { st.nodes++; if (first_active_lane()) st.wnodes++; if ((unsigned int)r.sp > st.max_sp) st.max_sp = (unsigned int)r.sp; }
+#if defined(PRT_PROBE_EXTRA_VALU) && defined(__HIP_DEVICE_COMPILE__)
+    // sensitivity probe (tools/ab_probe.sh): PRT_PROBE_EXTRA_VALU more vector ALU instructions per node step, on a value it needs
+    { unsigned int x = q0.w;
+#pragma unroll
+      for (int i = 0; i < PRT_PROBE_EXTRA_VALU; ++i) asm volatile("v_mov_b32 %0, %0" : "+v"(x));
+      const_cast<uint4 &>(q0).w = x; }
+#endif
     const float kx = __uint_as_float(q0.w & 0x7F800000u) * r.ix;
     const float ky = __uint_as_float(q1.z & 0x7F800000u) * r.iy;
     const float kz = __uint_as_float(q1.w & 0x7F800000u) * r.iz;
@@ -201,7 +211,13 @@ PRT_D void trav_node_step(const DevScene & sc, TravRay & r, const STK & stk, Tra
         const float fz = __builtin_fmaf((float)((qfz[h] >> (8 * k)) & 0xFFu), kz, cfz);
         const float tmin = fmaxf(fmaxf(fmaxf(nx, ny), nz), 0.0f);
         const float tmax = fminf(fminf(fminf(fx, fy), fz), r.best.t);
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(PRT_BVH8_NO_ADDC)
+        // m = 2 m + (tmin <= tmax): the compare's lane mask goes straight into an add-with-carry, one instruction per child
+        // where a select and an or would be two
+        asm("v_cmp_le_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(m) : "v"(tmin), "v"(tmax) : "vcc");
+#else
         m = (m << 1) | (tmin <= tmax ? 1u : 0u);
+#endif
     }
     const unsigned int imask = q0.w & 0xFFu;
     // the node's hit leaves wait for the leaf phase
@@ -209,7 +225,11 @@ PRT_D void trav_node_step(const DevScene & sc, TravRay & r, const STK & stk, Tra
     r.tbits = (m & ~imask) | (q0.w & 0xFF00u) | (q1.z << 16);
     // the next node: from this node's hit internal children, else from the group on top of the stack
     const unsigned int mi = m & imask;
+#if defined(PRT_BVH8_OCTANT)
     unsigned int gbase = q1.x, gbits = imask | mi << 8;
+#else
+    unsigned int gbase = q1.x, gbits = imask | mi << 8 | (q1.w & 3u) << 16;
+#endif
     int at = r.sp;                                      // where the group's remainder goes: a new entry, or back where it came from
     if (mi == 0u) {
         if (COUNT && r.best.tri >= 0 && (m & ~imask) == 0u) st.culled++;
@@ -223,10 +243,18 @@ PRT_D void trav_node_step(const DevScene & sc, TravRay & r, const STK & stk, Tra
         gbase = (unsigned int)e.x;
         gbits = (unsigned int)e.y;
     }
+#if defined(PRT_BVH8_OCTANT)
     const unsigned int s = trav_pick_slot(gbits >> 8, ((unsigned int)r.kind >> 4) & 7u);
+#else
+    // the slots of a node are sorted along its ordering axis (bits 16-17 of the group word): a ray takes the hit ones in
+    // ascending or descending slot order by its direction sign on that axis
+    const unsigned int rest8 = (gbits >> 8) & 0xFFu;
+    const bool backwards = (((unsigned int)r.kind >> 4) >> ((gbits >> 16) & 3u)) & 1u;
+    const unsigned int s = backwards ? 31u - (unsigned int)__clz((int)rest8) : (unsigned int)(__ffs((int)rest8) - 1);
+#endif
     r.node = (int)(gbase + (unsigned int)__popc(gbits & ((1u << s) - 1u) & 0xFFu));
     gbits &= ~(0x100u << s);
-    if (gbits >> 8) {
+    if ((gbits >> 8) & 0xFFu) {
         if (stk.put(at, make_int2((int)gbase, (int)gbits))) r.sp = at + 1;
         else { stk.flag(TRAV_FLAG_OVERFLOW); r.sp = at; }
     } else {

@@ -1132,6 +1132,11 @@ prt_ctx * prt_create(int device_id) {
     memset(&ctx->info, 0, sizeof(ctx->info));
     memset(&ctx->last_stats, 0, sizeof(ctx->last_stats));
     prt_options_from_env(ctx->opt);       // the environment is read here and nowhere else
+#if defined(PRT_BVH8_OCTANT)
+    ctx->opt.bvh.slot_order = 0;          // the traversal of this build expects one slot per octant (dev_trace8.h)
+#else
+    ctx->opt.bvh.slot_order = 1;          // ... slots sorted along the node's ordering axis
+#endif
     // PRT_RESERVE_CUS=k (multi-GPU callers): the context's streams are created with a CU mask that leaves the last k compute
     // units to others - the RCCL gather of the previous frame must not wait for a wave slot while this context's persistent
     // kernels hold every one of theirs (bench.py sets it for N > 1 with frames in flight).  The persistent grids are sized
@@ -1796,6 +1801,11 @@ int prt_debug_check_bvh(const prt_scene_desc * s, uint64_t * out) {
         for (int c = 0; c < 3; ++c) memcpy(&verts[(size_t)t * 9 + 3 * c], s->positions + 3 * (size_t)s->idx_positions[3 * t + c], 12);
     PrtOptions opt;
     prt_options_from_env(opt);                  // the test-suite selects the collapse rule through the environment
+#if defined(PRT_BVH8_OCTANT)
+    opt.bvh.slot_order = 0;
+#else
+    opt.bvh.slot_order = 1;
+#endif
     BvhWide bvh;
     PRT_BUILD_WIDE(verts.data(), n_tris, BVH_LEAF_MAX, 4, &bvh, 1.0f, &opt.bvh);
     return check_bvh_wide(verts, n_tris, bvh, out);

@@ -19,6 +19,9 @@ struct BvhBuildOptions {
     long long collapse = -1;          // 0 = greedy ("open the largest child"), 1 = dynamic programme; -1 = the back end's default
     long long lbvh_plain = 0;         // GPU builder: the radix tree as it is (no SAH inside / across its clusters)
     long long lbvh_cluster = -1;      // GPU builder, hybrid: triangles per Morton cluster (default 64)
+    long long slot_order = 1;         // 8-wide: 1 = children sorted along the node's ordering axis (what dev_trace8.h expects), 0 = one slot
+                                      // per octant (Ylitie et al.; the traversal built with -DPRT_BVH8_OCTANT).  Set by the library, not a knob
+    long long width = 8;              // 8-wide back end: children per node (experiment: 6)
     long long debug = 0;              // print build timings
 };
 
@@ -58,6 +61,7 @@ inline const OptEntry * option_table(size_t * n) {
         { "RESERVE_CUS", &PrtOptions::reserve_cus, nullptr }, { "LEAF_MAX", &PrtOptions::leaf_max, nullptr },
         { "SAH_BINS", nullptr, &BvhBuildOptions::sah_bins }, { "SAH_SWEEP", nullptr, &BvhBuildOptions::sah_sweep },
         { "LBVH_PLAIN", nullptr, &BvhBuildOptions::lbvh_plain }, { "LBVH_CLUSTER", nullptr, &BvhBuildOptions::lbvh_cluster },
+        { "BVH8_WIDTH", nullptr, &BvhBuildOptions::width },
     };
     *n = sizeof(table) / sizeof(table[0]);
     return table;

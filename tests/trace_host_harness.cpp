@@ -1,8 +1,8 @@
 // trace_host_harness.cpp - the DEVICE traversal code (par_raytracer_amd/csrc/dev_trace*.h), compiled for the host with
 // tests/hip_shim and run one lane at a time against a brute-force restatement of the reference's hit filter.
 //
-// What it checks, with no GPU: that trace_ray() over the BVH the library builds (8-wide octant-ordered by default, 4-wide
-// sorted with -DPRT_BVH4) returns, for every ray, exactly the hit the reference's sequential filter returns over ALL triangles
+// What it checks, with no GPU: that trace_ray() over the BVH the library builds (8-wide by default - slots sorted along one axis, or one per
+// octant with -DPRT_BVH8_OCTANT -, 4-wide sorted with -DPRT_BVH4) returns, for every ray, exactly the hit the reference's sequential filter returns over ALL triangles
 // in visit order (raytracer.cpp:104, 149, 208-220) - t, barycentrics and triangle bit for bit, near ties included - and
 // that any-hit rays agree on occluded / not occluded.  Scene: a wavy height field plus floating, doubled and coplanar
 // triangles.  Built and run by tests/test_trace_host.py.
@@ -15,6 +15,7 @@
 
 #include "dev_trace.h"
 #include "bvh_build.h"
+#include "prt_options.h"
 
 using namespace prt;
 
@@ -54,7 +55,11 @@ int main(int argc, char ** argv) {
     build_bvh4q(verts.data(), n_tris, 4, 2, &bvh);
 #else
     Bvh8Result bvh;
-    build_bvh8q(verts.data(), n_tris, 4, 2, &bvh);
+    BvhBuildOptions bopt;
+#if defined(PRT_BVH8_OCTANT)
+    bopt.slot_order = 0;
+#endif
+    build_bvh8q(verts.data(), n_tris, 4, 2, &bvh, 1.0f, &bopt);
 #endif
     // device records, as prt_upload_scene lays them out
     std::vector<float4> tris((size_t)(n_tris + 1) * 3, make_float4(0, 0, 0, 0));
@@ -116,8 +121,17 @@ int main(int argc, char ** argv) {
                 best = t; bv = v; bw = w; btri = (int)slot;
             }
         }
+        if (btri >= 0) {                                     // rays whose hit has company within 2^-19: resolve_near_ties decides them
+            unsigned int company = 0;
+            for (uint32_t slot = 0; slot < n_tris; ++slot) {
+                const float4 r0 = tris[(size_t)slot * 3], r1 = tris[(size_t)slot * 3 + 1], r2 = tris[(size_t)slot * 3 + 2];
+                float t, dd, v, w;
+                if (tri_geom(o, qp, mk3(r0.x, r0.y, r0.z), mk3(r0.w, r1.x, r1.y), mk3(r1.z, r1.w, r2.x), mk3(r2.y, r2.z, r2.w), t, dd, v, w) &&
+                    t / dd <= best * PRT_TIE_NEAR) company++;
+            }
+            if (company > 1) near++;
+        }
         const HitRec h = trace_ray<GlobalStack, true>(sc, o, d, TRACE_CLOSEST, pad, stk, st);
-        if (stk.marker() & TRAV_FLAG_NEAR) near++;
         if (btri >= 0) hits++;
         if (h.tri != btri || (btri >= 0 && (memcmp(&h.t, &best, 4) || memcmp(&h.v, &bv, 4) || memcmp(&h.w, &bw, 4)))) {
             if (mismatches < 10) fprintf(stderr, "ray %d: traversal (t %.9g tri %d) reference (t %.9g tri %d)\n", k, h.t, h.tri, best, btri);

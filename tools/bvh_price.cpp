@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "bvh_build.h"
+#include "prt_options.h"
 
 using namespace prt;
 
@@ -208,7 +209,7 @@ static Hit trace8u(const Bvh8Result & bvh, const Ray & r, Stats & st, int mode) 
                 tmin = std::max(tmin, t0);
                 tmax = std::min(tmax, t1);
             }
-            g.key[s] = mode == 1 ? tmin : (double)(s ^ oct);
+            g.key[s] = mode == 1 ? tmin : mode == 2 ? ((&r.d.x)[d[7] & 3u] >= 0 ? (double)s : (double)(7 - s)) : (double)(s ^ oct);
             if (!empty && tmin <= tmax) g.rest |= 1u << s;
         }
         return g;
@@ -265,9 +266,16 @@ int main(int argc, char ** argv) {
     const int lattice = argc > 2 ? atoi(argv[2]) : 4;
 
     Bvh4Result b4;
-    Bvh8Result b8;
+    Bvh8Result b8, b8a;
+    const uint32_t leaf_max = getenv("PRICE_LEAF_MAX") ? (uint32_t)atoi(getenv("PRICE_LEAF_MAX")) : 4u;
     build_bvh4q(g_verts.data(), n_tris, 4, 8, &b4);
-    build_bvh8q(g_verts.data(), n_tris, 4, 8, &b8);
+    BvhBuildOptions oct_opt;
+    oct_opt.slot_order = 0;
+    build_bvh8q(g_verts.data(), n_tris, leaf_max, 8, &b8, 1.0f, &oct_opt);
+    BvhBuildOptions axis_opt;
+    axis_opt.slot_order = 1;
+    if (getenv("PRICE_WIDTH")) axis_opt.width = atoi(getenv("PRICE_WIDTH"));
+    build_bvh8q(g_verts.data(), n_tris, leaf_max, 8, &b8a, 1.0f, &axis_opt);
 
     // camera (main.cpp:145-177)
     const int W = 1920, H = 1080;
@@ -276,7 +284,7 @@ int main(int argc, char ** argv) {
     const V3 right = norm(cross(fwd, V3{ 0, 1, 0 })), up = norm(cross(right, fwd));
     const V3 light = norm(V3{ 1, -1.5, 0.25 }) * -1.0;
 
-    Stats s4[3], s8[3], s8u[3], s8o[3], s8d[3];            // primary, shadow, bounce
+    Stats s4[3], s8[3], s8u[3], s8o[3], s8d[3], s8a[3];            // primary, shadow, bounce
     uint64_t mismatches = 0;
     uint64_t rng = 0x9E3779B97F4A7C15ull;
     auto rnd = [&]() { rng ^= rng << 13; rng ^= rng >> 7; rng ^= rng << 17; return (double)(rng >> 11) / 9007199254740992.0; };
@@ -286,6 +294,7 @@ int main(int argc, char ** argv) {
         trace8(b8, r, s8u[cls], false);
         trace8u(b8, r, s8o[cls], 0);
         trace8u(b8, r, s8d[cls], 1);
+        trace8u(b8a, r, s8a[cls], 2);
         if (r.any ? (h4.tri < 0) != (h8.tri < 0) : (h4.tri < 0) != (h8.tri < 0) || (h4.tri >= 0 && std::fabs(h4.t - h8.t) > 1e-9 * std::max(1.0, h4.t))) mismatches++;
         return h8;
     };
@@ -321,13 +330,15 @@ int main(int argc, char ** argv) {
         report("8-wide, slot order (no octant)", s8u[k], b8.node_count, 80, b8.max_depth);
         report("8-wide, one octant order, leaves too", s8o[k], b8.node_count, 80, b8.max_depth);
         report("8-wide, sorted by entry distance", s8d[k], b8.node_count, 80, b8.max_depth);
+        report("8-wide, one axis per node", s8a[k], b8a.node_count, 80, b8a.max_depth);
     }
-    Stats t4, t8, t8u, t8o, t8d;
+    Stats t4, t8, t8u, t8o, t8d, t8a;
     for (int k = 0; k < 3; ++k) {
         t4.rays += s4[k].rays; t4.nodes += s4[k].nodes; t4.tris += s4[k].tris; t4.max_sp = std::max(t4.max_sp, s4[k].max_sp);
         t8.rays += s8[k].rays; t8.nodes += s8[k].nodes; t8.tris += s8[k].tris; t8.max_sp = std::max(t8.max_sp, s8[k].max_sp);
         t8u.rays += s8u[k].rays; t8u.nodes += s8u[k].nodes; t8u.tris += s8u[k].tris; t8u.max_sp = std::max(t8u.max_sp, s8u[k].max_sp);
         t8o.rays += s8o[k].rays; t8o.nodes += s8o[k].nodes; t8o.tris += s8o[k].tris; t8o.max_sp = std::max(t8o.max_sp, s8o[k].max_sp);
+        t8a.rays += s8a[k].rays; t8a.nodes += s8a[k].nodes; t8a.tris += s8a[k].tris; t8a.max_sp = std::max(t8a.max_sp, s8a[k].max_sp);
         t8d.rays += s8d[k].rays; t8d.nodes += s8d[k].nodes; t8d.tris += s8d[k].tris; t8d.max_sp = std::max(t8d.max_sp, s8d[k].max_sp);
     }
     printf("-- all rays: %llu\n", (unsigned long long)t4.rays);
@@ -336,6 +347,7 @@ int main(int argc, char ** argv) {
     report("8-wide, slot order (no octant)", t8u, b8.node_count, 80, b8.max_depth);
     report("8-wide, one octant order, leaves too", t8o, b8.node_count, 80, b8.max_depth);
     report("8-wide, sorted by entry distance", t8d, b8.node_count, 80, b8.max_depth);
+    report("8-wide, one axis per node", t8a, b8a.node_count, 80, b8a.max_depth);
     printf("hit / miss or distance mismatches between the two trees: %llu\n", (unsigned long long)mismatches);
     return mismatches ? 1 : 0;
 }
