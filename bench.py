@@ -24,10 +24,13 @@ Total work is fixed as N grows -> "scaling": "strong".
 
 Extra objects on the JSON line:
   roofline      the dominant kernel (k_pool: one launch = one frame): SURVEY.md §8d algorithmic bytes of a launch (rays x 52 B +
-                BVH nodes fetched x 64 B + triangle tests x 36 B + shaded hits x 80 B + pixels x 16 B) / its duration, measured
-                with HIP events on the kernel's own stream inside the timed region.  `traffic` = HBM bytes per launch from
-                rocprofv3 PMC passes of this command (profiles/traffic_C4.json, FETCH_SIZE x 2 + WRITE_SIZE as the gfx950
-                guide prescribes), or null.  `lane_utilisation`, `valu_busy`, `ta_busy`: what really bounds the kernel.
+                BVH nodes fetched x the build's node size (80 B, 8-wide) + triangle tests x 36 B + shaded hits x 80 B + pixels
+                x 16 B) / its duration, measured with HIP events on the kernel's own stream inside the timed region.  That
+                figure counts every per-lane node fetch, most of which the caches serve, so its label says what it is
+                ("cache-inclusive algorithmic bytes") and `hbm_measured` / `limiter` say what the memory system and the
+                kernel really do.  `traffic` = HBM bytes per launch from rocprofv3 PMC passes of this command
+                (profiles/traffic_C4.json, FETCH_SIZE x 2 + WRITE_SIZE as the gfx950 guide prescribes) - printed only when the
+                file was taken with the library that is running (its sha256 is in the file), else null.
   cpu_baseline  the CPU oracle ("port", oracle/prt_oracle.cpp, bit-identical to the compiled reference on every fixture) timed
                 on the physical cores of this host's socket 0, one pinned thread each, on a sparse pixel lattice of the SAME
                 frame; rank 0, N = 1 only.  The same lattice is the parity check of the GPU frame (max |dRGB|, ray counts).
@@ -61,11 +64,12 @@ WORKLOADS = {
 SHARD_BLOCK_ROWS = 8
 SEED = 1234
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s HBM3E spec peak
-# SURVEY.md §8d algorithmic bytes per unit of work: ray 52 (32 read + 20 written), BVH node = the build's node (64 B, 4-wide),
+# SURVEY.md §8d algorithmic bytes per unit of work: ray 52 (32 read + 20 written), BVH node = the build's node (80 B, 8-wide;
+# read from prt_scene_info.bvh_node_bytes),
 # triangle test 36 (three float3), shaded hit 80 (3 normals + 3 indices + material), pixel 16.  `roofline.achieved` / `frac`
 # use THESE.  The build's own records are fatter (48 B pre-differenced triangle, 64 B shading record + 64 B material + 16 B
 # hit record = 144 B per shaded hit); the same figure with those sizes is reported next to it, not instead of it.
-B_RAY, B_NODE, B_TRI, B_SHADE, B_PIXEL = 52, 64, 36, 80, 16
+B_RAY, B_TRI, B_SHADE, B_PIXEL = 52, 36, 80, 16
 B_TRI_BUILD, B_SHADE_BUILD = 48, 144
 
 # The other BASELINE configs, timed in the same run (extra.other_workloads) and checked against the reference's golden pixels
@@ -183,6 +187,12 @@ def main():
         else:
             dist.init_process_group("gloo")
     cdev = dev if args.backend == "nccl" else torch.device("cpu")   # where collective payloads live
+    if world > 1:
+        # The context's CU-masked render streams (PRT_RESERVE_CUS) are created by hipExtStreamCreateWithCUMask, which has no
+        # flags: they are BLOCKING streams, implicitly ordered against the legacy null stream - torch's default.  Everything
+        # this rank does in torch from here on (gather, cat, assemble, event records) therefore runs on a stream of its own
+        # (torch streams are non-blocking), so the frames in flight never serialise against it.
+        torch.cuda.set_stream(torch.cuda.Stream(device=dev))
 
     scene_name, width, height, spp, depth, descr = WORKLOADS[args.workload]
 
@@ -342,6 +352,7 @@ def main():
     # have no ray record, so they are not priced either
     rays_elided = int(st.elided_shadow_rays)
     rays_traced = int(cc.ray_count) - rays_elided
+    B_NODE = int(info.bvh_node_bytes)           # the build's node: 80 B (8-wide), 64 B for a -DPRT_BVH4 library
     def algorithmic_bytes(b_tri, b_shade):
         n = rays_traced * B_RAY + cc.node_visits * B_NODE + cc.tri_tests * b_tri
         if fused:
@@ -351,17 +362,33 @@ def main():
     alg_bytes_build = algorithmic_bytes(B_TRI_BUILD, B_SHADE_BUILD)
     kernel_ms = float(np.mean(trace_ms))
     achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
-    traffic = valu_busy = ta_busy = None
+    # The PMC figures come from a committed file (counters cannot be collected inside this run).  They are only printed when
+    # the file says it was taken with THIS library: tools/profile_summary.py stamps it with the sha256 of libprt_hip.so, its ABI
+    # version and build flags; anything else and traffic / the counter-derived fields are null, with the reason beside them.
+    traffic = valu_busy = ta_busy = wait_frac = l1_latency = None
+    traffic_note = "no profiles/traffic_%s.json" % args.workload
     tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.workload)
     if os.path.exists(tpath) and world == 1 and used in (2, 4):
         try:
+            import hashlib
             with open(tpath) as f:
                 tj = json.load(f)
-            traffic = tj.get("hbm_bytes_per_frame_" + kernel_name)
-            valu_busy = tj.get("valu_busy_" + kernel_name)          # SQ_ACTIVE_INST_VALU x 4 / SQ_BUSY_CYCLES of the same command (PMC)
-            ta_busy = tj.get("ta_busy_" + kernel_name)              # TA_TA_BUSY / (GRBM_GUI_ACTIVE per XCD x compute units)
-        except Exception:
+            with open(os.path.join(ROOT, "par_raytracer_amd", os.path.basename(os.environ.get("PRT_HIP_LIB", "libprt_hip.so"))), "rb") as f:
+                lib_sha = hashlib.sha256(f.read()).hexdigest()
+            stamp = tj.get("library", {})
+            if stamp.get("sha256") != lib_sha or stamp.get("abi_version") != int(capi.hip_lib().prt_abi_version()):
+                traffic_note = "profiles/traffic_%s.json was taken with another build of libprt_hip.so (%s..., this one is %s...): not printed" % (
+                    args.workload, str(stamp.get("sha256"))[:12], lib_sha[:12])
+            else:
+                traffic_note = "profiles/traffic_%s.json, taken with this library (sha256 %s..., commit %s)" % (args.workload, lib_sha[:12], stamp.get("commit"))
+                traffic = tj.get("hbm_bytes_per_frame_" + kernel_name)
+                valu_busy = tj.get("valu_busy_" + kernel_name)      # SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES x resident waves per SIMD (PMC)
+                ta_busy = tj.get("ta_busy_" + kernel_name)          # TA_TA_BUSY / (GRBM_GUI_ACTIVE per XCD x compute units)
+                wait_frac = tj.get("wait_frac_" + kernel_name)      # SQ_WAIT_ANY / SQ_WAVE_CYCLES: share of a wave's cycles parked on s_waitcnt
+                l1_latency = tj.get("l1_latency_clk_" + kernel_name)  # TCP_TCP_LATENCY_sum / TCP_TA_TCP_STATE_READ_sum
+        except Exception as e:
             traffic = None
+            traffic_note = "profiles/traffic_%s.json unreadable: %r" % (args.workload, e)
     launches = max(1, int(cc.trace_kernel_launches))
     lane_util = None
     if st.wave_node_steps and st.wave_tri_steps:
@@ -373,7 +400,7 @@ def main():
                      "rays_parked_for_the_exact_launch": int(st.parked_rays)}
     # `achieved` = algorithmic bytes per launch / mean launch duration; `traffic` = measured HBM bytes per launch.  Both are
     # also given per frame (launches_per_frame launches of the kernel make one frame).
-    roofline = {"bound": "hbm", "kernel": kernel_name, "launches_per_frame": launches,
+    roofline = {"bound": "cache-inclusive algorithmic bytes", "kernel": kernel_name, "launches_per_frame": launches,
                 "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": int(traffic / launches) if traffic else None,
                 "traffic_per_frame": traffic, "algorithmic_bytes_per_launch": int(alg_bytes / launches),
@@ -389,6 +416,14 @@ def main():
                 # The algorithmic figure counts every per-lane node fetch; most are served by L1 / L2 / Infinity Cache.  What
                 # the kernel is bounded by is vector issue with divergent lanes, with the texture addresser not far behind:
                 "lane_utilisation": lane_util, "valu_busy": valu_busy, "ta_busy": ta_busy,
+                # what bounds the kernel: not HBM (hbm_measured below) and not one unit - its waves hold 5 per SIMD (96 VGPRs) and
+                # issue vector instructions for lanes of which little more than half carry a walking ray, while each waits on
+                # its node-to-node chain for about half its cycles; profiles/r03_ab_bvh8.txt shows vector instructions, vector
+                # memory instructions and chain length each returning a quarter of what they cost
+                "limiter": {"kind": "vector issue at partial lane occupancy, latency of the dependent node chain at 5 waves per SIMD",
+                            "valu_busy": valu_busy, "lane_utilisation": ({"node_loop": lane_util["node_loop"], "triangle_loop": lane_util["triangle_loop"]} if lane_util else None),
+                            "wait_frac": wait_frac, "l1_latency_clk": l1_latency, "ta_busy": ta_busy},
+                "traffic_source": traffic_note,
                 # SURVEY.md §8d asks for these two beside the algorithmic figure: what the kernel really moved through HBM
                 # (PMC, per second of kernel time, as a fraction of the 8 TB/s peak) and the compulsory minimum of a frame
                 # (every ray record once, the resident scene once, the framebuffer once)
@@ -543,8 +578,10 @@ def main():
                        "spp": spp, "bounce_depth": depth, "rays_per_frame": int(rays_total / args.steps),
                        # A ray is one TraceRay call of the reference (raytracer.cpp:161) and ray_count equals the reference's.  Of
                        # those, the shadow rays whose radiance-if-unoccluded is exactly zero (surface facing away from the light, no
-                       # highlight) cannot change the image and are counted without being traced; PRT_TRACE_DEAD_SHADOW_RAYS=1
+                       # highlight) cannot change the image and are counted without being traced; the option TRACE_DEAD_SHADOW_RAYS=1
                        # traces them too.  `value_traced_rays_only` is the rate without them.
+                       "ray_definition": "one TraceRay call of the reference (raytracer.cpp:161): `value` divides the reference's ray_count, which the "
+                                         "device reproduces exactly, by the time; value_traced_rays_only and the roofline count only the rays the device traces",
                        "rays_counted_not_traced_per_frame": rays_elided if world == 1 else None,
                        "value_traced_rays_only": round(value * rays_traced / max(1, int(cc.ray_count)), 3) if world == 1 else None,
                        "parallelism": "pixel rows sharded in %d-row blocks over %d GPU(s)%s" % (

@@ -234,6 +234,25 @@ int prt_render_pixel_list(prt_ctx * ctx, const prt_camera * cam, const prt_param
                           uint32_t width, uint32_t height, const uint32_t * pixel_ids, uint32_t n_pixels,
                           float * rgba_out, prt_counters * counters);
 
+/* ---- several devices behind one handle --------------------------------------------------------------------------------
+ * SURVEY.md 8(b)'s prt_create(const int * device_ids, int n_dev): what the host mirror's Render() uses for n GPUs, in place
+ * of the reference's one-rank-per-core partition + MPI_Gather (main.cpp:311-347).  The scene is replicated (as every MPI rank
+ * holds it); device g renders the 8-row blocks b with b % n == g into a packed buffer in its own HBM; the shards go to
+ * device_ids[0] as peer-to-peer copies (DMA engines over xGMI: no compute unit, so no contest with the persistent render
+ * kernels), a small kernel there puts the rows in place, and one copy takes the frame to the host buffer rgba_out
+ * (width * height * 4 floats).  The frame is bit-identical to what prt_render gives on one device.  The same ordinal may be
+ * listed more than once (rehearsal of the n-device path on one GPU: the peer copy is then a copy within the device).
+ * prt_multi_context(m, i) is device i's ordinary context (options, scene info, stats). */
+typedef struct prt_multi prt_multi;
+prt_multi * prt_multi_create(const int * device_ids, int n_dev);
+void prt_multi_destroy(prt_multi * m);
+const char * prt_multi_last_error(const prt_multi * m);           /* m may be NULL: last creation error */
+int prt_multi_device_count(const prt_multi * m);
+prt_ctx * prt_multi_context(prt_multi * m, int i);
+int prt_multi_upload_scene(prt_multi * m, const prt_scene_desc * scene);
+int prt_multi_render(prt_multi * m, const prt_camera * cam, const prt_params * params, uint32_t width, uint32_t height,
+                     float * rgba_out, prt_counters * counters);
+
 /* Introspection for DESIGN.md / bench.py: sizes of what upload built. */
 typedef struct prt_scene_info {
     uint32_t triangle_count;

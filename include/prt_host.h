@@ -37,8 +37,9 @@ void prt_host_make_camera(float fov, uint32_t width, uint32_t height, const floa
 /* The reference defaults of gParams that the hot path reads (main.cpp:419-425), spp/seed as given. */
 void prt_host_default_params(uint32_t spp, uint64_t seed, prt_params * out);
 
-/* Render(): uploads the flattened scene to `n_gpus` devices (ordinals 0..n-1), renders interleaved
- * scan-line blocks and assembles the full frame on the host.  rgba_out: width*height*4 floats. */
+/* Render(): uploads the flattened scene to `n_gpus` devices (ordinals 0..n-1) through ONE multi-device handle
+ * (include/prt.h prt_multi_*): interleaved scan-line blocks, the shards gathered to device 0 by peer-to-peer copies
+ * and put in place there, one copy to the host.  rgba_out: width*height*4 floats. */
 int prt_host_render(const prt_host_scene * scene, const prt_camera * cam, const prt_params * params,
                     uint32_t width, uint32_t height, int n_gpus, float * rgba_out, prt_counters * counters);
 /* Message of the last prt_host_render / Render() failure (a copy private to the calling thread).  The uploaded contexts

@@ -102,7 +102,9 @@ BUILD_EXPERIMENTAL, BUILD_BVH4 = 1, 2
 
 # Every symbol include/prt.h declares; tests/test_capi_symbols.py checks the library exports them all.
 PRT_SYMBOLS = ["prt_create", "prt_destroy", "prt_last_error", "prt_abi_version", "prt_set_option", "prt_build_flags", "prt_upload_scene", "prt_render",
-               "prt_render_device", "prt_shard_rows", "prt_render_shard_device", "prt_render_shard", "prt_render_pixel_list", "prt_get_scene_info", "prt_get_render_stats", "prt_debug_check_bvh", "prt_debug_check_bvh_lbvh", "prt_debug_device_kat"]
+               "prt_render_device", "prt_shard_rows", "prt_render_shard_device", "prt_render_shard", "prt_render_pixel_list", "prt_get_scene_info", "prt_get_render_stats", "prt_debug_check_bvh", "prt_debug_check_bvh_lbvh", "prt_debug_device_kat",
+               "prt_multi_create", "prt_multi_destroy", "prt_multi_last_error", "prt_multi_device_count", "prt_multi_context",
+               "prt_multi_upload_scene", "prt_multi_render"]
 PRT_HOST_SYMBOLS = ["prt_host_load_obj", "prt_host_free_scene", "prt_host_scene_desc", "prt_host_scene_hierarchy_seconds",
                     "prt_host_scene_parse_seconds", "prt_host_last_error", "prt_host_make_camera",
                     "prt_host_default_params", "prt_host_render", "prt_host_render_error", "prt_host_write_image", "prt_host_tonemap",
@@ -158,6 +160,17 @@ def hip_lib() -> C.CDLL:
         lib.prt_debug_check_bvh_lbvh.argtypes = [C.c_void_p, C.POINTER(PrtSceneDesc), C.POINTER(C.c_uint64)]
         lib.prt_debug_device_kat.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_uint32,
                                              C.POINTER(PrtCamera)]
+        lib.prt_multi_create.restype = C.c_void_p
+        lib.prt_multi_create.argtypes = [C.POINTER(C.c_int), C.c_int]
+        lib.prt_multi_destroy.argtypes = [C.c_void_p]
+        lib.prt_multi_last_error.restype = C.c_char_p
+        lib.prt_multi_last_error.argtypes = [C.c_void_p]
+        lib.prt_multi_device_count.argtypes = [C.c_void_p]
+        lib.prt_multi_context.restype = C.c_void_p
+        lib.prt_multi_context.argtypes = [C.c_void_p, C.c_int]
+        lib.prt_multi_upload_scene.argtypes = [C.c_void_p, C.POINTER(PrtSceneDesc)]
+        lib.prt_multi_render.argtypes = [C.c_void_p, C.POINTER(PrtCamera), C.POINTER(PrtParams), C.c_uint32, C.c_uint32,
+                                         C.c_void_p, C.POINTER(PrtCounters)]
         _hip = lib
     return _hip
 

@@ -1825,4 +1825,161 @@ int prt_debug_check_bvh_lbvh(prt_ctx * ctx, const prt_scene_desc * s, uint64_t *
     return check_bvh_wide(verts, n_tris, bvh, out);
 }
 
+// =============================================================================================================
+// Several devices behind one handle (prt_create(const int * device_ids, int n_dev)) - the product's
+// multi-GPU path.  Replaces the reference's partition + MPI_Gather (main.cpp:311-347): the scene is replicated (as every
+// MPI rank holds it), device g renders the row blocks b with b % n == g into a packed buffer in its own HBM, the shards
+// travel to device 0 over the fabric as peer-to-peer copies - DMA engines over xGMI, no compute unit involved, so they
+// do not compete with the persistent render kernels for wave slots the way a collective's kernels do -, one small kernel
+// on device 0 puts the rows where they belong, and ONE copy takes the frame to the host.
+__global__ void k_assemble_shards(const float4 * staging, float4 * frame, unsigned int width, unsigned int height,
+                                  unsigned int block_rows, unsigned int n_dev, unsigned int max_shard_rows) {
+    const unsigned int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= width * height) return;
+    const unsigned int y = i / width, x = i - y * width;
+    const unsigned int b = y / block_rows, g = b % n_dev;
+    const unsigned int local_row = (b / n_dev) * block_rows + (y - b * block_rows);
+    frame[i] = staging[((size_t)g * max_shard_rows + local_row) * width + x];
+}
+
+struct prt_multi {
+    std::vector<prt_ctx *> ctx;
+    std::vector<DevBuf<float4> > shard;      // per device: its packed shard (device g's memory)
+    DevBuf<float4> staging, frame;           // device 0: every shard side by side; the assembled frame
+    std::vector<hipEvent_t> done;            // per device: its peer copy has landed
+    std::string error;
+};
+
+enum { PRT_MULTI_BLOCK_ROWS = 8 };
+
+prt_multi * prt_multi_create(const int * device_ids, int n_dev) {
+    if (!device_ids || n_dev < 1) { g_create_error = "prt_multi_create: no devices"; return nullptr; }
+    prt_multi * m = new prt_multi;
+    for (int g = 0; g < n_dev; ++g) {
+        prt_ctx * c = prt_create(device_ids[g]);
+        if (!c) { prt_multi_destroy(m); return nullptr; }
+        m->ctx.push_back(c);
+    }
+    m->shard.resize((size_t)n_dev);
+    m->done.assign((size_t)n_dev, nullptr);
+    for (int g = 0; g < n_dev; ++g) {
+        if (hipSetDevice(m->ctx[(size_t)g]->device) != hipSuccess || hipEventCreateWithFlags(&m->done[(size_t)g], hipEventDisableTiming) != hipSuccess) {
+            g_create_error = "prt_multi_create: event creation failed";
+            prt_multi_destroy(m);
+            return nullptr;
+        }
+        // direct loads / stores between the devices where the fabric offers them (the copies work either way)
+        if (g > 0 && m->ctx[(size_t)g]->device != m->ctx[0]->device) {
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, m->ctx[0]->device, m->ctx[(size_t)g]->device) == hipSuccess && can) {
+                (void)hipSetDevice(m->ctx[0]->device);
+                (void)hipDeviceEnablePeerAccess(m->ctx[(size_t)g]->device, 0);
+                (void)hipGetLastError();             // "already enabled" is fine
+            }
+        }
+    }
+    return m;
+}
+
+void prt_multi_destroy(prt_multi * m) {
+    if (!m) return;
+    for (size_t g = 0; g < m->ctx.size(); ++g) {
+        (void)hipSetDevice(m->ctx[g]->device);
+        if (g < m->shard.size()) m->shard[g].release();
+        if (g < m->done.size() && m->done[g]) (void)hipEventDestroy(m->done[g]);
+    }
+    if (!m->ctx.empty()) {
+        (void)hipSetDevice(m->ctx[0]->device);
+        m->staging.release();
+        m->frame.release();
+    }
+    for (size_t g = 0; g < m->ctx.size(); ++g) prt_destroy(m->ctx[g]);
+    delete m;
+}
+
+const char * prt_multi_last_error(const prt_multi * m) { return m ? m->error.c_str() : g_create_error.c_str(); }
+int prt_multi_device_count(const prt_multi * m) { return m ? (int)m->ctx.size() : 0; }
+prt_ctx * prt_multi_context(prt_multi * m, int i) { return m && i >= 0 && (size_t)i < m->ctx.size() ? m->ctx[(size_t)i] : nullptr; }
+
+int prt_multi_upload_scene(prt_multi * m, const prt_scene_desc * scene) {
+    if (!m) return -1;
+    for (size_t g = 0; g < m->ctx.size(); ++g) {
+        const int rc = prt_upload_scene(m->ctx[g], scene);
+        if (rc) { m->error = prt_last_error(m->ctx[g]); return rc; }
+    }
+    return 0;
+}
+
+#define MULTI_TRY(m, call)                                                                                   \
+    do {                                                                                                     \
+        hipError_t e_ = (call);                                                                              \
+        if (e_ != hipSuccess) { (m)->error = std::string(#call) + ": " + hipGetErrorString(e_); return -10; } \
+    } while (0)
+
+int prt_multi_render(prt_multi * m, const prt_camera * cam, const prt_params * params, uint32_t width, uint32_t height,
+                     float * rgba_out, prt_counters * counters) {
+    if (!m || m->ctx.empty()) return -1;
+    if (!rgba_out && width && height) { m->error = "prt_multi_render: null output"; return -1; }
+    const unsigned int n = (unsigned int)m->ctx.size();
+    std::vector<prt_counters> ctr(n);
+    for (unsigned int g = 0; g < n; ++g) memset(&ctr[g], 0, sizeof(prt_counters));
+    if (n == 1) {
+        const int rc = prt_render(m->ctx[0], cam, params, width, height, 0, width * height, rgba_out, &ctr[0]);
+        if (rc) { m->error = prt_last_error(m->ctx[0]); return rc; }
+        if (counters) *counters = ctr[0];
+        return 0;
+    }
+    const size_t n_px = (size_t)width * height;
+    const uint32_t max_rows = prt_shard_rows(height, PRT_MULTI_BLOCK_ROWS, 0, n);       // rank 0 owns the most rows
+    prt_ctx * c0 = m->ctx[0];
+    MULTI_TRY(m, hipSetDevice(c0->device));
+    MULTI_TRY(m, m->staging.ensure((size_t)n * max_rows * width));
+    MULTI_TRY(m, m->frame.ensure(n_px));
+    // one host thread per device renders its shard (the render call blocks its caller), then queues the shard's trip to
+    // device 0 on its own stream: a shard that is done travels while the others still render
+    std::vector<int> rc(n, 0);
+    std::vector<std::string> err(n);
+    std::vector<std::thread> pool;
+    for (unsigned int g = 0; g < n; ++g) {
+        pool.emplace_back([&, g]() {
+            prt_ctx * c = m->ctx[g];
+            const size_t rows = prt_shard_rows(height, PRT_MULTI_BLOCK_ROWS, g, n);
+            hipError_t e = hipSetDevice(c->device);
+            if (e == hipSuccess) e = m->shard[g].ensure(std::max<size_t>(1, rows * width));
+            if (e != hipSuccess) { rc[g] = -10; err[g] = std::string("shard buffer: ") + hipGetErrorString(e); return; }
+            rc[g] = prt_render_shard_device(c, cam, params, width, height, PRT_MULTI_BLOCK_ROWS, g, n, m->shard[g].p, &ctr[g]);
+            if (rc[g]) { err[g] = prt_last_error(c); return; }
+            if (rows) e = hipMemcpyPeerAsync(m->staging.p + (size_t)g * max_rows * width, c0->device, m->shard[g].p, c->device,
+                                             rows * width * sizeof(float4), c->stream);
+            if (e == hipSuccess) e = hipEventRecord(m->done[g], c->stream);
+            if (e != hipSuccess) { rc[g] = -10; err[g] = std::string("peer copy: ") + hipGetErrorString(e); }
+        });
+    }
+    for (size_t t = 0; t < pool.size(); ++t) pool[t].join();
+    for (unsigned int g = 0; g < n; ++g)
+        if (rc[g]) { m->error = err[g]; return rc[g]; }
+    MULTI_TRY(m, hipSetDevice(c0->device));
+    for (unsigned int g = 0; g < n; ++g) MULTI_TRY(m, hipStreamWaitEvent(c0->stream, m->done[g], 0));
+    if (n_px) {
+        hipLaunchKernelGGL(k_assemble_shards, dim3((unsigned int)((n_px + 255) / 256)), dim3(256), 0, c0->stream, m->staging.p, m->frame.p,
+                           width, height, (unsigned int)PRT_MULTI_BLOCK_ROWS, n, max_rows);
+        MULTI_TRY(m, hipGetLastError());
+        MULTI_TRY(m, hipMemcpyAsync(rgba_out, m->frame.p, n_px * sizeof(float4), hipMemcpyDeviceToHost, c0->stream));
+    }
+    MULTI_TRY(m, hipStreamSynchronize(c0->stream));
+    if (counters) {
+        prt_counters sum;
+        memset(&sum, 0, sizeof(sum));
+        for (unsigned int g = 0; g < n; ++g) {
+            sum.ray_count += ctr[g].ray_count; sum.node_visits += ctr[g].node_visits; sum.tri_tests += ctr[g].tri_tests;
+            sum.shaded_hits += ctr[g].shaded_hits; sum.trace_kernel_launches += ctr[g].trace_kernel_launches;
+            sum.render_ms = std::max(sum.render_ms, ctr[g].render_ms);                   // the devices run concurrently
+            sum.trace_kernel_ms = std::max(sum.trace_kernel_ms, ctr[g].trace_kernel_ms);
+            sum.pipeline = ctr[g].pipeline;
+        }
+        *counters = sum;
+    }
+    return 0;
+}
+
 }  // extern "C"

@@ -1,10 +1,11 @@
 // render_host.cpp - Render(): the reference's distribution layer (main.cpp:301-358) over the HIP path.
 //
 // Reference: every MPI rank loads the full scene, renders the contiguous pixel range
-// [rank*cpp, (rank+1)*cpp) on one CPU core and MPI_Gathers float RGBA to rank 0.  Here one process
-// drives n GPUs: the flattened scene is uploaded to each (replicated, as every rank does today), GPU r
-// renders the row blocks b with b % n == r (interleaved, because contiguous ranges balance badly -
-// NOTES.txt:25) through prt_render_shard, and the host scatters the packed shards into the frame.
+// [rank*cpp, (rank+1)*cpp) on one CPU core and MPI_Gathers float RGBA to rank 0 (main.cpp:311-347).  Here one
+// process drives n GPUs through ONE handle (include/prt.h prt_multi_*): the flattened scene is uploaded to each
+// (replicated, as every rank does today), GPU r renders the row blocks b with b % n == r (interleaved, because
+// contiguous ranges balance badly - NOTES.txt:25) into its own HBM, the shards travel to GPU 0 as peer-to-peer
+// copies over the fabric, a kernel there puts the rows in place and one copy brings the frame to the host.
 // (bench.py's multi-process path does the same sharding with one rank per GPU and an RCCL gather.)
 #include <cstdio>
 #include <cstdlib>
@@ -24,16 +25,14 @@ u32 gRenderGpuCount = 1;
 
 namespace {
 
-enum { SHARD_BLOCK_ROWS = 8 };
-
 // The uploaded contexts are kept between calls, keyed by a scene id that is never reused (NOT by the scene's address: a
 // freed scene's address is likely to be handed out again for the next one).  0 = no scene.
 struct ContextCache {
     u64 key = 0;
-    std::vector<prt_ctx *> ctxs;
+    prt_multi * multi = NULL;
     void Clear() {
-        for (size_t i = 0; i < ctxs.size(); ++i) prt_destroy(ctxs[i]);
-        ctxs.clear();
+        if (multi) prt_multi_destroy(multi);
+        multi = NULL;
         key = 0;
     }
     ~ContextCache() { Clear(); }
@@ -47,58 +46,21 @@ int RenderFlat(u64 cache_key, const prt_scene_desc * desc, const prt_camera * ca
                u32 width, u32 height, int n_gpus, float * rgba_out, prt_counters * total) {
     std::lock_guard<std::mutex> lock(gRenderMutex);
     if (n_gpus < 1) n_gpus = 1;
-    if (cache_key == 0 || gCache.key != cache_key || (int)gCache.ctxs.size() != n_gpus) {
+    if (cache_key == 0 || gCache.key != cache_key || prt_multi_device_count(gCache.multi) != n_gpus) {
         gCache.Clear();
         // PRT_HOST_SHARE_DEVICE=1: every "GPU" of the call is device 0 (rehearsal of the n_gpus > 1 path on a one-GPU box)
         const char * share = getenv("PRT_HOST_SHARE_DEVICE");
-        for (int g = 0; g < n_gpus; ++g) {
-            prt_ctx * ctx = prt_create(share && atoi(share) ? 0 : g);
-            if (!ctx) { gRenderError = prt_last_error(NULL); gCache.Clear(); return -1; }
-            gCache.ctxs.push_back(ctx);
-            if (prt_upload_scene(ctx, desc) != 0) { gRenderError = prt_last_error(ctx); gCache.Clear(); return -2; }
-        }
+        std::vector<int> ids((size_t)n_gpus);
+        for (int g = 0; g < n_gpus; ++g) ids[(size_t)g] = share && atoi(share) ? 0 : g;
+        gCache.multi = prt_multi_create(ids.data(), n_gpus);
+        if (!gCache.multi) { gRenderError = prt_multi_last_error(NULL); return -1; }
+        if (prt_multi_upload_scene(gCache.multi, desc) != 0) { gRenderError = prt_multi_last_error(gCache.multi); gCache.Clear(); return -2; }
         gCache.key = cache_key;
-    }
-
-    std::vector<prt_counters> ctr((size_t)n_gpus);
-    std::vector<int> rc((size_t)n_gpus, 0);
-    if (n_gpus == 1) {
-        rc[0] = prt_render(gCache.ctxs[0], cam, params, width, height, 0, width * height, rgba_out, &ctr[0]);
-    } else {
-        std::vector<std::vector<float> > shard((size_t)n_gpus);
-        std::vector<std::thread> pool;
-        for (int g = 0; g < n_gpus; ++g) {
-            shard[(size_t)g].resize((size_t)prt_shard_rows(height, SHARD_BLOCK_ROWS, (u32)g, (u32)n_gpus) * width * 4);
-            pool.emplace_back([&, g]() {
-                rc[(size_t)g] = prt_render_shard(gCache.ctxs[(size_t)g], cam, params, width, height, SHARD_BLOCK_ROWS, (u32)g,
-                                                 (u32)n_gpus, shard[(size_t)g].data(), &ctr[(size_t)g]);
-            });
-        }
-        for (size_t t = 0; t < pool.size(); ++t) pool[t].join();
-        for (int g = 0; g < n_gpus; ++g) {
-            if (rc[(size_t)g]) continue;
-            size_t local_row = 0;
-            for (u32 b = (u32)g; (u64)b * SHARD_BLOCK_ROWS < height; b += (u32)n_gpus) {
-                u32 y0 = b * SHARD_BLOCK_ROWS;
-                u32 rows = (height - y0 < (u32)SHARD_BLOCK_ROWS) ? height - y0 : (u32)SHARD_BLOCK_ROWS;
-                memcpy(rgba_out + (size_t)y0 * width * 4, shard[(size_t)g].data() + local_row * width * 4, (size_t)rows * width * 16);
-                local_row += rows;
-            }
-        }
     }
     prt_counters sum;
     memset(&sum, 0, sizeof(sum));
-    for (int g = 0; g < n_gpus; ++g) {
-        if (rc[(size_t)g]) { gRenderError = prt_last_error(gCache.ctxs[(size_t)g]); return rc[(size_t)g]; }
-        sum.ray_count += ctr[(size_t)g].ray_count;
-        sum.node_visits += ctr[(size_t)g].node_visits;
-        sum.tri_tests += ctr[(size_t)g].tri_tests;
-        sum.shaded_hits += ctr[(size_t)g].shaded_hits;
-        if (ctr[(size_t)g].render_ms > sum.render_ms) sum.render_ms = ctr[(size_t)g].render_ms;          // GPUs run concurrently
-        if (ctr[(size_t)g].trace_kernel_ms > sum.trace_kernel_ms) sum.trace_kernel_ms = ctr[(size_t)g].trace_kernel_ms;
-        sum.trace_kernel_launches += ctr[(size_t)g].trace_kernel_launches;
-        sum.pipeline = ctr[(size_t)g].pipeline;
-    }
+    const int rc = prt_multi_render(gCache.multi, cam, params, width, height, rgba_out, &sum);
+    if (rc) { gRenderError = prt_multi_last_error(gCache.multi); return rc; }
     if (total) *total = sum;
     return 0;
 }

@@ -270,3 +270,128 @@ def test_render_stats_of_a_counting_render(gpu_renderer_factory):
         if name == "pool":
             assert st.phase_cycles[3] >= st.phase_cycles[0] + st.phase_cycles[1] + st.phase_cycles[2] > 0
             assert st.parked_rays <= 4 and st.parked_shadow_rays == 0
+
+
+def test_multi_device_handle_gathers_on_the_device_and_matches_one_device():
+    """prt_multi_* (SURVEY.md 8(b)'s multi-device context; what the C++ Render() uses): interleaved 8-row blocks on n contexts,
+    shards moved to device 0 by peer-to-peer copies and put in place by a kernel there, ONE copy to the host.  All three
+    "devices" are GPU 0 here (a peer copy to self): the frame must be the single-context frame bit for bit, and the counters
+    must add up."""
+    from par_raytracer_amd import api, capi
+    lib = capi.hip_lib()
+    w, h = 150, 83                                     # not a multiple of the block height: the last block is short
+    s, hs, cam = _setup("terrain_64", w, h)
+    p = api.default_params(3, 99)
+    r = api.Renderer(0)
+    r.upload(hs)
+    want, wc = r.render(cam, p, w, h)
+    r.close()
+    for n in (1, 2, 3):
+        ids = (C.c_int * n)(*([0] * n))
+        m = lib.prt_multi_create(ids, n)
+        assert m, lib.prt_multi_last_error(None)
+        try:
+            assert lib.prt_multi_device_count(m) == n
+            assert lib.prt_multi_upload_scene(m, hs.desc) == 0, lib.prt_multi_last_error(m)
+            out = np.zeros((h * w, 4), dtype=np.float32)
+            ctr = capi.PrtCounters()
+            for _ in range(2):                         # the second call reuses every buffer
+                assert lib.prt_multi_render(m, C.byref(cam), C.byref(p), w, h, out.ctypes.data, C.byref(ctr)) == 0, lib.prt_multi_last_error(m)
+                assert ctr.ray_count == wc.ray_count
+                assert np.array_equal(out.view(np.uint32), want.view(np.uint32)), n
+        finally:
+            lib.prt_multi_destroy(m)
+    assert not lib.prt_multi_create(None, 0)
+
+
+def test_options_are_set_through_the_abi_not_the_environment(monkeypatch):
+    """prt_set_option: the environment is read once, at prt_create; afterwards only the ABI changes a knob.  Unknown names and
+    values that do not parse are errors."""
+    from par_raytracer_amd import api
+    w, h = 64, 36
+    s, hs, cam = _setup("terrain_64", w, h)
+    p = api.default_params(2, 5, pipeline=PIPELINES["pool"])
+    r = api.Renderer(0)
+    try:
+        r.upload(hs)
+        a, ca = r.render(cam, p, w, h)
+        monkeypatch.setenv("PRT_PASS_SAMPLES", "100")              # too late for this context: one launch still
+        b, cb = r.render(cam, p, w, h)
+        assert cb.trace_kernel_launches == ca.trace_kernel_launches == 1
+        r.set_option("PRT_PASS_SAMPLES", 100)                       # prefix and case do not matter
+        c, cc = r.render(cam, p, w, h)
+        assert cc.trace_kernel_launches > 1 and cc.ray_count == ca.ray_count
+        assert np.array_equal(a.view(np.uint32), c.view(np.uint32))
+        r.set_option("pass_samples", None)
+        r.set_option("TRACE_DEAD_SHADOW_RAYS", 1)                   # a behaviour switch: same image, same count, every ray traced
+        d, cd = r.render(cam, api.default_params(2, 5, pipeline=PIPELINES["pool"] | 0x100), w, h)
+        assert cd.ray_count == ca.ray_count and np.array_equal(a.view(np.uint32), d.view(np.uint32))
+        assert r.render_stats().elided_shadow_rays == 0
+        with pytest.raises(RuntimeError, match="unknown option"):
+            r.set_option("NO_SUCH_KNOB", 1)
+        with pytest.raises(RuntimeError, match="unknown option or bad value"):
+            r.set_option("STACK_CAP", "many")
+        with pytest.raises(RuntimeError, match="creation only"):
+            r.set_option("RESERVE_CUS", 8)
+    finally:
+        r.close()
+    r2 = api.Renderer(0)                                             # a NEW context does read the environment
+    try:
+        r2.upload(hs)
+        e, ce = r2.render(cam, p, w, h)
+        assert ce.trace_kernel_launches > 1 and np.array_equal(a.view(np.uint32), e.view(np.uint32))
+    finally:
+        r2.close()
+
+
+def test_park_lists_sized_for_a_few_pixels_with_many_shadow_rays():
+    """The pool pipeline's park lists are clamped to the frame's worst case.  For a handful of pixels that worst case is not
+    pixels x lights: every shaded hit of a sample's bounce tree emits one shadow ray per light, and with two-entry stack columns
+    all of them are parked.  Point light + directional light over coincident geometry, depth 4, 20 pixels, lists that start at
+    8 entries: the pixels must be those of an ordinary render."""
+    from par_raytracer_amd import api
+    w, h, lat = 160, 120, 32
+    s, hs, cam = _setup("coincident", w, h, light_mode=2)
+    p = api.default_params(4, 31, bounce_depth=4, pipeline=PIPELINES["pool"])
+    r = api.Renderer(0)
+    try:
+        r.upload(hs)
+        want, wc = r.render_lattice(cam, p, w, h, lat)
+        r.set_option("POOL_PARK_CAP", 8)
+        r.set_option("STACK_CAP", 2)
+        got, gc = r.render_lattice(cam, p, w, h, lat)
+        st_parked = r.render_stats()
+    finally:
+        r.close()
+    assert gc.ray_count == wc.ray_count
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+def test_near_tie_resolution_that_gives_up_is_reported():
+    """resolve_near_ties widens its candidate set until the band above it is empty; if it ever ran out of widenings the hit
+    would be decided over an incomplete set.  That is counted on the device and fails the call (TIE_WIDEN_MAX = 0 forces it on
+    the coincident-geometry scene, where candidates do sit in the band)."""
+    from par_raytracer_amd import api
+    g = load_golden_or_skip("coincident_192x144_d3")
+    w, h = int(g["width"]), int(g["height"])
+    hs = host_scene(str(g["scene"]), 0)
+    from conftest import camera_and_params
+    cam, p = camera_and_params(g, PIPELINES["pool"])
+    r = api.Renderer(0)
+    try:
+        r.upload(hs)
+        ok, c = r.render(cam, p, w, h)
+        assert c.ray_count == int(g["ray_count"])
+        r.set_option("TIE_WIDEN_MAX", 0)
+        with pytest.raises(RuntimeError, match="near-tied hits could not be resolved"):
+            r.render(cam, p, w, h)
+        r.set_option("TIE_WIDEN_MAX", None)
+        again, c2 = r.render(cam, p, w, h)
+        assert np.array_equal(ok.view(np.uint32), again.view(np.uint32))
+    finally:
+        r.close()
+
+
+def load_golden_or_skip(name):
+    from conftest import load_golden
+    return load_golden(name)

@@ -20,6 +20,7 @@ pass write WRITE_SIZE
 pass sq1 SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_BUSY_CYCLES SQ_WAVES
 pass sq2 SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS
 pass ta GRBM_GUI_ACTIVE TA_TA_BUSY_sum TA_BUSY_avr
+pass tcp TCP_TCP_LATENCY_sum TCP_TA_TCP_STATE_READ_sum TCP_PENDING_STALL_CYCLES_sum
 echo "adaptive trace" | tee -a "$out/progress.txt"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace_other" -- python3 $root/bench.py --no-cpu-baseline --steps 2 --warmup 1 > "$out/trace_other.log" 2>&1 || echo "trace_other failed" >> "$out/failed.txt"
 echo done | tee -a "$out/progress.txt"

@@ -5,7 +5,7 @@ import collections, csv, glob, json, os, shutil, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(ROOT, "gpurun_out", "prof_round")
 dst = os.path.join(ROOT, "profiles")
-rnd = sys.argv[1] if len(sys.argv) > 1 else "r02"
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r03"
 
 def short(name):
     return name.replace("void prt::", "").replace("prt::", "").split("(")[0]
@@ -27,8 +27,19 @@ for tag, name in (("trace", "%s_pool_C4_kernel_stats.csv" % rnd), ("trace_other"
 fetch, nf = counters("fetch"); write, _ = counters("write")
 sq1, n1 = counters("sq1"); sq2, _ = counters("sq2"); ta, nta = counters("ta")
 FAST = "k_pool<256, 5, false, true, false, false, false, false, false>"        # the timed frames' kernel (COUNT = false, EXACT = false)
+import hashlib, subprocess
+lib = os.path.join(ROOT, "par_raytracer_amd", "libprt_hip.so")
+try:
+    commit = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], stdout=subprocess.PIPE).stdout.decode().strip()
+except Exception:
+    commit = None
+sys.path.insert(0, ROOT)
+from par_raytracer_amd import capi
 out = {"command": "rocprofv3 --pmc <one counter group per pass> --output-format csv -- python3 bench.py --no-cpu-baseline --no-other-workloads --steps 5 --warmup 1",
        "round": rnd, "workload": "C4",
+       # bench.py prints these figures only while the library it runs is the one they were measured on
+       "library": {"sha256": hashlib.sha256(open(lib, "rb").read()).hexdigest(), "abi_version": int(capi.hip_lib().prt_abi_version()),
+                   "build_flags": int(capi.hip_lib().prt_build_flags()), "kernel": FAST, "commit": commit},
        "unit_note": "FETCH_SIZE / WRITE_SIZE are KiB; raw = FETCH + WRITE (lower bound), corrected = 2*FETCH + WRITE (gfx950 FETCH_SIZE halving, upper bound)",
        "kernels": {}}
 for k in sorted(fetch):
@@ -46,6 +57,7 @@ if FAST in sq1:
     # waves of a SIMD it is that SIMD's vector-pipe busy time.  SQ_BUSY_CYCLES is per SE-level SQ; the ratio below follows
     # (ACTIVE_INST_VALU / WAVE_CYCLES) x resident waves per SIMD.
     out["valu_busy_k_pool"] = round(c["SQ_ACTIVE_INST_VALU"] / c["SQ_WAVE_CYCLES"] * 5.0, 4)
+    out["wait_frac_k_pool"] = round(c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"], 4)
     out["sq_k_pool"] = {k2: c[k2] / max(1, n1[FAST][k2]) for k2 in c}
     out["sq_k_pool"].update({k2: sq2[FAST][k2] / max(1, n1[FAST]["SQ_WAVES"]) for k2 in sq2.get(FAST, {})})
 if FAST in ta:
@@ -53,6 +65,9 @@ if FAST in ta:
     per_xcd_active = c["GRBM_GUI_ACTIVE"] / 8.0
     out["ta_busy_k_pool"] = round(c["TA_TA_BUSY_sum"] / 256.0 / per_xcd_active, 4)       # 256 texture addressers (one per compute unit)
     out["ta_busy_avr_k_pool"] = round(c["TA_BUSY_avr"] / per_xcd_active, 4)
+tcp, _ = counters("tcp")
+if FAST in tcp and tcp[FAST].get("TCP_TA_TCP_STATE_READ_sum"):
+    out["l1_latency_clk_k_pool"] = round(tcp[FAST]["TCP_TCP_LATENCY_sum"] / tcp[FAST]["TCP_TA_TCP_STATE_READ_sum"], 1)
 json.dump(out, open(os.path.join(dst, "traffic_C4.json"), "w"), indent=1)
 with open(os.path.join(dst, "%s_pool_C4_issue_stalls.txt" % rnd), "w") as f:
     f.write("k_pool (fast kernel, one launch per C4 frame), rocprofv3 --pmc passes of bench.py (tools/profile_round.sh)\n")
