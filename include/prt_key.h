@@ -13,7 +13,7 @@
 
 #include <stdint.h>
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define PRT_KEY_FN static inline __host__ __device__
 #else
 #define PRT_KEY_FN static inline

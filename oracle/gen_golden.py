@@ -27,6 +27,8 @@ sys.path.insert(0, HERE)
 
 import oracle_py as orc                                  # noqa: E402
 from par_raytracer_amd import scenes                     # noqa: E402
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import texture_fixtures                                   # noqa: E402,F401  (registers the textured gallery scenes)
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 

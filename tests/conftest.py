@@ -16,6 +16,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
 
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
@@ -44,6 +46,7 @@ _SCENE_DIRS = {}
 def scene_dir(name: str):
     """(ObjScene, directory) with <directory>/scene.obj written once per session."""
     from par_raytracer_amd import scenes
+    import texture_fixtures  # noqa: F401  (registers the textured gallery scenes)
     if name not in _SCENE_DIRS:
         d = tempfile.mkdtemp(prefix="prt_test_%s_" % name)
         s = scenes.make_scene(name)

@@ -14,6 +14,7 @@ import zlib
 import numpy as np
 import pytest
 
+import texture_fixtures
 from conftest import ROOT, host_scene, load_golden, scene_dir
 
 from par_raytracer_amd import api, capi, scenes
@@ -217,7 +218,7 @@ def test_tga_corner_cases_bit_identical_to_reference_and_round_trip(tmp_path):
                              ("tga_map24", few, few), ("tga_map32_rle", few_a, few_a), ("tga_map24_i16", rgb, rgb),
                              ("tga_map16", few, ((few >> 3).astype(np.uint32) * 255 // 31).astype(np.uint8))):
         path = str(tmp_path / ("t_%s.tga" % enc))
-        scenes.write_texture(path, img, enc)
+        texture_fixtures.write_texture(path, img, enc)
         got = _load_texture(lib, path)
         assert got is not None and got.shape == expect.shape and np.array_equal(got, expect), enc
 
@@ -241,7 +242,7 @@ def test_gif_bit_identical_to_reference_and_round_trip(tmp_path):
     key = (img == img[0, 0]).all(axis=2)
     for enc in ("gif", "gif_i", "gif_t", "gif_local_i_t"):
         path = str(tmp_path / ("t_%s.gif" % enc))
-        scenes.write_texture(path, img, enc)
+        texture_fixtures.write_texture(path, img, enc)
         got = _load_texture(lib, path)
         assert got is not None and got.shape == (23, 31, 4), enc
         if "t" in enc.split("_", 1)[-1] and enc != "gif_i":
@@ -249,7 +250,7 @@ def test_gif_bit_identical_to_reference_and_round_trip(tmp_path):
         else:
             assert np.array_equal(got[:, :, :3], img) and np.all(got[:, :, 3] == 255), enc
     path = str(tmp_path / "canvas.gif")
-    scenes.write_texture(path, img, "gif_canvas")
+    texture_fixtures.write_texture(path, img, "gif_canvas")
     got = _load_texture(lib, path)
     assert got is not None and got.shape == (28, 38, 4)
     assert np.array_equal(got[2:25, 3:34, :3], img) and np.all(got[2:25, 3:34, 3] == 255)
@@ -275,7 +276,7 @@ def test_psd_bit_identical_to_reference_and_round_trip(tmp_path):
     rgba = np.concatenate([rgb, np.where(rng.integers(0, 2, size=(9, 13, 1)) > 0, 255, 0).astype(np.uint8)], axis=2)
     for enc, img in (("psd", rgb), ("psd_rle", rgb), ("psd16", rgb), ("psd", rgba), ("psd_rle", rgba)):
         path = str(tmp_path / ("t_%s.psd" % enc))
-        scenes.write_texture(path, img, enc)
+        texture_fixtures.write_texture(path, img, enc)
         got = _load_texture(lib, path)
         assert got is not None and got.shape == (9, 13, 4) and np.array_equal(got[:, :, :img.shape[2]], img), enc
         if img.shape[2] == 3:
@@ -299,7 +300,7 @@ def test_hdr_bit_identical_to_reference(tmp_path):
     want = (np.clip(rad, 0, None) ** (1 / 2.2) * 255 + 0.5).clip(0, 255)
     for enc in ("hdr", "hdr_flat"):
         path = str(tmp_path / ("t_%s.hdr" % enc))
-        scenes.write_texture(path, rad, enc)
+        texture_fixtures.write_texture(path, rad, enc)
         got = _load_texture(lib, path)
         assert got is not None and got.shape == (12, 20, 3), enc
         assert np.abs(got.astype(np.float64) - want).max() <= 5.0, enc         # the 8-bit shared-exponent mantissa truncates
@@ -323,7 +324,7 @@ def test_pic_bit_identical_to_reference_and_round_trip(tmp_path):
     for enc in ("pic", "pic_raw", "pic_pure"):
         for img in (rgb, rgba):
             path = str(tmp_path / ("t_%s_%d.pic" % (enc, img.shape[2])))
-            scenes.write_texture(path, img, enc)
+            texture_fixtures.write_texture(path, img, enc)
             got = _load_texture(lib, path)
             assert got is not None and got.shape == img.shape and np.array_equal(got, img), (enc, img.shape)
 
@@ -339,15 +340,15 @@ def test_bmp_flavours_round_trip(tmp_path):
     few = (rng.integers(0, 2, size=(9, 7, 3), dtype=np.uint8) * 200 + 20).astype(np.uint8)
     for enc, img in (("bmp", rgb), ("bmp_top", rgb), ("bmp_os2", rgb), ("bmp_os2_8", few), ("bmp8", few), ("bmp4", few), ("bmp32", rgba), ("bmp32_v4", rgba)):
         path = str(tmp_path / ("t_%s.bmp" % enc))
-        scenes.write_texture(path, img, enc)
+        texture_fixtures.write_texture(path, img, enc)
         got = _load_texture(lib, path)
         assert got is not None and got.shape == img.shape and np.array_equal(got, img), enc
     path = str(tmp_path / "t16.bmp")
-    scenes.write_texture(path, rgb, "bmp16")
+    texture_fixtures.write_texture(path, rgb, "bmp16")
     got = _load_texture(lib, path)
     q = rgb >> 3
     assert got is not None and np.array_equal(got, ((q << 3) | (q >> 2)).astype(np.uint8))
-    scenes.write_texture(path, rgb, "bmp32")                          # alpha bytes all 0
+    texture_fixtures.write_texture(path, rgb, "bmp32")                          # alpha bytes all 0
     got = _load_texture(lib, path)
     assert got is not None and got.shape == (9, 7, 4) and np.array_equal(got[:, :, :3], rgb) and np.all(got[:, :, 3] == 255)
 
@@ -364,7 +365,7 @@ def test_png_variants_round_trip_with_every_filter(tmp_path):
 
     def check(img, expect, **kw):
         path = str(tmp_path / "v.png")
-        scenes.write_png(path, img, filters=allf, **kw)
+        texture_fixtures.write_png(path, img, filters=allf, **kw)
         got = _load_texture(lib, path)
         assert got is not None and got.shape == expect.shape and np.array_equal(got, expect), (img.shape, kw)
 
@@ -395,7 +396,7 @@ def test_png_variants_round_trip_with_every_filter(tmp_path):
 
 
 def test_jpeg_files_decode_close_to_what_was_encoded(tmp_path):
-    """scenes.write_jpeg is a real (lossy) encoder: what comes back is the picture that went in, within the quantisation
+    """texture_fixtures.write_jpeg is a real (lossy) encoder: what comes back is the picture that went in, within the quantisation
     error, for every layout - so the bit-identity test above is about pictures, not about noise."""
     from par_raytracer_amd import scenes
     lib = capi.host_lib()
@@ -403,21 +404,21 @@ def test_jpeg_files_decode_close_to_what_was_encoded(tmp_path):
     img = np.stack([128 + 100 * np.sin(xx * 0.21) * np.cos(yy * 0.17), 128 + 90 * np.cos(yy * 0.3), 40 + 2.5 * xx], axis=2).clip(0, 255).astype(np.uint8)
     for enc in ("jpg", "jpg422", "jpg440", "jpg420", "jpg411", "jpg420_rst", "jpg_scans", "jpg_rgb", "jpg_prog", "jpg_prog420", "jpg_prog422_rst"):
         path = str(tmp_path / ("t_%s.jpg" % enc))
-        scenes.write_texture(path, img, enc)
+        texture_fixtures.write_texture(path, img, enc)
         got = _load_texture(lib, path)
         assert got is not None and got.shape == img.shape, enc
         err = np.abs(got.astype(np.int32) - img.astype(np.int32))
         assert err.mean() < 6.0 and np.percentile(err, 99) < 40, (enc, err.mean(), err.max())
     path = str(tmp_path / "grey.jpg")
     for enc in ("jpg", "jpg_prog"):
-        scenes.write_texture(path, img[:, :, 0], enc)
+        texture_fixtures.write_texture(path, img[:, :, 0], enc)
         got = _load_texture(lib, path)
         assert got is not None and got.shape == (45, 70, 1), enc
         assert np.abs(got[:, :, 0].astype(np.int32) - img[:, :, 0].astype(np.int32)).mean() < 4.0, enc
 
 
 def test_texture_writers_round_trip_through_the_loader(tmp_path):
-    """Every encoding of scenes.write_texture decodes to the array that was written (16-bit PNG keeps the high
+    """Every encoding of texture_fixtures.write_texture decodes to the array that was written (16-bit PNG keeps the high
     byte; palette images come back as RGB / RGBA)."""
     from par_raytracer_amd import scenes
     rng = np.random.default_rng(5)
@@ -428,14 +429,14 @@ def test_texture_writers_round_trip_through_the_loader(tmp_path):
         img = rng.integers(0, 256, size=(13, 7, ch), dtype=np.uint8)
         img[3:9, 1:6] = img[3, 1]                                   # runs, so the run-length packets are exercised
         path = str(tmp_path / ("t_%s_%d.img" % (enc, ch)))
-        scenes.write_texture(path, img, enc)
+        texture_fixtures.write_texture(path, img, enc)
         got = _load_texture(lib, path)
         assert got is not None, (enc, ch)
         assert got.shape == img.shape and np.array_equal(got, img), (enc, ch)
     few = (rng.integers(0, 4, size=(9, 11, 4), dtype=np.uint8) * 80).astype(np.uint8)
     for enc, ch in (("png_palette", 3), ("png_palette_alpha", 4)):
         path = str(tmp_path / ("p_%s.png" % enc))
-        scenes.write_texture(path, few[:, :, :ch], enc)
+        texture_fixtures.write_texture(path, few[:, :, :ch], enc)
         got = _load_texture(lib, path)
         assert got is not None and np.array_equal(got, few[:, :, :ch]), enc
 
@@ -449,18 +450,18 @@ def test_unsupported_images_leave_the_slot_empty_like_a_decoder_failure(tmp_path
     assert _load_texture(lib, str(bad)) is None
     from par_raytracer_amd import scenes as _scenes
     prog = tmp_path / "arithmetic.jpg"
-    _scenes.write_texture(str(prog), np.full((16, 16, 3), 90, dtype=np.uint8), "jpg")
+    texture_fixtures.write_texture(str(prog), np.full((16, 16, 3), 90, dtype=np.uint8), "jpg")
     raw = bytearray(prog.read_bytes())
     raw[raw.index(b"\xff\xc0") + 1] = 0xC9                    # SOF0 -> SOF9: arithmetic coding, which the reference's decoder rejects too
     prog.write_bytes(bytes(raw))
     assert _load_texture(lib, str(prog)) is None
     cut = tmp_path / "cut.jpg"
-    _scenes.write_texture(str(cut), np.full((24, 24, 3), 90, dtype=np.uint8), "jpg420")
+    texture_fixtures.write_texture(str(cut), np.full((24, 24, 3), 90, dtype=np.uint8), "jpg420")
     cut.write_bytes(cut.read_bytes()[:150])
     assert _load_texture(lib, str(cut)) is None
     trunc = tmp_path / "t.png"
     from par_raytracer_amd import scenes
-    scenes.write_texture(str(trunc), np.zeros((8, 8, 3), dtype=np.uint8), "png")
+    texture_fixtures.write_texture(str(trunc), np.zeros((8, 8, 3), dtype=np.uint8), "png")
     trunc.write_bytes(trunc.read_bytes()[:40])
     assert _load_texture(lib, str(trunc)) is None
     assert _load_texture(lib, str(tmp_path / "missing.tga")) is None
@@ -485,7 +486,7 @@ def test_malformed_obj_and_image_files_fail_cleanly(tmp_path):
     (tmp_path / "later.obj").write_text("vt 0 0\nvn 0 0 1\ng a\nf 1/1/1 2/1/1 3/1/1\nv 0 0 0\nv 1 0 0\nv 0 1 0\n")   # vertices after the face: fine
     assert api.HostScene(str(tmp_path), "later.obj").n_tris == 1
     png = bytearray()
-    scenes.write_texture(str(tmp_path / "ok.png"), np.zeros((4, 4, 3), dtype=np.uint8), "png")
+    texture_fixtures.write_texture(str(tmp_path / "ok.png"), np.zeros((4, 4, 3), dtype=np.uint8), "png")
     png = bytearray((tmp_path / "ok.png").read_bytes())
     png[16:24] = b"\xff\xff\xff\xf0\xff\xff\xff\xf0"                                            # IHDR width / height
     (tmp_path / "huge.png").write_bytes(bytes(png))

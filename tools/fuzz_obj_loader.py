@@ -3,7 +3,9 @@
 import sys, os, ctypes as C, tempfile
 sys.path.insert(0, "/root/repo")
 import numpy as np
+sys.path.insert(0, "/root/repo/tests")
 from par_raytracer_amd import scenes
+import texture_fixtures  # registers the textured gallery scenes
 lib = C.CDLL(os.environ.get("PRT_HOST_LIB", "/root/repo/par_raytracer_amd/libprt_host.so"))
 lib.prt_host_load_obj.restype = C.c_void_p
 lib.prt_host_load_obj.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.POINTER(C.c_float)]

@@ -5,7 +5,9 @@ ROOT = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import numpy as np
 import oracle_py as orc
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 from par_raytracer_amd import api, scenes
+import texture_fixtures  # registers the textured gallery scenes
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 names = ["coincident", "cornell_box", "sphere_plane", "icosphere_l3", "terrain_64", "many_materials", "textured_gallery", "terrain_192", "jpeg_gallery", "png_gallery", "bmp_gallery", "tga_gallery"]

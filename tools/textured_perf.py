@@ -2,13 +2,16 @@
 import sys, os, tempfile
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import numpy as np, torch
+sys.path.insert(0, os.path.join(os.environ.get("GRAFT_REPO_ROOT", "/root/repo"), "tests"))
 from par_raytracer_amd import api, scenes
+import texture_fixtures
 s = scenes.make_scene("terrain_1m")
 rng = np.random.default_rng(1)
 yy, xx = np.mgrid[0:1024, 0:1024]
 kd = np.stack([(128 + 100 * np.sin(xx / 37.0) * np.cos(yy / 53.0)), (140 + 80 * np.sin(xx / 11.0)), (120 + 60 * np.cos(yy / 19.0))], axis=2).clip(0, 255).astype(np.uint8)
 bump = (128 + 100 * np.sin(xx / 5.0) * np.sin(yy / 7.0)).clip(0, 255).astype(np.uint8)
 s.textures = {"kd.png": (kd, "png"), "bump.tga": (bump, "tga")}
+s.texture_writer = texture_fixtures.write_texture
 for m in s.materials:
     m.map_Kd = "kd.png"; m.map_bump = "bump.tga"
 d = tempfile.mkdtemp(); scenes.write_obj(s, d, "scene.obj")
