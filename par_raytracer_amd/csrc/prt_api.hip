@@ -33,6 +33,10 @@
 
 using namespace prt;
 
+#ifndef PRT_POOL_WAVES
+#define PRT_POOL_WAVES 5          // waves per SIMD of the fixed-spp pool kernel: 96 VGPRs (6 = 80 VGPRs spills, profiles/r03_ab_bvh8.txt)
+#endif
+
 // The acceleration structure the library is built with (dev_trace.h): 8-wide octant-ordered, or -DPRT_BVH4 the 4-wide
 // sorted one of rounds 1-2.
 #if defined(PRT_BVH4)
@@ -961,8 +965,8 @@ int render_pixels_once(prt_ctx * ctx, const prt_camera * cam_in, const prt_param
                                    : launch_pool<256, 4, false, true, false, true>(ctx, count_visits, cam, P, n_samples, stack_entries);
             else
                 rc = ctx->textured ? launch_pool<256, 4, false, true, true, false>(ctx, count_visits, cam, P, n_samples, stack_entries)
-                   : ring ? launch_pool<256, 5, false, true, false, false>(ctx, count_visits, cam, P, n_samples, stack_entries)
-                          : launch_pool<256, 5, false, true, false, false, false>(ctx, count_visits, cam, P, n_samples, stack_entries);
+                   : ring ? launch_pool<256, PRT_POOL_WAVES, false, true, false, false>(ctx, count_visits, cam, P, n_samples, stack_entries)
+                          : launch_pool<256, PRT_POOL_WAVES, false, true, false, false, false>(ctx, count_visits, cam, P, n_samples, stack_entries);
             launches += 1;
         } else {
             unsigned long long rays = 0;

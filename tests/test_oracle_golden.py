@@ -19,7 +19,7 @@ FAST = ["c1_sphere_plane_256", "c2_cornell_128", "c2_cornell_512_l4", "cornell_p
         "icosphere_l3_two_lights", "terrain64_d3", "coincident_192x144_d3", "coincident_two_lights", "gallery_160x120", "gallery_two_lights_d4",
         "cornell_adaptive_4_16", "gallery_adaptive_10_50", "terrain64_adaptive_3_12_d4", "many_materials_two_lights",
         "jpeg_gallery_128x96", "png_gallery_128x96", "bmp_gallery_128x96", "tga_gallery_128x96", "gif_gallery_128x96", "psd_gallery_128x96", "hdr_gallery_128x96", "pic_gallery_128x96"]
-SLOW = ["terrain192_d2", "c3_icosphere_1080p_l24", "c4_terrain1m_1080p_l40", "c4_terrain1m_adaptive_l60"]
+SLOW = ["terrain192_d2", "c3_icosphere_1080p_l24", "c4_terrain1m_1080p_l40", "c4_terrain1m_adaptive_l60", "c5_terrain1m_4k_l120"]
 
 
 def _check(name, threads=8):
