@@ -630,6 +630,31 @@ void finish_bvh8q_impl(Builder & b, uint32_t n_tris, Bvh8Result * out) {
                 }
             int axis = 0;
             for (int a = 1; a < 3; ++a) if (hi[a] - lo[a] > hi[axis] - lo[axis]) axis = a;
+            if (b.opt.axis_rule == 1) {
+                // experiment: the longest axis of the node's box
+                Box u2; u2.reset();
+                for (uint32_t k = 0; k < n; ++k) u2.grow(b.pool[kids[k]].box);
+                axis = 0;
+                for (int a = 1; a < 3; ++a) if (u2.hi[a] - u2.lo[a] > u2.hi[axis] - u2.lo[axis]) axis = a;
+            } else if (b.opt.axis_rule == 2) {
+                // experiment: the axis along which the children's boxes, sorted by centre, overlap least (sum over all pairs of
+                // the overlap of their intervals, relative to the node's extent on that axis)
+                float best = FLT_MAX;
+                for (int a = 0; a < 3; ++a) {
+                    float ext = 0.0f, lo_a = FLT_MAX, hi_a = -FLT_MAX;
+                    for (uint32_t k = 0; k < n; ++k) { lo_a = std::min(lo_a, b.pool[kids[k]].box.lo[a]); hi_a = std::max(hi_a, b.pool[kids[k]].box.hi[a]); }
+                    ext = hi_a - lo_a;
+                    if (!(ext > 0.0f)) continue;
+                    float ov = 0.0f;
+                    for (uint32_t i = 0; i < n; ++i)
+                        for (uint32_t j = i + 1; j < n; ++j) {
+                            const Box & bi = b.pool[kids[i]].box, & bj = b.pool[kids[j]].box;
+                            const float o = std::min(bi.hi[a], bj.hi[a]) - std::max(bi.lo[a], bj.lo[a]);
+                            if (o > 0.0f) ov += o / ext;
+                        }
+                    if (ov < best) { best = ov; axis = a; }
+                }
+            }
             uint32_t order[8];
             for (uint32_t k = 0; k < n; ++k) order[k] = k;
             std::sort(order, order + n, [&](uint32_t x, uint32_t y) { return c[x][axis] < c[y][axis]; });

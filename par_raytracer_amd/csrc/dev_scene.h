@@ -194,9 +194,24 @@ PRT_D void accum_zero(Accum * a) { a->x = 0; a->y = 0; a->z = 0; a->w = 0; }
 // park it for a memory round trip at every finished shadow ray), and several shadow rays of one sample may finish at once.
 // They are performed in the L2, past the compute unit's vector L1 - so reads must not be served from that L1 either.
 PRT_D void accum_add(Accum * a, f3 c) {
+
     __hip_atomic_fetch_add(reinterpret_cast<unsigned long long *>(&a->x), (unsigned long long)accum_fix(c.x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_fetch_add(reinterpret_cast<unsigned long long *>(&a->y), (unsigned long long)accum_fix(c.y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_fetch_add(reinterpret_cast<unsigned long long *>(&a->z), (unsigned long long)accum_fix(c.z), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// Additions by the sample's OWNER: a lane that is, for the duration of its phase, the only one that touches *a (the shading
+// lane of the sample's one closest-hit ray: kernels_wave.h shade_entry_on).  A plain read-modify-write - loads past the L1,
+// where a shadow ray's atomic of the previous phase may have changed the record in the L2 - of one 24-byte run that the lanes
+// of a wave (consecutive samples) read and write as whole cache lines, in two halves so that the load is issued with the
+// caller's other loads and the rest done when the contribution is known.  Integer addition: the result is the same bits
+// whichever way a contribution arrives (the shadow rays' still arrive as atomics).
+PRT_D void accum_load_owner(const Accum * a, long long & x, long long & y, long long & z) {
+    x = __hip_atomic_load(&a->x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    y = __hip_atomic_load(&a->y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    z = __hip_atomic_load(&a->z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+PRT_D void accum_store_owner(Accum * a, long long x, long long y, long long z, f3 c) {
+    a->x = x + accum_fix(c.x); a->y = y + accum_fix(c.y); a->z = z + accum_fix(c.z);
 }
 PRT_D f3 accum_read(const Accum * a) {
     const long long x = __hip_atomic_load(&a->x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

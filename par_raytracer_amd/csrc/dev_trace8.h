@@ -29,6 +29,12 @@ namespace prt {
 
 typedef int2 StackEntry;                 // (child_base, imask | unvisited hit slots << 8); the marker: (TRAV_SENTINEL | flags, 0)
 enum { STACK_ENTRY_INTS = 2, BVH_NODE_BYTES = 80, STACK_LDS_CAP_DEFAULT = 13 };
+// distance between nodes in the device array: 80 = packed.  (Experiment -DPRT_BVH8_STRIDE=128: one node per 128-byte cache line,
+// so that no node straddles two lines - half of the packed ones do; profiles/r03_ab_bvh8.txt item 7.)
+#ifndef PRT_BVH8_STRIDE
+#define PRT_BVH8_STRIDE 80
+#endif
+enum { BVH_NODE_STRIDE = PRT_BVH8_STRIDE };
 
 // Per-lane traversal registers.  A ray can be suspended and resumed at any step boundary.
 struct TravRay {
@@ -175,7 +181,7 @@ PRT_D unsigned int trav_pick_slot(unsigned int rest, unsigned int oct) {
 template <class STK, bool COUNT>
 PRT_D void trav_node_step(const DevScene & sc, TravRay & r, const STK & stk, TraceStats & st, float pad) {
     // 32-bit byte offset from the (scalar) array base (upload caps the scene at 2^26 triangles)
-    const uint4 * np = reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(sc.nodes) + (unsigned int)r.node * 80u);
+    const uint4 * np = reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(sc.nodes) + (unsigned int)r.node * (unsigned int)BVH_NODE_STRIDE);
     const uint4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3], q4 = np[4];
     if (COUNT) { st.nodes++; if (first_active_lane()) st.wnodes++; if ((unsigned int)r.sp > st.max_sp) st.max_sp = (unsigned int)r.sp; }
 #if defined(PRT_PROBE_EXTRA_VALU) && defined(__HIP_DEVICE_COMPILE__)

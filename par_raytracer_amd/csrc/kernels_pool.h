@@ -326,10 +326,12 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_pool(const PoolArgs * args, De
                         sample_begin<RING>(cam, P, pixel_of_local(P, gsid / P.spp), gsid % P.spp, S, fr, ring, B.ring_stride);
                     }
                     B.rng[sid] = make_ulonglong2(S.rng.chain, S.rng.prev);
-                    if (RING) B.rng_aux[sid] = make_ulonglong2(S.rng.seed0, (u64)S.rng.k);
-                    accum_zero(B.accum + sid);
+                    if (RING && RINGMEM) B.rng_aux[sid] = make_ulonglong2(S.rng.seed0, (u64)S.rng.k);     // (seed word 0, draw count): only a sample that can pass 15 draws needs them
+                    // fixed spp: the record is first written by the sample's first shade event (WF_PENDING_FRESH_BIT); the adaptive
+                    // mode's finalise step reads and zeroes it between the samples of a pixel, and starts from a zeroed one
+                    if (ADAPT) accum_zero(B.accum + sid);
                     co[n_c + k] = make_float4(fr.ray_o.x, fr.ray_o.y, fr.ray_o.z, as_f((int)sid));
-                    cd[n_c + k] = make_float4(fr.ray_d.x, fr.ray_d.y, fr.ray_d.z, as_f(0));
+                    cd[n_c + k] = make_float4(fr.ray_d.x, fr.ray_d.y, fr.ray_d.z, as_f(ADAPT ? 0 : (int)WF_PENDING_FRESH_BIT << 8));
                     ct[n_c + k] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
                 }
                 n_c += cnt;

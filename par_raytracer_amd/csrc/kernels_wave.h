@@ -32,6 +32,10 @@ namespace prt {
 
 enum { WF_KIND_CLOSEST = 0, WF_KIND_SHADOW_ANY = 1, WF_KIND_SHADOW_DIST = 2 };
 enum { WF_STAGE_REFL = 0, WF_STAGE_SPEC = 1, WF_STAGE_ALPHA = 2, WF_STAGE_DONE = 3 };
+// In a closest-hit list entry's `pending` field (24 bits; the low 17 are the levels with a parked frame): this is the FIRST
+// closest-hit ray of its sample, so the sample's radiance record holds nothing yet - the shading lane does not read it and
+// writes it whatever it adds (no zero fill when the sample is fetched, no read at its first hit: 56 bytes per sample).
+enum { WF_PENDING_FRESH_BIT = 0x400000 };
 
 struct WaveBuffers {
     Accum * accum;               // [N] per-sample radiance (xyz), fixed point (dev_scene.h)
@@ -111,9 +115,8 @@ __global__ __launch_bounds__(256) void k_raygen(DevCamera cam, DevParams P, Wave
     sample_begin<RING>(cam, P, pixel, samp, S, cur, ring, B.ring_stride);
     B.rng[sid] = make_ulonglong2(S.rng.chain, S.rng.prev);
     if (RING) B.rng_aux[sid] = make_ulonglong2(S.rng.seed0, (u64)S.rng.k);
-    accum_zero(B.accum + sid);
     B.rq_o[0][sid] = make_float4(cur.ray_o.x, cur.ray_o.y, cur.ray_o.z, as_f((int)sid));
-    B.rq_d[0][sid] = make_float4(cur.ray_d.x, cur.ray_d.y, cur.ray_d.z, as_f(0));
+    B.rq_d[0][sid] = make_float4(cur.ray_d.x, cur.ray_d.y, cur.ray_d.z, as_f((int)WF_PENDING_FRESH_BIT << 8));
     B.rq_t[0][sid] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
 }
 
@@ -305,7 +308,7 @@ __global__ __launch_bounds__(256) void k_trace_exact(DevScene sc, DevParams P, W
 // ---------------------------------------------------------------------------------------------------------
 // Pending frame record: FR4 float4 per (level, sample).
 //   f0 = (hit_p.xyz, mat)  f1 = (hit_n.xyz, stage | idx << 8)  f2 = (ray_d.xyz, alpha)  f3 = (T_in.xyz, w_diffuse)
-//   f4 = (hit_pos.xyz, -)   only when translucent materials exist (alpha continuation, raytracer.cpp:547-552)
+//   f4 = (hit_pos.xyz, -)   only when translucent materials can occur (alpha continuation, raytracer.cpp:547-552)
 //   f5 = (Kd.xyz, -)  f6 = (Ks.xyz, -)   only for textured scenes: the hit's own colours (raytracer.cpp:455-462);
 //                                        untextured scenes re-read them from the material table instead
 struct WFrame {
@@ -353,35 +356,37 @@ struct WFrameLds {
 };
 enum { WFRAME_LDS_DWORDS = 26 };
 
-template <bool RING, bool TEX, class FrameT>
+// POS: the frame carries hit_pos (alpha continuation rays start there, raytracer.cpp:547-552): only renders that can meet a
+// translucent material (RING && RINGMEM in the pool pipeline, RING in the wavefront pipeline) pay for that fifth float4.
+template <bool POS, bool TEX, class FrameT>
 PRT_D void wframe_save(const WaveBuffers & B, int level, unsigned int s, const FrameT & fr) {
     WFrame f;
     f.hit_p = fr.hit_p; f.hit_n = fr.hit_n; f.ray_d = fr.ray_d; f.T_in = fr.T_in; f.hit_pos = fr.hit_pos; f.kd = fr.kd; f.ks = fr.ks;
     f.alpha = fr.alpha; f.w_diffuse = fr.w_diffuse; f.mat = fr.mat; f.stage = fr.stage; f.idx = fr.idx;
-    constexpr int FR4 = TEX ? 7 : RING ? 5 : 4;
+    constexpr int FR4 = TEX ? 7 : POS ? 5 : 4;
     float4 * p = B.frames + ((size_t)level * FR4) * B.n_samples + s;
     p[0] = make_float4(f.hit_p.x, f.hit_p.y, f.hit_p.z, as_f(f.mat));
     p[(size_t)B.n_samples] = make_float4(f.hit_n.x, f.hit_n.y, f.hit_n.z, as_f(f.stage | (f.idx << 8)));
     p[(size_t)B.n_samples * 2] = make_float4(f.ray_d.x, f.ray_d.y, f.ray_d.z, f.alpha);
     p[(size_t)B.n_samples * 3] = make_float4(f.T_in.x, f.T_in.y, f.T_in.z, f.w_diffuse);
-    if (RING) p[(size_t)B.n_samples * 4] = make_float4(f.hit_pos.x, f.hit_pos.y, f.hit_pos.z, 0.0f);
+    if (POS) p[(size_t)B.n_samples * 4] = make_float4(f.hit_pos.x, f.hit_pos.y, f.hit_pos.z, 0.0f);
     if (TEX) {
         p[(size_t)B.n_samples * 5] = make_float4(f.kd.x, f.kd.y, f.kd.z, 0.0f);
         p[(size_t)B.n_samples * 6] = make_float4(f.ks.x, f.ks.y, f.ks.z, 0.0f);
     }
 }
 
-template <bool RING, bool TEX, class FrameT>
+template <bool POS, bool TEX, class FrameT>
 PRT_D void wframe_load(const WaveBuffers & B, int level, unsigned int s, FrameT & fr) {
     WFrame f;
-    constexpr int FR4 = TEX ? 7 : RING ? 5 : 4;
+    constexpr int FR4 = TEX ? 7 : POS ? 5 : 4;
     const float4 * p = B.frames + ((size_t)level * FR4) * B.n_samples + s;
     const float4 a = p[0], b = p[(size_t)B.n_samples], c = p[(size_t)B.n_samples * 2], d = p[(size_t)B.n_samples * 3];
     f.hit_p = mk3(a.x, a.y, a.z); f.mat = as_i(a.w);
     f.hit_n = mk3(b.x, b.y, b.z); f.stage = as_i(b.w) & 0xFF; f.idx = as_i(b.w) >> 8;
     f.ray_d = mk3(c.x, c.y, c.z); f.alpha = c.w;
     f.T_in = mk3(d.x, d.y, d.z); f.w_diffuse = d.w;
-    if (RING) {
+    if (POS) {
         const float4 e = p[(size_t)B.n_samples * 4];
         f.hit_pos = mk3(e.x, e.y, e.z);
     } else {
@@ -417,10 +422,19 @@ PRT_D void shade_entry_on(const DevScene & sc, const DevParams & P, const WaveBu
     const int depth = (int)P.bounce_depth;
     Rng rng;
     rng.chain = rng.prev = rng.seed0 = 0; rng.k = 0;
+    // the sample's radiance record, requested with the rest of its state: this lane owns the sample for the phase (a sample has
+    // one closest-hit ray in flight), so what the hit adds is a plain read-modify-write - no atomic -, and the read rides in the
+    // memory round trip the pass makes anyway (dev_scene.h accum_add_owner; at the end of the pass it was a round trip of its own)
+    long long acc_x = 0, acc_y = 0, acc_z = 0;
+    const bool fresh = (pending & (unsigned int)WF_PENDING_FRESH_BIT) != 0u;     // the sample's first closest-hit ray
+    pending &= ~(unsigned int)WF_PENDING_FRESH_BIT;
     if (live) {
         const ulonglong2 rs = B.rng[s];
         rng.chain = rs.x; rng.prev = rs.y;
-        if (RING) { const ulonglong2 ra = B.rng_aux[s]; rng.seed0 = ra.x; rng.k = (u32)ra.y; }
+        // (seed word 0, draws so far) matter from the 15th draw on: a render whose samples provably stop before that
+        // (RINGMEM = false) neither reads nor writes them - 32 bytes less per shaded hit
+        if (RING && RINGMEM) { const ulonglong2 ra = B.rng_aux[s]; rng.seed0 = ra.x; rng.k = (u32)ra.y; }
+        if (!fresh) accum_load_owner(B.accum + s, acc_x, acc_y, acc_z);
     }
     // RINGMEM = false: the general-RNG code without its draw ring in memory, for renders whose samples provably make at
     // most 15 draws (dev_rng.h) - a compile-time NULL, so the ring code folds away
@@ -531,6 +545,9 @@ PRT_D void shade_entry_on(const DevScene & sc, const DevParams & P, const WaveBu
         }
     }
 
+    // everything this invocation adds to the sample is known now (the bounce walk below adds nothing): write the record back
+    if (live && (fresh || add.x != 0.0f || add.y != 0.0f || add.z != 0.0f)) accum_store_owner(B.accum + s, acc_x, acc_y, acc_z, add);
+
     // ---- shadow rays of this hit (raytracer.cpp:507-511, 378-411): radiance-if-unoccluded rides with the ray
     for (unsigned int li = 0; li < sc.light_count; ++li) {
         f3 so = mk3(0, 0, 0), sd = mk3(0, 0, 1), contrib = mk3(0, 0, 0);
@@ -625,7 +642,7 @@ PRT_D void shade_entry_on(const DevScene & sc, const DevParams & P, const WaveBu
             if (!dead) {
                 // the child flies: park its parent frame if that still has children to spawn afterwards
                 if (f_held && f.stage != WF_STAGE_DONE) {
-                    wframe_save<RING, TEX>(B, level, s, f);
+                    wframe_save<RING && RINGMEM, TEX>(B, level, s, f);
                     pending |= 1u << level;
                 }
                 emit_closest = true;
@@ -639,16 +656,15 @@ PRT_D void shade_entry_on(const DevScene & sc, const DevParams & P, const WaveBu
             if (pending == 0u) { mode = M_DONE; break; }
             level = 31 - __clz((int)pending);
             pending &= ~(1u << level);
-            wframe_load<RING, TEX>(B, level, s, f);
+            wframe_load<RING && RINGMEM, TEX>(B, level, s, f);
             mode = M_NEXT_CHILD;
         }
     }
 
     // ---- outputs ------------------------------------------------------------------------------------------
     if (live) {
-        if (add.x != 0.0f || add.y != 0.0f || add.z != 0.0f) accum_add(B.accum + s, add);
         B.rng[s] = make_ulonglong2(rng.chain, rng.prev);
-        if (RING) B.rng_aux[s] = make_ulonglong2(rng.seed0, (u64)rng.k);
+        if (RING && RINGMEM) B.rng_aux[s] = make_ulonglong2(rng.seed0, (u64)rng.k);
     }
     emit.closest(emit_closest, s, next_o, next_d, next_T, next_level, pending, live && !emit_closest);
 }

@@ -553,7 +553,7 @@ int launch_pool(prt_ctx * ctx, bool count, const DevCamera & cam, DevParams P, u
     prt_ctx::ChainWs & w = ctx->chain[0];
     const size_t N = n_samples;
     const unsigned int levels = std::max(1u, P.bounce_depth);
-    const unsigned int fr4 = TEX ? 7u : RING ? 5u : 4u;
+    const unsigned int fr4 = TEX ? 7u : (RING && RINGMEM) ? 5u : 4u;       // kernels_wave.h wframe_save
     HIP_TRY(ctx, w.f4.ensure((size_t)levels * fr4 * N));
     HIP_TRY(ctx, w.rng.ensure(RING ? 2 * N : N));
     HIP_TRY(ctx, ctx->pool_f4.ensure((size_t)waves * (7u * (size_t)cap + 3u * (size_t)scap)));
@@ -1462,8 +1462,14 @@ int prt_upload_scene(prt_ctx * ctx, const prt_scene_desc * s) {
     std::vector<float4> ddirs(1024);
     for (uint32_t i = 0; i < 1024; ++i) ddirs[i] = diffuse_tangent_dir(i);
 
+#if !defined(PRT_BVH4) && PRT_BVH8_STRIDE != 80
+    std::vector<float4> nodes4((size_t)bvh.node_count * (BVH_NODE_STRIDE / 16), make_float4(0, 0, 0, 0));
+    for (uint32_t ni = 0; ni < bvh.node_count; ++ni)
+        memcpy(reinterpret_cast<char *>(nodes4.data()) + (size_t)ni * BVH_NODE_STRIDE, &bvh.nodes[(size_t)ni * BVH8_NODE_DWORDS], BVH8_NODE_DWORDS * 4);
+#else
     std::vector<float4> nodes4(bvh.nodes.size() / 4);
     memcpy(nodes4.data(), bvh.nodes.data(), bvh.nodes.size() * sizeof(uint32_t));
+#endif
     ctx->stack_bound = bvh.stack_bound;
 
     HIP_TRY(ctx, ctx->nodes.upload(nodes4));

@@ -22,6 +22,8 @@ struct BvhBuildOptions {
     long long slot_order = 1;         // 8-wide: 1 = children sorted along the node's ordering axis (what dev_trace8.h expects), 0 = one slot
                                       // per octant (Ylitie et al.; the traversal built with -DPRT_BVH8_OCTANT).  Set by the library, not a knob
     long long width = 8;              // 8-wide back end: children per node (experiment: 6)
+    long long axis_rule = 0;          // ordering axis of a node: 0 = largest spread of the children's centres; experiments: 1 = longest box
+                                      // axis, 2 = least overlap of the children's intervals
     long long debug = 0;              // print build timings
 };
 
@@ -61,7 +63,7 @@ inline const OptEntry * option_table(size_t * n) {
         { "RESERVE_CUS", &PrtOptions::reserve_cus, nullptr }, { "LEAF_MAX", &PrtOptions::leaf_max, nullptr },
         { "SAH_BINS", nullptr, &BvhBuildOptions::sah_bins }, { "SAH_SWEEP", nullptr, &BvhBuildOptions::sah_sweep },
         { "LBVH_PLAIN", nullptr, &BvhBuildOptions::lbvh_plain }, { "LBVH_CLUSTER", nullptr, &BvhBuildOptions::lbvh_cluster },
-        { "BVH8_WIDTH", nullptr, &BvhBuildOptions::width },
+        { "BVH8_WIDTH", nullptr, &BvhBuildOptions::width }, { "BVH8_AXIS_RULE", nullptr, &BvhBuildOptions::axis_rule },
     };
     *n = sizeof(table) / sizeof(table[0]);
     return table;

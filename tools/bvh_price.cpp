@@ -275,6 +275,7 @@ int main(int argc, char ** argv) {
     BvhBuildOptions axis_opt;
     axis_opt.slot_order = 1;
     if (getenv("PRICE_WIDTH")) axis_opt.width = atoi(getenv("PRICE_WIDTH"));
+    if (getenv("PRICE_AXIS_RULE")) axis_opt.axis_rule = atoi(getenv("PRICE_AXIS_RULE"));
     build_bvh8q(g_verts.data(), n_tris, leaf_max, 8, &b8a, 1.0f, &axis_opt);
 
     // camera (main.cpp:145-177)
