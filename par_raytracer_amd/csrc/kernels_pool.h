@@ -57,6 +57,7 @@ struct PoolBuffers {
 // Emitter of k_pool: appends to the wave's private lists, slots by rank among the appending lanes.
 template <bool ADAPT>
 struct PoolEmit {
+    enum { KEEPS_RNG = ADAPT ? 1 : 0 };      // adaptive mode: the pixel's next sample continues the RNG stream of the one that ended
     float4 * co, * cd, * ct;     // next closest list
     float4 * so, * sc, * sd;     // next shadow list
     unsigned int * fin;          // ADAPT: pixels to finalise after the next trace phase

@@ -662,7 +662,9 @@ PRT_D void shade_entry_on(const DevScene & sc, const DevParams & P, const WaveBu
     }
 
     // ---- outputs ------------------------------------------------------------------------------------------
-    if (live) {
+    // the RNG state goes back to memory for the sample's next shade event; a sample that has no ray left (every level returned)
+    // will never draw again - except in adaptive mode, where the pixel's next sample continues the stream (Emit::KEEPS_RNG)
+    if (live && (emit_closest || Emit::KEEPS_RNG)) {
         B.rng[s] = make_ulonglong2(rng.chain, rng.prev);
         if (RING && RINGMEM) B.rng_aux[s] = make_ulonglong2(rng.seed0, (u64)rng.k);
     }
@@ -690,6 +692,7 @@ PRT_D void shade_entry_lds(const DevScene & sc, const DevParams & P, const WaveB
 // Emitter of k_shade: workgroup-aggregated appends to the global next-round queues.
 template <int BLOCK>
 struct QueueEmit {
+    enum { KEEPS_RNG = 0 };           // fixed spp: a sample that has ended never draws again
     const WaveBuffers & B;
     int nxt;
     unsigned int * s_cnt;
