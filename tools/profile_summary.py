@@ -56,7 +56,8 @@ if FAST in sq1:
     # SQ_ACTIVE_INST_VALU counts, per SIMD-resident wave, the quad-cycles a vector instruction was in flight; summed over the
     # waves of a SIMD it is that SIMD's vector-pipe busy time.  SQ_BUSY_CYCLES is per SE-level SQ; the ratio below follows
     # (ACTIVE_INST_VALU / WAVE_CYCLES) x resident waves per SIMD.
-    out["valu_busy_k_pool"] = round(c["SQ_ACTIVE_INST_VALU"] / c["SQ_WAVE_CYCLES"] * 5.0, 4)
+    out["valu_issue_share_x5_waves_raw_k_pool"] = round(c["SQ_ACTIVE_INST_VALU"] / c["SQ_WAVE_CYCLES"] * 5.0, 4)
+    out["valu_busy_k_pool"] = min(1.0, out["valu_issue_share_x5_waves_raw_k_pool"])      # the raw ratio can pass 1: fewer than 5 waves per SIMD in the drain tail
     out["wait_frac_k_pool"] = round(c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"], 4)
     out["sq_k_pool"] = {k2: c[k2] / max(1, n1[FAST][k2]) for k2 in c}
     out["sq_k_pool"].update({k2: sq2[FAST][k2] / max(1, n1[FAST]["SQ_WAVES"]) for k2 in sq2.get(FAST, {})})
