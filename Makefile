@@ -23,7 +23,7 @@ HOST_SRCS := $(PKG)/host/obj_loader.cpp $(PKG)/host/sphere_tree.cpp $(PKG)/host/
 HOST_DEPS := $(wildcard $(PKG)/host/*.h) $(ROOT)/include/prt.h $(ROOT)/include/prt_host.h
 HOST_FLAGS := -O2 -std=c++14 -fPIC -ffp-contract=off -fno-strict-aliasing -Wall -Wno-unused-function -pthread -I$(ROOT)/include
 
-.PHONY: all hip host oracle clean hip-experimental hip-bvh4
+.PHONY: all hip host oracle clean hip-experimental hip-bvh8
 all: hip host oracle
 
 hip: $(PKG)/libprt_hip.so
@@ -33,13 +33,13 @@ $(PKG)/libprt_hip.so: $(HIP_DEPS)
 # Variant libraries (not built by default; git-ignored like every .so):
 #   hip-experimental  the shipped library + the two experimental pipelines (MEGAKERNEL: the exact-association cross-check of
 #                     round 1, PERSISTENT); tests/test_gpu_parity.py runs its four-pipeline comparisons when the file exists
-#   hip-bvh4          the 4-wide sorted traversal of rounds 1-2 instead of the 8-wide octant-ordered one (tools/ab_bvh8.sh)
+#   hip-bvh8          the 8-wide compressed BVH of round 3 (80 B nodes, no per-step sort) instead of the 4-wide sorted one
 hip-experimental: $(PKG)/libprt_hip_experimental.so
 $(PKG)/libprt_hip_experimental.so: $(HIP_DEPS)
 	$(HIPCC) $(HIP_FLAGS) -DPRT_EXPERIMENTAL -o $@ $(HIP_SRCS) $(PKG)/csrc/bvh_build.cpp
-hip-bvh4: $(PKG)/libprt_hip_bvh4.so
-$(PKG)/libprt_hip_bvh4.so: $(HIP_DEPS)
-	$(HIPCC) $(HIP_FLAGS) -DPRT_BVH4 -o $@ $(HIP_SRCS) $(PKG)/csrc/bvh_build.cpp
+hip-bvh8: $(PKG)/libprt_hip_bvh8.so
+$(PKG)/libprt_hip_bvh8.so: $(HIP_DEPS)
+	$(HIPCC) $(HIP_FLAGS) -DPRT_BVH8 -o $@ $(HIP_SRCS) $(PKG)/csrc/bvh_build.cpp
 
 host: $(PKG)/libprt_host.so $(PKG)/prt_main
 $(PKG)/libprt_host.so: $(HOST_SRCS) $(HOST_DEPS) $(PKG)/libprt_hip.so
@@ -51,5 +51,5 @@ oracle:
 	$(MAKE) -C $(ROOT)/oracle port ref
 
 clean:
-	rm -f $(PKG)/libprt_hip.so $(PKG)/libprt_hip_experimental.so $(PKG)/libprt_hip_bvh4.so $(PKG)/libprt_host.so $(PKG)/prt_main
+	rm -f $(PKG)/libprt_hip.so $(PKG)/libprt_hip_experimental.so $(PKG)/libprt_hip_bvh8.so $(PKG)/libprt_host.so $(PKG)/prt_main
 	$(MAKE) -C $(ROOT)/oracle clean

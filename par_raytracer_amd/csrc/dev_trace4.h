@@ -1,6 +1,6 @@
 // dev_trace4.h - traversal of the quantised 4-wide BVH (64 B nodes, children sorted by entry distance at every step).
-// Round 1-2's traversal; since round 3 the 8-wide tree (dev_trace8.h) is the default and this one is what -DPRT_BVH4 builds,
-// kept for the same-call A/B of the two (tools/ab_bvh8.sh).
+// The default.  Round 3 built the 8-wide alternative (dev_trace8.h, -DPRT_BVH8) and measured the two against each other
+// (profiles/r03_ab_bvh8.txt): level on the headline frame until the shading phase got lighter, then this one 1 - 2 % ahead.
 #pragma once
 
 #include "dev_trace_common.h"
@@ -13,7 +13,9 @@ struct TravRay {
     f3 o, d;                          // origin ALREADY biased by direction * ray_bias (raytracer.cpp:163), direction
     float ix, iy, iz;                 // 1 / direction, components clamped away from 0
     float pnx, pny, pnz;              // (o +- pad) / direction for the plane the ray ENTERS through on each axis
+#if defined(PRT_BVH4_SIX_PLANE_OFFSETS)
     float pfx, pfy, pfz;              // ... and for the plane it LEAVES through (pad always widens the box)
+#endif                                // (default: the exit side's offset is the entry side's plus 2 pad |1 / d|, formed per step - three registers fewer)
     HitRec best;
     int node, sp, kind;               // kind: TRACE_CLOSEST / TRACE_ANY
 };
@@ -123,9 +125,14 @@ PRT_D void trav_init(TravRay & r, f3 o, f3 d, int kind, float pad, const STK & s
     float dz = fabsf(d.z) < tiny ? (d.z < 0.0f ? -tiny : tiny) : d.z;
     r.ix = 1.0f / dx; r.iy = 1.0f / dy; r.iz = 1.0f / dz;
     // direction >= 0: enters through the lo plane (seen from o + pad), leaves through hi (from o - pad); else swapped
-    r.pnx = (dx < 0.0f ? o.x - pad : o.x + pad) * r.ix; r.pfx = (dx < 0.0f ? o.x + pad : o.x - pad) * r.ix;
-    r.pny = (dy < 0.0f ? o.y - pad : o.y + pad) * r.iy; r.pfy = (dy < 0.0f ? o.y + pad : o.y - pad) * r.iy;
-    r.pnz = (dz < 0.0f ? o.z - pad : o.z + pad) * r.iz; r.pfz = (dz < 0.0f ? o.z + pad : o.z - pad) * r.iz;
+    r.pnx = (dx < 0.0f ? o.x - pad : o.x + pad) * r.ix;
+    r.pny = (dy < 0.0f ? o.y - pad : o.y + pad) * r.iy;
+    r.pnz = (dz < 0.0f ? o.z - pad : o.z + pad) * r.iz;
+#if defined(PRT_BVH4_SIX_PLANE_OFFSETS)
+    r.pfx = (dx < 0.0f ? o.x + pad : o.x - pad) * r.ix;
+    r.pfy = (dy < 0.0f ? o.y + pad : o.y - pad) * r.iy;
+    r.pfz = (dz < 0.0f ? o.z + pad : o.z - pad) * r.iz;
+#endif
     r.best.t = 3.402823466e+38f;
     r.best.v = r.best.w = 0.0f;
     r.best.tri = -1;
@@ -148,7 +155,7 @@ PRT_D void cswap(float & ka, float & kb, int & la, int & lb) {
 // so after 3 scale products and 6 FMAs per node every plane costs one byte->float convert and one FMA.
 // The slab test may use FMA: it only has to be conservative, and the boxes are widened by `pad`.
 template <class STK, bool COUNT>
-PRT_D void trav_node_step(const DevScene & sc, TravRay & r, const STK & stk, TraceStats & st, float /*pad: in the ray already*/) {
+PRT_D void trav_node_step(const DevScene & sc, TravRay & r, const STK & stk, TraceStats & st, float pad) {
     // 32-bit byte offset from the (scalar) array base: the loads take the SGPR-base + VGPR-offset form and no 64-bit address is
     // built per lane (-0.7 % frame time; upload caps the scene at 2^26 triangles, so nodes * 64 and triangles * 48 fit)
     const uint4 * np = reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(sc.nodes) + ((unsigned int)r.node << 6));
@@ -172,9 +179,17 @@ PRT_D void trav_node_step(const DevScene & sc, TravRay & r, const STK & stk, Tra
     // entry / exit parameter of the node origin on each axis; the ray's direction signs pick, per axis, which
     // quantised plane set (lo or hi bytes) is the entry side - no per-plane min/max, and an empty child slot
     // (lo = 255 > hi = 0 on every axis) can never satisfy entry <= exit.
+#if defined(PRT_BVH4_SIX_PLANE_OFFSETS)
     const float cnx = __builtin_fmaf(ox, r.ix, -r.pnx), cfx = __builtin_fmaf(ox, r.ix, -r.pfx);
     const float cny = __builtin_fmaf(oy, r.iy, -r.pny), cfy = __builtin_fmaf(oy, r.iy, -r.pfy);
     const float cnz = __builtin_fmaf(oz, r.iz, -r.pnz), cfz = __builtin_fmaf(oz, r.iz, -r.pfz);
+#else
+    // (o -+ pad) / d on the exit side = the entry side's value + 2 pad |1 / d|: same six FMAs, three ray registers fewer
+    const float pad2 = pad + pad;
+    const float cnx = __builtin_fmaf(ox, r.ix, -r.pnx), cfx = __builtin_fmaf(pad2, fabsf(r.ix), cnx);
+    const float cny = __builtin_fmaf(oy, r.iy, -r.pny), cfy = __builtin_fmaf(pad2, fabsf(r.iy), cny);
+    const float cnz = __builtin_fmaf(oz, r.iz, -r.pnz), cfz = __builtin_fmaf(pad2, fabsf(r.iz), cnz);
+#endif
     const bool sx = r.ix < 0.0f, sy = r.iy < 0.0f, sz = r.iz < 0.0f;
     const unsigned int qnx = sx ? w1.w : w1.x, qfx = sx ? w1.x : w1.w;
     const unsigned int qny = sy ? w2.x : w1.y, qfy = sy ? w1.y : w2.x;

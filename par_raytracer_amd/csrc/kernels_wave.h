@@ -342,19 +342,28 @@ struct LdsF3 {
     PRT_D LdsF3 & operator=(f3 v) { p[0] = as_i(v.x); p[STRIDE] = as_i(v.y); p[2 * STRIDE] = as_i(v.z); return *this; }
     PRT_D LdsF3 & operator=(const LdsF3 & o) { return *this = (f3)o; }
 };
-template <int STRIDE>
-struct WFrameLds {
-    LdsF3<STRIDE> hit_p, hit_n, ray_d, T_in, hit_pos, kd, ks;
+// hit_pos - where an alpha continuation ray starts (raytracer.cpp:547-552) - is only ever read when a material can be
+// translucent; a render that cannot meet one (POS = false) has no such field: writes vanish, 23 dwords per lane instead of 26.
+struct NoF3 {
+    PRT_D NoF3 & operator=(f3) { return *this; }
+    PRT_D operator f3() const { return mk3(0.0f, 0.0f, 0.0f); }
+};
+template <int STRIDE, bool POS> struct WFramePos { LdsF3<STRIDE> hit_pos; PRT_D void place(int * col) { hit_pos.p = col + 23 * STRIDE; } };
+template <int STRIDE> struct WFramePos<STRIDE, false> { NoF3 hit_pos; PRT_D void place(int *) {} };
+template <int STRIDE, bool POS>
+struct WFrameLds : WFramePos<STRIDE, POS> {
+    LdsF3<STRIDE> hit_p, hit_n, ray_d, T_in, kd, ks;
     LdsF<STRIDE> alpha, w_diffuse;
     LdsI<STRIDE> mat, stage, idx;
     PRT_D explicit WFrameLds(int * col) {
         hit_p.p = col; hit_n.p = col + 3 * STRIDE; ray_d.p = col + 6 * STRIDE; T_in.p = col + 9 * STRIDE;
-        hit_pos.p = col + 12 * STRIDE; kd.p = col + 15 * STRIDE; ks.p = col + 18 * STRIDE;
-        alpha.p = col + 21 * STRIDE; w_diffuse.p = col + 22 * STRIDE;
-        mat.p = col + 23 * STRIDE; stage.p = col + 24 * STRIDE; idx.p = col + 25 * STRIDE;
+        kd.p = col + 12 * STRIDE; ks.p = col + 15 * STRIDE;
+        alpha.p = col + 18 * STRIDE; w_diffuse.p = col + 19 * STRIDE;
+        mat.p = col + 20 * STRIDE; stage.p = col + 21 * STRIDE; idx.p = col + 22 * STRIDE;
+        this->place(col);
     }
 };
-enum { WFRAME_LDS_DWORDS = 26 };
+enum { WFRAME_LDS_DWORDS = 26, WFRAME_LDS_DWORDS_NOPOS = 23 };
 
 // POS: the frame carries hit_pos (alpha continuation rays start there, raytracer.cpp:547-552): only renders that can meet a
 // translucent material (RING && RINGMEM in the pool pipeline, RING in the wavefront pipeline) pay for that fifth float4.
@@ -685,7 +694,7 @@ template <bool RING, bool TEX, int STRIDE, bool RINGMEM, class Emit>
 PRT_D void shade_entry_lds(const DevScene & sc, const DevParams & P, const WaveBuffers & B, const ShadeTables & tb, bool live,
                            unsigned int s, int level, unsigned int pending, f3 ray_o, f3 ray_d, f3 T, const HitRec & hit, Emit & emit,
                            unsigned int & shaded, int * col) {
-    WFrameLds<STRIDE> f(col);
+    WFrameLds<STRIDE, RING && RINGMEM> f(col);
     shade_entry_on<RING, TEX, RINGMEM>(sc, P, B, tb, live, s, level, pending, ray_o, ray_d, T, hit, emit, shaded, f);
 }
 

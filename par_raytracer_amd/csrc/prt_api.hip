@@ -37,9 +37,9 @@ using namespace prt;
 #define PRT_POOL_WAVES 5          // waves per SIMD of the fixed-spp pool kernel: 96 VGPRs (6 = 80 VGPRs spills, profiles/r03_ab_bvh8.txt)
 #endif
 
-// The acceleration structure the library is built with (dev_trace.h): 8-wide octant-ordered, or -DPRT_BVH4 the 4-wide
-// sorted one of rounds 1-2.
-#if defined(PRT_BVH4)
+// The acceleration structure the library is built with (dev_trace.h): the 4-wide sorted tree, or -DPRT_BVH8 the 8-wide one
+// of round 3.
+#if !defined(PRT_BVH8)
 typedef Bvh4Result BvhWide;
 static const int kBvhNodeDwords = 16;
 #define PRT_BUILD_WIDE build_bvh4q
@@ -519,7 +519,7 @@ int launch_pool_kernel(prt_ctx * ctx, unsigned int grid, size_t lds, const PoolA
 template <int BLOCK, int WAVES, bool LDSTAB, bool RING, bool TEX, bool ADAPT, bool RINGMEM = true>
 int launch_pool(prt_ctx * ctx, bool count, const DevCamera & cam, DevParams P, unsigned int n_samples, unsigned int stack_entries) {
     // the stack columns double as the shading phase's frame storage (WFRAME_LDS_DWORDS per lane)
-    const size_t lds = (size_t)std::max(stack_entries * (unsigned int)STACK_ENTRY_INTS, (unsigned int)WFRAME_LDS_DWORDS) * BLOCK * sizeof(int);
+    const size_t lds = (size_t)std::max(stack_entries * (unsigned int)STACK_ENTRY_INTS, (unsigned int)((RING && RINGMEM) ? WFRAME_LDS_DWORDS : WFRAME_LDS_DWORDS_NOPOS)) * BLOCK * sizeof(int);
     const PrtOptions & opt = ctx->opt;
     // Three launches (kernels_pool.h PoolBuffers::park): the fast kernel, which parks the rays it cannot finish - a hit with
     // company within a few ulp, a stack column that overflowed -; k_pool_parked_shadows for the parked shadow rays; the EXACT
@@ -1102,7 +1102,7 @@ int prt_build_flags(void) {
 #if defined(PRT_EXPERIMENTAL)
     f |= PRT_BUILD_EXPERIMENTAL;
 #endif
-#if defined(PRT_BVH4)
+#if !defined(PRT_BVH8)
     f |= PRT_BUILD_BVH4;
 #endif
     return f;
@@ -1462,7 +1462,7 @@ int prt_upload_scene(prt_ctx * ctx, const prt_scene_desc * s) {
     std::vector<float4> ddirs(1024);
     for (uint32_t i = 0; i < 1024; ++i) ddirs[i] = diffuse_tangent_dir(i);
 
-#if !defined(PRT_BVH4) && PRT_BVH8_STRIDE != 80
+#if defined(PRT_BVH8) && PRT_BVH8_STRIDE != 80
     std::vector<float4> nodes4((size_t)bvh.node_count * (BVH_NODE_STRIDE / 16), make_float4(0, 0, 0, 0));
     for (uint32_t ni = 0; ni < bvh.node_count; ++ni)
         memcpy(reinterpret_cast<char *>(nodes4.data()) + (size_t)ni * BVH_NODE_STRIDE, &bvh.nodes[(size_t)ni * BVH8_NODE_DWORDS], BVH8_NODE_DWORDS * 4);
@@ -1797,7 +1797,7 @@ static int check_bvh8q(const std::vector<float> & verts, uint32_t n_tris, const 
     return 0;
 }
 
-#if defined(PRT_BVH4)
+#if !defined(PRT_BVH8)
 static int check_bvh_wide(const std::vector<float> & verts, uint32_t n_tris, const BvhWide & bvh, uint64_t * out) { return check_bvh4q(verts, n_tris, bvh, out); }
 #else
 static int check_bvh_wide(const std::vector<float> & verts, uint32_t n_tris, const BvhWide & bvh, uint64_t * out) { return check_bvh8q(verts, n_tris, bvh, out); }

@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 @pytest.mark.parametrize("flavour", ["bvh8", "bvh8_octant", "bvh4"])
 def test_device_traversal_equals_the_references_filter_on_the_host(flavour, tmp_path):
     exe = str(tmp_path / ("trace_host_" + flavour))
-    flags = {"bvh8": [], "bvh8_octant": ["-DPRT_BVH8_OCTANT"], "bvh4": ["-DPRT_BVH4"]}[flavour]
+    flags = {"bvh4": [], "bvh8": ["-DPRT_BVH8"], "bvh8_octant": ["-DPRT_BVH8", "-DPRT_BVH8_OCTANT"]}[flavour]
     cmd = ["g++", "-O1", "-std=c++17", "-ffp-contract=off", "-pthread", "-I" + os.path.join(ROOT, "tests", "hip_shim"),
            "-I" + os.path.join(ROOT, "par_raytracer_amd", "csrc")] + flags + [
            os.path.join(ROOT, "tests", "trace_host_harness.cpp"), os.path.join(ROOT, "par_raytracer_amd", "csrc", "bvh_build.cpp"), "-o", exe]

@@ -1,8 +1,8 @@
 // trace_host_harness.cpp - the DEVICE traversal code (par_raytracer_amd/csrc/dev_trace*.h), compiled for the host with
 // tests/hip_shim and run one lane at a time against a brute-force restatement of the reference's hit filter.
 //
-// What it checks, with no GPU: that trace_ray() over the BVH the library builds (8-wide by default - slots sorted along one axis, or one per
-// octant with -DPRT_BVH8_OCTANT -, 4-wide sorted with -DPRT_BVH4) returns, for every ray, exactly the hit the reference's sequential filter returns over ALL triangles
+// What it checks, with no GPU: that trace_ray() over the BVH the library builds (4-wide sorted by default; -DPRT_BVH8: 8-wide, slots sorted along one
+// axis, or one per octant with -DPRT_BVH8_OCTANT) returns, for every ray, exactly the hit the reference's sequential filter returns over ALL triangles
 // in visit order (raytracer.cpp:104, 149, 208-220) - t, barycentrics and triangle bit for bit, near ties included - and
 // that any-hit rays agree on occluded / not occluded.  Scene: a wavy height field plus floating, doubled and coplanar
 // triangles.  Built and run by tests/test_trace_host.py.
@@ -50,7 +50,7 @@ int main(int argc, char ** argv) {
     }
     const uint32_t n_tris = (uint32_t)(verts.size() / 9);
 
-#if defined(PRT_BVH4)
+#if !defined(PRT_BVH8)
     Bvh4Result bvh;
     build_bvh4q(verts.data(), n_tris, 4, 2, &bvh);
 #else
