@@ -189,7 +189,6 @@ PRT_D long long accum_fix(float c) {
     return c < 0.0f ? -v : v;
 }
 PRT_D float accum_float(long long v) { return (float)((double)v * (1.0 / 4294967296.0)); }
-PRT_D void accum_zero(Accum * a) { a->x = 0; a->y = 0; a->z = 0; a->w = 0; }
 // Additions are atomics without return value, always: the issuing wave does not wait for them (a read-modify-write would
 // park it for a memory round trip at every finished shadow ray), and several shadow rays of one sample may finish at once.
 // They are performed in the L2, past the compute unit's vector L1 - so reads must not be served from that L1 either.

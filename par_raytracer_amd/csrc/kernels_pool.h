@@ -328,11 +328,11 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_pool(const PoolArgs * args, De
                     }
                     B.rng[sid] = make_ulonglong2(S.rng.chain, S.rng.prev);
                     if (RING && RINGMEM) B.rng_aux[sid] = make_ulonglong2(S.rng.seed0, (u64)S.rng.k);     // (seed word 0, draw count): only a sample that can pass 15 draws needs them
-                    // fixed spp: the record is first written by the sample's first shade event (WF_PENDING_FRESH_BIT); the adaptive
-                    // mode's finalise step reads and zeroes it between the samples of a pixel, and starts from a zeroed one
-                    if (ADAPT) accum_zero(B.accum + sid);
+                    // the radiance record is first written by the sample's first shade event (WF_PENDING_FRESH_BIT) - in adaptive
+                    // mode too: the finalise step has read the previous sample's sum before that event (same wave, earlier in
+                    // the phase), so nothing zeroes the record between the samples of a pixel
                     co[n_c + k] = make_float4(fr.ray_o.x, fr.ray_o.y, fr.ray_o.z, as_f((int)sid));
-                    cd[n_c + k] = make_float4(fr.ray_d.x, fr.ray_d.y, fr.ray_d.z, as_f(ADAPT ? 0 : (int)WF_PENDING_FRESH_BIT << 8));
+                    cd[n_c + k] = make_float4(fr.ray_d.x, fr.ray_d.y, fr.ray_d.z, as_f((int)WF_PENDING_FRESH_BIT << 8));
                     ct[n_c + k] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
                 }
                 n_c += cnt;
@@ -588,10 +588,23 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_pool(const PoolArgs * args, De
                         unsigned int samp = (unsigned int)(job & POOL_JOB_SAMPLE_MASK);  // index of the sample that just ended
                         const f3 sum_prev = mk3(st.x, st.y, st.z);
                         const f3 c = a;
-                        scratch[POOL_SCRATCH_AT(samp, j)] = make_float4(c.x, c.y, c.z, 0.0f);
+                        // .w of a stored sample: the sum of squares of all channels of the samples up to and including it
+                        const float sq_prev = samp ? scratch[POOL_SCRATCH_AT(samp - 1u, j)].w : 0.0f;
+                        scratch[POOL_SCRATCH_AT(samp, j)] = make_float4(c.x, c.y, c.z, sq_prev + ((c.x * c.x + c.y * c.y) + c.z * c.z));
                         const f3 sum = sum_prev + c;                                // color += scratch_buffer[samp]
                         bool stop = false;
-                        if (samp >= P.spp) {                                        // second loop: CalculateVariance(scratch, samp), main.cpp:253
+                        // The rule's sum of squared L1 distances to the mean is at least the sum of squared Euclidean distances,
+                        // and that is at least sq - |sum|^2 / n whatever value the mean was rounded to.  When this bound clears
+                        // the threshold by more than any rounding of either side (float sums of <= 50 terms: 6e-6 relative;
+                        // 2e-5 of sq and 1e-3 of the threshold are allowed) the verdict is "go on" without the loop over the
+                        // stored samples - which is the verdict of nearly every pixel that is not sky.  NaN fails the test.
+                        bool decided = false;
+                        if (samp >= P.spp) {
+                            const float n = (float)samp;
+                            const float bound = sq_prev - ((sum_prev.x * sum_prev.x + sum_prev.y * sum_prev.y) + sum_prev.z * sum_prev.z) / n;
+                            decided = bound - 2e-5f * sq_prev > P.variance_threshold * (n - 1.0f) * 1.001f + 1e-30f;
+                        }
+                        if (samp >= P.spp && !decided) {                            // second loop: CalculateVariance(scratch, samp), main.cpp:253
                             const f3 mean = sum_prev / (float)samp;                 // the mean's running sum IS the colour sum so far
                             float variance = 0.0f;
                             // the sum runs in sample order, as in the reference; the LOADS do not have to: eight in flight at a
@@ -626,7 +639,6 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_pool(const PoolArgs * args, De
                             Q.final_rgb[j] = make_float4(out.x, out.y, out.z, 1.0f);
                         } else {
                             Q.jobsum[j] = make_float4(sum.x, sum.y, sum.z, as_f((int)samp));
-                            accum_zero(B.accum + j);
                             if (!(job & POOL_JOB_SPEC_FLYING)) {
                                 // the sample's camera ray is not in the pool yet (the common case is that it is: see below)
                                 float off_x, off_y;
@@ -652,7 +664,7 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_pool(const PoolArgs * args, De
                             }
                         }
                     }
-                    emit.closest(go_on, j, ray_o, ray_d, mk3(1.0f, 1.0f, 1.0f), 0, 0u, false);
+                    emit.closest(go_on, j, ray_o, ray_d, mk3(1.0f, 1.0f, 1.0f), 0, (unsigned int)WF_PENDING_FRESH_BIT, false);
                 }
                 emit.m_f = 0;                                                       // the list is consumed; shading refills it from 0
                 pool_fence();
@@ -734,7 +746,7 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_pool(const PoolArgs * args, De
                         Q.final_rgb[j] = make_float4(off_x, off_y, as_f((int)slot), 0.0f);
                         Q.jobsum[j].w = as_f(as_i(Q.jobsum[j].w) | POOL_JOB_SPEC_FLYING);
                     }
-                    emit.closest(go, j, ray_o, ray_d, mk3(1.0f, 1.0f, 1.0f), 0, (unsigned int)POOL_SPEC_PENDING_BIT, false);
+                    emit.closest(go, j, ray_o, ray_d, mk3(1.0f, 1.0f, 1.0f), 0, (unsigned int)POOL_SPEC_PENDING_BIT | (unsigned int)WF_PENDING_FRESH_BIT, false);
                     started += (unsigned int)__popcll(m);
                 }
                 n_spec = started;

@@ -544,8 +544,9 @@ int launch_pool(prt_ctx * ctx, bool count, const DevCamera & cam, DevParams P, u
     cap = std::max(64u, std::min(512u, cap));
     // adaptive mode: a pixel stays in its pool for all its samples (up to 50 x several rounds), so what a wave takes it keeps;
     // smaller pools leave more of the frame on the counter for the waves whose pixels end early (C4: 512 slots 195 ms,
-    // 256 168 ms, 64 - 192 161 - 164 ms, profiles/r02_adaptive_pool_capacity.txt)
-    if (ADAPT) cap = std::min(cap, 192u);
+    // 256 168 ms, 64 - 192 161 - 164 ms, profiles/r02_adaptive_pool_capacity.txt; round 3, once the variance rule no longer
+    // walks the stored samples: 512 160, 256 145, 192 133 - 138, 128 129 - 133, 64 138 ms, profiles/r03_adaptive.txt)
+    if (ADAPT) cap = std::min(cap, 128u);
     if (opt.pool_cap >= 0) cap = (unsigned int)std::max(64ll, std::min(4096ll, opt.pool_cap / 64 * 64));
     const unsigned int n_lights = std::max(1u, ctx->scene.light_count);
     const unsigned int scap = cap * n_lights;

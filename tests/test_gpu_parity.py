@@ -346,6 +346,35 @@ def test_random_configurations_against_the_oracle(cfg):
         r.close()
 
 
+@pytest.mark.parametrize("scene", ["cornell_box", "terrain_64"])
+def test_adaptive_stopping_rule_at_thresholds_among_the_pixels_variances(scene):
+    """The stopping rule (main.cpp:190-222, 253-257) is decided from a lower bound on the variance where that bound clears the
+    threshold, and by the reference's loop over the stored samples otherwise (kernels_pool.h finalise step).  Thresholds
+    spread over the range of the pixels' variances put pixels on either side of it and close to it: every verdict shows in
+    the ray count, which must be the oracle's."""
+    import oracle_py as orc
+    from conftest import host_scene, scene_dir
+    from par_raytracer_amd import api
+    s, _ = scene_dir(scene)
+    hs = host_scene(scene, 0)
+    w, h = 48, 36
+    cam = api.make_camera(s.fov, w, h, s.camera_position, s.camera_facing)
+    r = api.Renderer(0)
+    try:
+        r.upload(hs)
+        stopped_early = []
+        for thr in (1e-4, 0.01, 0.1, 0.5, 2.0, 8.0, 40.0, 1e4):
+            p = api.default_params(3, 77, pipeline=PIPELINES["pool"], max_spp=14, variance_threshold=thr)
+            ref, c_ref = orc.render(hs.desc, cam, p, w, h, 1, 8)
+            img, c = r.render(cam, p, w, h)
+            assert c.ray_count == c_ref.ray_count, "threshold %g: ray count %d != oracle %d" % (thr, c.ray_count, c_ref.ray_count)
+            assert np.abs(img.reshape(h, w, 4)[:, :, :3] - ref[:, :, :3]).max() <= TOL
+            stopped_early.append(c.ray_count)
+        assert len(set(stopped_early)) >= 4, "the thresholds were meant to split the pixels differently: %r" % (stopped_early,)
+    finally:
+        r.close()
+
+
 def test_default_pipeline_try_out_is_invisible(gpu_renderer_factory):
     """PRT_PIPELINE_DEFAULT is the pool pipeline.  With PRT_FLAG_TRYOUT, between 1 M and 64 M samples the first DEFAULT
     call of a configuration renders the frame with both production pipelines and keeps the faster one: the image is the
