@@ -24,7 +24,7 @@ Total work is fixed as N grows -> "scaling": "strong".
 
 Extra objects on the JSON line:
   roofline      the dominant kernel (k_pool: one launch = one frame): SURVEY.md §8d algorithmic bytes of a launch (rays x 52 B +
-                BVH nodes fetched x the build's node size (80 B, 8-wide) + triangle tests x 36 B + shaded hits x 80 B + pixels
+                BVH nodes fetched x the build's node size (64 B, 4-wide) + triangle tests x 36 B + shaded hits x 80 B + pixels
                 x 16 B) / its duration, measured with HIP events on the kernel's own stream inside the timed region.  That
                 figure counts every per-lane node fetch, most of which the caches serve, so its label says what it is
                 ("cache-inclusive algorithmic bytes") and `hbm_measured` / `limiter` say what the memory system and the
@@ -64,7 +64,7 @@ WORKLOADS = {
 SHARD_BLOCK_ROWS = 8
 SEED = 1234
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s HBM3E spec peak
-# SURVEY.md §8d algorithmic bytes per unit of work: ray 52 (32 read + 20 written), BVH node = the build's node (80 B, 8-wide;
+# SURVEY.md §8d algorithmic bytes per unit of work: ray 52 (32 read + 20 written), BVH node = the build's node (64 B, 4-wide;
 # read from prt_scene_info.bvh_node_bytes),
 # triangle test 36 (three float3), shaded hit 80 (3 normals + 3 indices + material), pixel 16.  `roofline.achieved` / `frac`
 # use THESE.  The build's own records are fatter (48 B pre-differenced triangle, 64 B shading record + 64 B material + 16 B
@@ -352,7 +352,7 @@ def main():
     # have no ray record, so they are not priced either
     rays_elided = int(st.elided_shadow_rays)
     rays_traced = int(cc.ray_count) - rays_elided
-    B_NODE = int(info.bvh_node_bytes)           # the build's node: 80 B (8-wide), 64 B for a -DPRT_BVH4 library
+    B_NODE = int(info.bvh_node_bytes)           # the build's node: 64 B (4-wide), 80 B for a -DPRT_BVH8 library
     def algorithmic_bytes(b_tri, b_shade):
         n = rays_traced * B_RAY + cc.node_visits * B_NODE + cc.tri_tests * b_tri
         if fused:

@@ -190,7 +190,8 @@ int prt_abi_version(void);
 int prt_set_option(prt_ctx * ctx, const char * name, const char * value);
 
 /* How the library was built: PRT_BUILD_EXPERIMENTAL - the MEGAKERNEL / PERSISTENT pipelines are present;
- * PRT_BUILD_BVH4 - the 4-wide sorted traversal of rounds 1-2 instead of the 8-wide octant-ordered one. */
+ * PRT_BUILD_BVH4 - the 4-wide sorted BVH traversal (the default build; clear in a -DPRT_BVH8 library, which traverses the
+ * 8-wide compressed tree instead: same results). */
 enum { PRT_BUILD_EXPERIMENTAL = 1, PRT_BUILD_BVH4 = 2 };
 int prt_build_flags(void);
 

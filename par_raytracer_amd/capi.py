@@ -130,7 +130,7 @@ def hip_lib() -> C.CDLL:
     """libprt_hip.so: the HIP kernels + C ABI."""
     global _hip
     if _hip is None:
-        # PRT_HIP_LIB names a variant build of the same ABI inside the package directory (make hip-experimental, hip-bvh4;
+        # PRT_HIP_LIB names a variant build of the same ABI inside the package directory (make hip-experimental, hip-bvh8;
         # tools/ab_*.sh); the product is libprt_hip.so
         lib = _load(os.path.join(PKG_DIR, os.path.basename(os.environ.get("PRT_HIP_LIB", "libprt_hip.so"))), "HIP extension")
         lib.prt_create.restype = C.c_void_p

@@ -1,4 +1,5 @@
-// dev_trace8.h - traversal of the 8-wide compressed BVH (80 B nodes: bvh_build.h Bvh8Result), octant-ordered.
+// dev_trace8.h - traversal of the 8-wide compressed BVH (80 B nodes: bvh_build.h Bvh8Result).  A build option (-DPRT_BVH8,
+// make hip-bvh8); the default library uses the 4-wide sorted tree of dev_trace4.h - see the last paragraph.
 //
 // Replaces TraceRay / IntersectRaySphere / IntersectRayMesh (raytracer.cpp:32-60, 127-232); the triangle test and what has to
 // be preserved about the reference's result are in dev_trace_common.h.
@@ -18,9 +19,11 @@
 //     deep as the tree (9 levels for a million triangles), so the 8-byte entries need no more LDS than the 4-wide tree's 24 links.
 // A node's hit LEAF slots are tested first, in slot order, then its internal children in ray order (a leaf that lies behind
 // an internal child is tested a little early: +0.5 triangle tests per ray).
-// What it buys on MI355X (profiles/r03_ab_bvh8.txt, same box): the frame of the headline config takes what it took - 30 % fewer
-// node steps but 17 % more vector instructions, and the kernel turns out to sit on a plateau where neither matters much - ;
-// deep bounce trees (C5, incoherent rays) render 8.5 % faster; the node array halves (8.2 MB instead of 16.6 MB).
+// What it buys on MI355X (profiles/r03_ab_bvh8.txt, same box): 25 % fewer wave-level node steps for 17 % more vector
+// instructions (205 per step for eight boxes against 140 for four; 15 % more triangle tests), and the node array halves (8.2 MB
+// instead of 16.6 MB).  On the headline frame that was level with the 4-wide tree while the shading phase still carried its
+// atomics, and is 2.3 % slower since (12.28 - 12.32 against 12.00 - 12.02 ms, same call): this kernel's vector pipe is full.
+// Deep bounce trees (C5) render 1.4 % faster, the 12-triangle C2 6 %.  Hence an option, not the default.
 #pragma once
 
 #include "dev_trace_common.h"
@@ -30,7 +33,7 @@ namespace prt {
 typedef int2 StackEntry;                 // (child_base, imask | unvisited hit slots << 8); the marker: (TRAV_SENTINEL | flags, 0)
 enum { STACK_ENTRY_INTS = 2, BVH_NODE_BYTES = 80, STACK_LDS_CAP_DEFAULT = 13 };
 // distance between nodes in the device array: 80 = packed.  (Experiment -DPRT_BVH8_STRIDE=128: one node per 128-byte cache line,
-// so that no node straddles two lines - half of the packed ones do; profiles/r03_ab_bvh8.txt item 7.)
+// so that no node straddles two lines - half of the packed ones do; no gain: profiles/r03_ab_bvh8.txt item 7.)
 #ifndef PRT_BVH8_STRIDE
 #define PRT_BVH8_STRIDE 80
 #endif
