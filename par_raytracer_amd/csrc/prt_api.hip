@@ -33,6 +33,9 @@
 
 using namespace prt;
 
+#ifndef PRT_ADAPT_WAVES
+#define PRT_ADAPT_WAVES 4         // waves per SIMD of the untextured adaptive kernel (128 VGPRs)
+#endif
 #ifndef PRT_POOL_WAVES
 #define PRT_POOL_WAVES 5          // waves per SIMD of the fixed-spp pool kernel: 96 VGPRs (6 = 80 VGPRs spills, profiles/r03_ab_bvh8.txt)
 #endif
@@ -963,7 +966,7 @@ int render_pixels_once(prt_ctx * ctx, const prt_camera * cam_in, const prt_param
             // 6 waves (80 VGPRs) spill 90-230 dwords: 29 ms.
             if (adaptive)
                 rc = ctx->textured ? launch_pool<256, 4, false, true, true, true>(ctx, count_visits, cam, P, n_samples, stack_entries)
-                                   : launch_pool<256, 4, false, true, false, true>(ctx, count_visits, cam, P, n_samples, stack_entries);
+                                   : launch_pool<256, PRT_ADAPT_WAVES, false, true, false, true>(ctx, count_visits, cam, P, n_samples, stack_entries);
             else
                 rc = ctx->textured ? launch_pool<256, 4, false, true, true, false>(ctx, count_visits, cam, P, n_samples, stack_entries)
                    : ring ? launch_pool<256, PRT_POOL_WAVES, false, true, false, false>(ctx, count_visits, cam, P, n_samples, stack_entries)
