@@ -1145,18 +1145,30 @@ prt_ctx * prt_create(int device_id) {
 #else
     ctx->opt.bvh.slot_order = 1;          // ... slots sorted along the node's ordering axis
 #endif
-    // PRT_RESERVE_CUS=k (multi-GPU callers): the context's streams are created with a CU mask that leaves the last k compute
-    // units to others - the RCCL gather of the previous frame must not wait for a wave slot while this context's persistent
-    // kernels hold every one of theirs (bench.py sets it for N > 1 with frames in flight).  The persistent grids are sized
-    // for the CUs that are left.
+    // PRT_RESERVE_CUS=k (multi-GPU callers): the context's streams are created with a CU mask that leaves k compute units to
+    // others - the RCCL gather of the previous frame must not wait for a wave slot while this context's persistent kernels
+    // hold every one of theirs (bench.py sets it for N > 1 with frames in flight).  The persistent grids are sized for the
+    // CUs that are left.  WHICH k matters: the mask's bits are XCD-major (32 per XCD), workgroups go round the XCDs, so
+    // clearing the last 8 bits takes a quarter of ONE XCD and leaves 35 of the grid's blocks without a slot there (C4 frame
+    // +7.5 %); every 32nd bit takes one CU of each XCD (+4.2 % for 3.1 % of the CUs).  Measured: profiles/r03_cu_mask.txt.
+    // A CU-masked stream is a BLOCKING stream (ordered against the null stream): callers keep their own work off the null
+    // stream (bench.py does; the same file shows what happens otherwise).
     std::vector<uint32_t> cu_mask;
     {
         const int reserve = (int)ctx->opt.reserve_cus;
         if (reserve > 0 && reserve < ctx->cu_count) {
             cu_mask.assign((size_t)(ctx->cu_count + 31) / 32, 0u);
-            for (int cu = 0; cu < ctx->cu_count - reserve; ++cu) cu_mask[(size_t)cu >> 5] |= 1u << (cu & 31);
-            ctx->cu_count -= reserve;
-            ctx->reserved_cus = reserve;
+            const int pattern = (int)ctx->opt.reserve_pattern, stride = ctx->cu_count / reserve;
+            int kept = 0;
+            for (int cu = 0; cu < ctx->cu_count; ++cu) {
+                const bool off = pattern == 1 ? cu < reserve
+                               : pattern == 2 ? (cu % stride == stride - 1 && cu / stride < reserve)
+                               : pattern == 3 ? false
+                               : cu >= ctx->cu_count - reserve;
+                if (!off) { cu_mask[(size_t)cu >> 5] |= 1u << (cu & 31); ++kept; }
+            }
+            ctx->reserved_cus = ctx->cu_count - kept;
+            ctx->cu_count = kept;
         }
     }
     auto make_stream = [&](hipStream_t * st) -> hipError_t {

@@ -40,6 +40,8 @@ struct PrtOptions {
     long long pool_blocks_per_cu = -1, pool_cap = -1, pool_topup = -1, pool_max_samples = -1, pool_park_cap = -1;
     long long pass_samples = -1, pass_mb = -1, stack_cap = -1, no_tiles = 0;
     long long reserve_cus = 0;              // creation only: compute units the context's streams leave free
+    long long reserve_pattern = 2;          // creation only: which bits of the CU mask are cleared - 2 = every (n / k)-th (k = 8: one compute unit per XCD),
+                                            // experiments: 0 = the last k, 1 = the first k, 3 = none (profiles/r03_cu_mask.txt)
     // ---- BVH build
     long long leaf_max = -1;
     double sah_trav_cost = 1.0;
@@ -60,7 +62,7 @@ inline const OptEntry * option_table(size_t * n) {
         { "POOL_TOPUP", &PrtOptions::pool_topup, nullptr }, { "POOL_MAX_SAMPLES", &PrtOptions::pool_max_samples, nullptr },
         { "POOL_PARK_CAP", &PrtOptions::pool_park_cap, nullptr }, { "PASS_SAMPLES", &PrtOptions::pass_samples, nullptr },
         { "PASS_MB", &PrtOptions::pass_mb, nullptr }, { "STACK_CAP", &PrtOptions::stack_cap, nullptr }, { "NO_TILES", &PrtOptions::no_tiles, nullptr },
-        { "RESERVE_CUS", &PrtOptions::reserve_cus, nullptr }, { "LEAF_MAX", &PrtOptions::leaf_max, nullptr },
+        { "RESERVE_CUS", &PrtOptions::reserve_cus, nullptr }, { "RESERVE_PATTERN", &PrtOptions::reserve_pattern, nullptr }, { "LEAF_MAX", &PrtOptions::leaf_max, nullptr },
         { "SAH_BINS", nullptr, &BvhBuildOptions::sah_bins }, { "SAH_SWEEP", nullptr, &BvhBuildOptions::sah_sweep },
         { "LBVH_PLAIN", nullptr, &BvhBuildOptions::lbvh_plain }, { "LBVH_CLUSTER", nullptr, &BvhBuildOptions::lbvh_cluster },
         { "BVH8_WIDTH", nullptr, &BvhBuildOptions::width }, { "BVH8_AXIS_RULE", nullptr, &BvhBuildOptions::axis_rule },
