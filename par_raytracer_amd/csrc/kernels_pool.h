@@ -180,7 +180,7 @@ __global__ void k_pool_store_args(PoolArgs a, PoolArgs * dst, unsigned int * zer
 // EXACT: the slow variant - stack columns that continue in global memory, near ties decided inside the traversal loop
 // (resolve_near_ties).  It runs as the adopting second launch of a render (PoolBuffers::park); the fast variant parks what
 // it cannot finish.
-template <int BLOCK, int WAVES, bool LDSTAB, bool RING, bool COUNT, bool TEX, bool ADAPT, bool RINGMEM, bool EXACT>
+template <int BLOCK, int WAVES, bool LDSTAB, bool RING, bool COUNT, bool TEX, bool ADAPT, int RINGMEM, bool EXACT>
 __global__ __launch_bounds__(BLOCK, WAVES) void k_pool(const PoolArgs * args, DevCounters * ctr) {
     extern __shared__ int s_stack[];
     constexpr int LDS_MATS = 32, LDS_LIGHTS = 4;
@@ -318,7 +318,7 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_pool(const PoolArgs * args, De
                     const unsigned int gsid = B.sample_base + sid;
                     SampleState S;
                     Frame fr;
-                    u64 * ring = RING && RINGMEM ? B.ring + (size_t)sid * B.ring_step : nullptr;
+                    u64 * ring = RING && RINGMEM != 0 ? B.ring + (size_t)sid * B.ring_step : nullptr;
                     if (ADAPT) {
                         // the unit is the pixel: one RNG stream, key of sample 0 (include/prt.h prt_params::max_spp)
                         sample_begin<RING>(cam, P, pixel_of_local(P, gsid), 0u, S, fr, ring, B.ring_stride);
@@ -327,7 +327,7 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_pool(const PoolArgs * args, De
                         sample_begin<RING>(cam, P, pixel_of_local(P, gsid / P.spp), gsid % P.spp, S, fr, ring, B.ring_stride);
                     }
                     B.rng[sid] = make_ulonglong2(S.rng.chain, S.rng.prev);
-                    if (RING && RINGMEM) B.rng_aux[sid] = make_ulonglong2(S.rng.seed0, (u64)S.rng.k);     // (seed word 0, draw count): only a sample that can pass 15 draws needs them
+                    if (RING && RINGMEM != 0) B.rng_aux[sid] = make_ulonglong2(S.rng.seed0, (u64)S.rng.k);     // (seed word 0, draw count): only a sample that can pass 15 draws needs them
                     // the radiance record is first written by the sample's first shade event (WF_PENDING_FRESH_BIT) - in adaptive
                     // mode too: the finalise step has read the previous sample's sum before that event (same wave, earlier in
                     // the phase), so nothing zeroes the record between the samples of a pixel

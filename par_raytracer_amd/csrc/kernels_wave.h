@@ -424,11 +424,14 @@ struct ShadeTables {
 // lane of the calling group must call it (the emitter aggregates appends).  emit.shadow(...) is called once per
 // light by every lane, emit.closest(...) once at the end (its last argument tells the emitter that this lane's
 // sample has no ray left - the adaptive mode of k_pool starts the pixel's next sample from there).
-template <bool RING, bool TEX, bool RINGMEM, class Emit, class FrameT>
+template <bool RING, bool TEX, int RINGMEM, class Emit, class FrameT>
 PRT_D void shade_entry_on(const DevScene & sc, const DevParams & P, const WaveBuffers & B, const ShadeTables & tb, bool live,
                           unsigned int s, int level, unsigned int pending, f3 ray_o, f3 ray_d, f3 T, const HitRec & hit, Emit & emit,
                           unsigned int & shaded, FrameT & f) {
     const int depth = (int)P.bounce_depth;
+    // RINGMEM: 0 = no draw ring in memory (and an opaque scene); 1 = draw ring, materials may be translucent; 2 = draw ring,
+    // opaque scene (kernels_pool.h k_pool).  TRANS: the translucency paths exist.  POS: frames carry the hit position.
+    constexpr bool RM = RINGMEM != 0, TRANS = RING && RINGMEM != 2, POS = RING && RINGMEM == 1;
     Rng rng;
     rng.chain = rng.prev = rng.seed0 = 0; rng.k = 0;
     // the sample's radiance record, requested with the rest of its state: this lane owns the sample for the phase (a sample has
@@ -442,12 +445,12 @@ PRT_D void shade_entry_on(const DevScene & sc, const DevParams & P, const WaveBu
         rng.chain = rs.x; rng.prev = rs.y;
         // (seed word 0, draws so far) matter from the 15th draw on: a render whose samples provably stop before that
         // (RINGMEM = false) neither reads nor writes them - 32 bytes less per shaded hit
-        if (RING && RINGMEM) { const ulonglong2 ra = B.rng_aux[s]; rng.seed0 = ra.x; rng.k = (u32)ra.y; }
+        if (RING && RM) { const ulonglong2 ra = B.rng_aux[s]; rng.seed0 = ra.x; rng.k = (u32)ra.y; }
         if (!fresh) accum_load_owner(B.accum + s, acc_x, acc_y, acc_z);
     }
     // RINGMEM = false: the general-RNG code without its draw ring in memory, for renders whose samples provably make at
     // most 15 draws (dev_rng.h) - a compile-time NULL, so the ring code folds away
-    u64 * ring = RING && RINGMEM ? B.ring + (size_t)s * B.ring_step : nullptr;
+    u64 * ring = RING && RM ? B.ring + (size_t)s * B.ring_step : nullptr;
     const size_t ring_stride = B.ring_stride;
 
     f3 add = mk3(0.0f, 0.0f, 0.0f);          // radiance this invocation adds to the sample
@@ -499,7 +502,7 @@ PRT_D void shade_entry_on(const DevScene & sc, const DevParams & P, const WaveBu
                 }
             }
             // (the non-RING variants only run scenes whose materials all have alpha >= 1: the translucency paths fold away)
-            if (RING && alpha_tested && alpha <= 0.05f) {                           // raytracer.cpp:443-453
+            if (TRANS && alpha_tested && alpha <= 0.05f) {                           // raytracer.cpp:443-453
                 next_o = pos + ray_d * P.ray_bias * 2.0f;
                 next_d = ray_d;
                 next_T = T;
@@ -546,7 +549,7 @@ PRT_D void shade_entry_on(const DevScene & sc, const DevParams & P, const WaveBu
                 f.w_diffuse = 1.0f - w_reflect;
                 f.stage = WF_STAGE_REFL;
                 f.idx = 0;
-                T_own = RING && alpha < 1.0f ? T * alpha : T;                       // raytracer.cpp:551
+                T_own = TRANS && alpha < 1.0f ? T * alpha : T;                       // raytracer.cpp:551
                 add = add + T_own * (ka * 0.1f);                                    // raytracer.cpp:543
                 want_shadow = true;
                 mode = M_NEXT_CHILD;
@@ -597,7 +600,7 @@ PRT_D void shade_entry_on(const DevScene & sc, const DevParams & P, const WaveBu
         if (mode == M_NEXT_CHILD) {                       // frame f at `level` spawns its next child, if any
             const int iters = depth - level;
             const DevMaterial fm = tb.materials[f.mat];
-            const f3 own = RING && f.alpha < 1.0f ? f.T_in * f.alpha : f.T_in;
+            const f3 own = TRANS && f.alpha < 1.0f ? f.T_in * f.alpha : f.T_in;
             // which child comes next (cheap), then ONE copy of the expensive direction code for both lobes
             int kind = -1;                                                          // 0 diffuse, 1 specular, 2 alpha continuation
             if (f.stage == WF_STAGE_REFL) {                                         // raytracer.cpp:516-526
@@ -610,7 +613,7 @@ PRT_D void shade_entry_on(const DevScene & sc, const DevParams & P, const WaveBu
             }
             if (kind < 0 && f.stage == WF_STAGE_ALPHA) {                            // raytracer.cpp:547-552
                 f.stage = WF_STAGE_DONE;
-                if (RING && f.alpha < 1.0f) kind = 2;
+                if (TRANS && f.alpha < 1.0f) kind = 2;
             }
             const bool spawned = kind >= 0;
             if (kind == 2) {
@@ -638,7 +641,7 @@ PRT_D void shade_entry_on(const DevScene & sc, const DevParams & P, const WaveBu
                 // (64 B written, 64 B read back later) nor revisited
                 const bool more_refl = kind == 0 && (unsigned int)f.idx < P.reflection_samples;
                 const bool more_spec = kind == 0 ? P.spec_samples > 0u : (unsigned int)f.idx < P.spec_samples;
-                if (!more_refl && !more_spec && !(RING && f.alpha < 1.0f)) f.stage = WF_STAGE_DONE;
+                if (!more_refl && !more_spec && !(TRANS && f.alpha < 1.0f)) f.stage = WF_STAGE_DONE;
             }
             if (!spawned) { f_held = false; mode = M_RETURN_UP; continue; }
             f_held = true;                                // f (at `level`) stays in registers until the child's fate is known
@@ -651,7 +654,7 @@ PRT_D void shade_entry_on(const DevScene & sc, const DevParams & P, const WaveBu
             if (!dead) {
                 // the child flies: park its parent frame if that still has children to spawn afterwards
                 if (f_held && f.stage != WF_STAGE_DONE) {
-                    wframe_save<RING && RINGMEM, TEX>(B, level, s, f);
+                    wframe_save<POS, TEX>(B, level, s, f);
                     pending |= 1u << level;
                 }
                 emit_closest = true;
@@ -665,7 +668,7 @@ PRT_D void shade_entry_on(const DevScene & sc, const DevParams & P, const WaveBu
             if (pending == 0u) { mode = M_DONE; break; }
             level = 31 - __clz((int)pending);
             pending &= ~(1u << level);
-            wframe_load<RING && RINGMEM, TEX>(B, level, s, f);
+            wframe_load<POS, TEX>(B, level, s, f);
             mode = M_NEXT_CHILD;
         }
     }
@@ -675,7 +678,7 @@ PRT_D void shade_entry_on(const DevScene & sc, const DevParams & P, const WaveBu
     // will never draw again - except in adaptive mode, where the pixel's next sample continues the stream (Emit::KEEPS_RNG)
     if (live && (emit_closest || Emit::KEEPS_RNG)) {
         B.rng[s] = make_ulonglong2(rng.chain, rng.prev);
-        if (RING && RINGMEM) B.rng_aux[s] = make_ulonglong2(rng.seed0, (u64)rng.k);
+        if (RING && RM) B.rng_aux[s] = make_ulonglong2(rng.seed0, (u64)rng.k);
     }
     emit.closest(emit_closest, s, next_o, next_d, next_T, next_level, pending, live && !emit_closest);
 }
@@ -686,15 +689,15 @@ PRT_D void shade_entry(const DevScene & sc, const DevParams & P, const WaveBuffe
                        unsigned int s, int level, unsigned int pending, f3 ray_o, f3 ray_d, f3 T, const HitRec & hit, Emit & emit,
                        unsigned int & shaded) {
     WFrame f;
-    shade_entry_on<RING, TEX, true>(sc, P, B, tb, live, s, level, pending, ray_o, ray_d, T, hit, emit, shaded, f);
+    shade_entry_on<RING, TEX, 1>(sc, P, B, tb, live, s, level, pending, ray_o, ray_d, T, hit, emit, shaded, f);
 }
 
 // ... or in the lane's LDS column `col` (stride STRIDE dwords between fields; WFRAME_LDS_DWORDS fields).
-template <bool RING, bool TEX, int STRIDE, bool RINGMEM, class Emit>
+template <bool RING, bool TEX, int STRIDE, int RINGMEM, class Emit>
 PRT_D void shade_entry_lds(const DevScene & sc, const DevParams & P, const WaveBuffers & B, const ShadeTables & tb, bool live,
                            unsigned int s, int level, unsigned int pending, f3 ray_o, f3 ray_d, f3 T, const HitRec & hit, Emit & emit,
                            unsigned int & shaded, int * col) {
-    WFrameLds<STRIDE, RING && RINGMEM> f(col);
+    WFrameLds<STRIDE, RING && RINGMEM == 1> f(col);
     shade_entry_on<RING, TEX, RINGMEM>(sc, P, B, tb, live, s, level, pending, ray_o, ray_d, T, hit, emit, shaded, f);
 }
 

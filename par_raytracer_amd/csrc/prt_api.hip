@@ -510,19 +510,19 @@ int render_wavefront(prt_ctx * ctx, const DevCamera & cam, const DevParams & P, 
 
 // The wave-pool pipeline (kernels_pool.h): one launch; per-sample arrays as in the wavefront pipeline (chain 0's
 // workspace, without the global queues), plus cap (+ cap * lights shadow) ray slots per resident wave.
-// RINGMEM = false: no sample can make more than 15 RNG draws (and the scene is opaque, untextured, fixed spp): the
+// RINGMEM = 0: no sample can make more than 15 RNG draws (and the scene is opaque, untextured, fixed spp): the
 // general-RNG variant runs without its draw ring in memory (dev_rng.h).
-template <int BLOCK, int WAVES, bool LDSTAB, bool RING, bool COUNT, bool TEX, bool ADAPT, bool RINGMEM, bool EXACT>
+template <int BLOCK, int WAVES, bool LDSTAB, bool RING, bool COUNT, bool TEX, bool ADAPT, int RINGMEM, bool EXACT>
 int launch_pool_kernel(prt_ctx * ctx, unsigned int grid, size_t lds, const PoolArgs * d_args) {
     hipLaunchKernelGGL((k_pool<BLOCK, WAVES, LDSTAB, RING, COUNT, TEX, ADAPT, RINGMEM, EXACT>), dim3(grid), dim3(BLOCK), lds, ctx->stream, d_args, ctx->counters.p);
     HIP_TRY(ctx, hipGetLastError());       // a template variant that cannot launch (LDS, registers) is reported here, by name of its cause
     return 0;
 }
 
-template <int BLOCK, int WAVES, bool LDSTAB, bool RING, bool TEX, bool ADAPT, bool RINGMEM = true>
+template <int BLOCK, int WAVES, bool LDSTAB, bool RING, bool TEX, bool ADAPT, int RINGMEM = 1>
 int launch_pool(prt_ctx * ctx, bool count, const DevCamera & cam, DevParams P, unsigned int n_samples, unsigned int stack_entries) {
     // the stack columns double as the shading phase's frame storage (WFRAME_LDS_DWORDS per lane)
-    const size_t lds = (size_t)std::max(stack_entries * (unsigned int)STACK_ENTRY_INTS, (unsigned int)((RING && RINGMEM) ? WFRAME_LDS_DWORDS : WFRAME_LDS_DWORDS_NOPOS)) * BLOCK * sizeof(int);
+    const size_t lds = (size_t)std::max(stack_entries * (unsigned int)STACK_ENTRY_INTS, (unsigned int)((RING && RINGMEM == 1) ? WFRAME_LDS_DWORDS : WFRAME_LDS_DWORDS_NOPOS)) * BLOCK * sizeof(int);
     const PrtOptions & opt = ctx->opt;
     // Three launches (kernels_pool.h PoolBuffers::park): the fast kernel, which parks the rays it cannot finish - a hit with
     // company within a few ulp, a stack column that overflowed -; k_pool_parked_shadows for the parked shadow rays; the EXACT
@@ -557,7 +557,7 @@ int launch_pool(prt_ctx * ctx, bool count, const DevCamera & cam, DevParams P, u
     prt_ctx::ChainWs & w = ctx->chain[0];
     const size_t N = n_samples;
     const unsigned int levels = std::max(1u, P.bounce_depth);
-    const unsigned int fr4 = TEX ? 7u : (RING && RINGMEM) ? 5u : 4u;       // kernels_wave.h wframe_save
+    const unsigned int fr4 = TEX ? 7u : (RING && RINGMEM == 1) ? 5u : 4u;       // kernels_wave.h wframe_save
     HIP_TRY(ctx, w.f4.ensure((size_t)levels * fr4 * N));
     HIP_TRY(ctx, w.rng.ensure(RING ? 2 * N : N));
     HIP_TRY(ctx, ctx->pool_f4.ensure((size_t)waves * (7u * (size_t)cap + 3u * (size_t)scap)));
@@ -597,7 +597,7 @@ int launch_pool(prt_ctx * ctx, bool count, const DevCamera & cam, DevParams P, u
     B.accum = reinterpret_cast<Accum *>(ctx->sample_rgb.p);
     B.rng = w.rng.p;
     B.rng_aux = RING ? w.rng.p + N : nullptr;
-    B.ring = RING && RINGMEM ? ctx->ring_ws.p : nullptr;
+    B.ring = RING && RINGMEM != 0 ? ctx->ring_ws.p : nullptr;
     B.ring_step = ADAPT ? 16u : 1u;                              // WaveBuffers::ring: pixel-major in adaptive mode
     B.ring_stride = ADAPT ? 1u : (unsigned int)n_samples;
     B.frames = w.f4.p;
@@ -964,13 +964,20 @@ int render_pixels_once(prt_ctx * ctx, const prt_camera * cam_in, const prt_param
             // Untextured fixed-spp renders: 5 waves per SIMD (96 VGPRs, 23 dwords spilled).  Textured (64 spilled at 96) and
             // adaptive (68 spilled at 96, no gain measured: profiles/r02_experiments.txt item 11) renders: 4 waves per SIMD.
             // 6 waves (80 VGPRs) spill 90-230 dwords: 29 ms.
+            // last argument (k_pool's RINGMEM): 0 = no sample passes 15 draws (and the scene is opaque and untextured): no draw ring
+            // in memory; 1 = draw ring, materials may be translucent; 2 = draw ring, opaque scene: the translucency paths and the
+            // frames' hit position fold away as they do for 0.  2 is used for the adaptive mode (-3.6 % on C4 10..50 spp); the
+            // fixed-spp kernel for deep bounce trees allocates worse with it at 96 VGPRs (47 dwords spilled instead of 31: +1 %)
+            // and stays on 1 (profiles/r03_adaptive.txt item 7)
+            const bool opaque = !ctx->any_translucent && !ctx->textured;
             if (adaptive)
                 rc = ctx->textured ? launch_pool<256, 4, false, true, true, true>(ctx, count_visits, cam, P, n_samples, stack_entries)
-                                   : launch_pool<256, PRT_ADAPT_WAVES, false, true, false, true>(ctx, count_visits, cam, P, n_samples, stack_entries);
+                   : opaque ? launch_pool<256, PRT_ADAPT_WAVES, false, true, false, true, 2>(ctx, count_visits, cam, P, n_samples, stack_entries)
+                            : launch_pool<256, PRT_ADAPT_WAVES, false, true, false, true, 1>(ctx, count_visits, cam, P, n_samples, stack_entries);
             else
                 rc = ctx->textured ? launch_pool<256, 4, false, true, true, false>(ctx, count_visits, cam, P, n_samples, stack_entries)
-                   : ring ? launch_pool<256, PRT_POOL_WAVES, false, true, false, false>(ctx, count_visits, cam, P, n_samples, stack_entries)
-                          : launch_pool<256, PRT_POOL_WAVES, false, true, false, false, false>(ctx, count_visits, cam, P, n_samples, stack_entries);
+                   : !ring ? launch_pool<256, PRT_POOL_WAVES, false, true, false, false, 0>(ctx, count_visits, cam, P, n_samples, stack_entries)
+                           : launch_pool<256, PRT_POOL_WAVES, false, true, false, false, 1>(ctx, count_visits, cam, P, n_samples, stack_entries);
             launches += 1;
         } else {
             unsigned long long rays = 0;

@@ -346,7 +346,7 @@ def test_random_configurations_against_the_oracle(cfg):
         r.close()
 
 
-@pytest.mark.parametrize("scene", ["cornell_box", "terrain_64"])
+@pytest.mark.parametrize("scene", ["cornell_box", "terrain_64", "many_materials"])      # the last one has translucent materials: the general adaptive kernel
 def test_adaptive_stopping_rule_at_thresholds_among_the_pixels_variances(scene):
     """The stopping rule (main.cpp:190-222, 253-257) is decided from a lower bound on the variance where that bound clears the
     threshold, and by the reference's loop over the stored samples otherwise (kernels_pool.h finalise step).  Thresholds

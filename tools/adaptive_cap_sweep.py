@@ -11,7 +11,7 @@ w, h = 1920, 1080
 cam = api.make_camera(s.fov, w, h, s.camera_position, s.camera_facing)
 buf = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda"); torch.cuda.synchronize()
 ref = None
-for cap, topup in ((0, 0), (64, 0), (64, 16), (64, 48), (128, 0), (128, 32), (128, 96), (128, 0), (0, 0)):
+for cap, topup in ((0, 0), (128, 16), (128, 32), (128, 48), (128, 80), (128, 96), (128, 112), (128, 128), (0, 0), (128, 32), (128, 96)):
     for k, v in (("PRT_POOL_CAP", cap), ("PRT_POOL_TOPUP", topup)):
         if v: os.environ[k] = str(v)
         else: os.environ.pop(k, None)
