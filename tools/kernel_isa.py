@@ -2,7 +2,7 @@
 """Disassemble one kernel of libprt_hip.so and summarise it per basic block: instruction counts, scratch (spill) traffic
 and where the node step (v_cvt_f32_ubyte*) and the triangle test (v_rcp / v_div) live.
 
-    python tools/kernel_isa.py "k_pool<256, 5, false, true, false, false, false, false>" [--dump out.s]
+    python tools/kernel_isa.py "k_pool<256, 5, false, true, false, false, false, 0, false>" [--dump out.s]
 """
 import os, re, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -26,7 +26,7 @@ for tag, name in (("trace", "%s_pool_C4_kernel_stats.csv" % rnd), ("trace_other"
 
 fetch, nf = counters("fetch"); write, _ = counters("write")
 sq1, n1 = counters("sq1"); sq2, _ = counters("sq2"); ta, nta = counters("ta")
-FAST = "k_pool<256, 5, false, true, false, false, false, false, false>"        # the timed frames' kernel (COUNT = false, EXACT = false)
+FAST = "k_pool<256, 5, false, true, false, false, false, 0, false>"        # the timed frames' kernel (COUNT = false, EXACT = false)
 import hashlib, subprocess
 lib = os.path.join(ROOT, "par_raytracer_amd", "libprt_hip.so")
 try:
