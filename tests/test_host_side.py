@@ -83,6 +83,19 @@ def test_error_paths_without_a_gpu_or_scene():
     assert lib.prt_upload_scene(None, None) == -1
     assert lib.prt_render(None, None, None, 1, 1, 0, 1, None, None) == -1
     assert lib.prt_shard_rows(1080, 8, 0, 0) == 0 and lib.prt_shard_rows(1080, 0, 0, 1) == 0
+    # the n-device handle and the option call: null handles are errors, never crashes
+    import ctypes as C
+    assert not lib.prt_multi_create(None, 0)
+    assert b"no devices" in lib.prt_multi_last_error(None)
+    if not torch.cuda.is_available():
+        assert not lib.prt_multi_create((C.c_int * 2)(0, 1), 2)
+        assert b"no HIP device" in lib.prt_multi_last_error(None)
+    assert lib.prt_multi_device_count(None) == 0 and not lib.prt_multi_context(None, 0)
+    assert lib.prt_multi_upload_scene(None, None) == -1
+    assert lib.prt_multi_render(None, None, None, 1, 1, None, None) == -1
+    lib.prt_multi_destroy(None)
+    assert lib.prt_set_option(None, b"STACK_CAP", b"2") == -1
+    assert lib.prt_build_flags() & ~(capi.BUILD_EXPERIMENTAL | capi.BUILD_BVH4) == 0
 
 
 def test_shard_rows_partition_the_frame():
