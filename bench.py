@@ -144,6 +144,11 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend; gloo (host-staged) only exists to rehearse the N > 1 path on a 1-GPU box")
     ap.add_argument("--share-device", action="store_true", help="rehearsal: every rank uses GPU 0")
+    ap.add_argument("--force-collective", action="store_true",
+                    help="--gpus 1 only: run the N > 1 machinery with ONE rank - the process group is initialised (RCCL with --backend "
+                         "nccl), the render streams are CU-masked (PRT_RESERVE_CUS=8), two frames are in flight, every frame's shard "
+                         "is gathered to rank 0 (= itself) on the side stream and assembled.  Everything of the multi-GPU path "
+                         "except xGMI meets the real library (reference: the MPI_Gather of main.cpp:345-347)")
     ap.add_argument("--frames-in-flight", type=int, default=0,
                     help="consecutive frames rendered concurrently (own context, stream and workspace each): the drain tail "
                          "of frame k overlaps the start of frame k + 1.  1 = strictly one frame at a time; 0 = auto: 1 on one "
@@ -161,6 +166,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit("WORLD_SIZE=%d but --gpus %d" % (world, args.gpus))
+    if args.force_collective and world != 1:
+        raise SystemExit("--force-collective is the one-rank rehearsal of the collective path: use it with --gpus 1")
+    collective = world > 1 or args.force_collective        # the gather / assemble / frames-in-flight machinery runs
+    if args.force_collective:
+        # a one-rank process group of our own (no launcher): rendezvous on 127.0.0.1, a free port
+        import socket
+        with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(port))
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
 
     import torch
     import torch.distributed as dist
@@ -169,7 +187,7 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
-    if world > 1 and args.backend == "nccl":
+    if collective and args.backend == "nccl":
         # The RCCL gather of frame k runs while frame k + 1 renders (frames in flight).  The render kernels are persistent and
         # fill every wave slot they are offered: their streams are created with a CU mask that leaves 8 compute units free, so
         # the gather's kernels never wait for a render block to retire (csrc/prt_api.hip prt_create).
@@ -178,7 +196,7 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    if collective:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if args.backend == "nccl":
             # the gather shares the GPU with persistent render kernels that fill every wave slot: let its kernels go first
@@ -187,7 +205,7 @@ def main():
         else:
             dist.init_process_group("gloo")
     cdev = dev if args.backend == "nccl" else torch.device("cpu")   # where collective payloads live
-    if world > 1:
+    if collective:
         # The context's CU-masked render streams (PRT_RESERVE_CUS) are created by hipExtStreamCreateWithCUMask, which has no
         # flags: they are BLOCKING streams, implicitly ordered against the legacy null stream - torch's default.  Everything
         # this rank does in torch from here on (gather, cat, assemble, event records) therefore runs on a stream of its own
@@ -205,7 +223,7 @@ def main():
         meta = [obj_dir, list(scene.camera_position), list(scene.camera_facing), float(scene.fov)]
     else:
         meta = [None, None, None, None]
-    if world > 1:
+    if collective:
         dist.broadcast_object_list(meta, src=0)
     obj_dir, cam_pos, cam_dir, fov = meta
     t1 = time.time()
@@ -225,7 +243,7 @@ def main():
     # workspace and output buffer; frame k runs on context k % F from its own host thread (the render call blocks its
     # caller: the wavefront pipeline needs host round trips).  Every frame is still complete - rendered, gathered,
     # assembled - inside the timed region; only the GPU idle time at the end of one frame is filled by the next.
-    F = args.frames_in_flight if args.frames_in_flight > 0 else (1 if world == 1 else 2)
+    F = args.frames_in_flight if args.frames_in_flight > 0 else (2 if collective else 1)
     renderers = [r]
     for _ in range(F - 1):
         extra = api.Renderer(local_rank)
@@ -238,7 +256,7 @@ def main():
     max_rows = sharding.max_shard_rows(height, SHARD_BLOCK_ROWS, world)
     # more output buffers than contexts: a buffer is only reused NB frames later, so a gather that the GPU schedules late
     # (the persistent render kernels leave it few free wave slots) does not stall the frames behind it
-    NB = F + 2 if world > 1 else F
+    NB = F + 2 if collective else F
     shards = [torch.zeros((max_rows, width, 4), dtype=torch.float32, device=dev) for _ in range(NB)]
     shard = shards[0]
     torch.cuda.synchronize()               # the zero fills ran on torch's stream; the renderer writes from its own streams
@@ -246,29 +264,33 @@ def main():
     gather_list = None
     row_index = None
     frame = None
-    if world > 1 and rank == 0:
+    gather_events = []                     # (start, end) event pairs around every gather + assemble on the side stream
+    if collective and rank == 0:
         gather_list = [torch.empty_like(shard) for _ in range(world)]
         row_index = torch.from_numpy(sharding.row_index(height, SHARD_BLOCK_ROWS, world)).to(dev)
 
     def render_frame(slot, bslot=None):
         """Render one frame into buffer `bslot` on context `slot` (called from a worker thread when F > 1)."""
         rr, buf = renderers[slot], shards[slot if bslot is None else bslot]
-        if world == 1:
+        if not collective:
             return rr.render_device(cam, params, width, height, 0, width * height, buf.data_ptr(), True)
         return rr.render_shard_device(cam, params, width, height, SHARD_BLOCK_ROWS, rank, world, buf.data_ptr(), True)
 
     def deliver_frame(slot):
         """Main thread, after the frame in buffer `slot` is rendered: gather the shards to rank 0 and assemble."""
         nonlocal frame
-        if world == 1:
+        if not collective:
             return
         buf = shards[slot]
         if args.backend == "nccl":
+            ev0 = torch.cuda.Event(enable_timing=True)
+            ev0.record()
             dist.gather(buf, gather_list, dst=0)                    # RCCL over xGMI: 7 shards -> GPU 0 (asynchronous)
             if rank == 0:
                 frame = sharding.assemble(torch.cat(gather_list, dim=0), row_index, height)
-            gathered[slot] = torch.cuda.Event()
+            gathered[slot] = torch.cuda.Event(enable_timing=True)
             gathered[slot].record()
+            gather_events.append((ev0, gathered[slot]))
         else:
             host = buf.cpu()
             gl = [torch.empty_like(host) for _ in range(world)] if rank == 0 else None
@@ -298,7 +320,7 @@ def main():
         return out
 
     def sync_all():
-        if world > 1:
+        if collective:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -317,7 +339,7 @@ def main():
     render_ms = [c.render_ms for c in counters]
 
     t = torch.tensor([elapsed, float(rays_local)], dtype=torch.float64, device=cdev)
-    if world > 1:
+    if collective:
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tsum = t.clone()
@@ -329,14 +351,14 @@ def main():
     ms_per_step = elapsed * 1e3 / args.steps
     value = rays_total / elapsed / 1e6
     ranks_seen = 1
-    if world > 1:
+    if collective:
         one = torch.ones(1, dtype=torch.int32, device=cdev)
         dist.all_reduce(one, op=dist.ReduceOp.SUM)                 # every rank of the group took part in the collective path
         ranks_seen = int(one.item())
 
     # ---- roofline of the dominant kernel: one extra, untimed render with visit counting (identical pixels)
     pcount = api.default_params(spp, SEED, bounce_depth=depth, pipeline=args.pipeline | capi.FLAG_COUNT_VISITS)
-    if world == 1:
+    if not collective:
         cc = r.render_device(cam, pcount, width, height, 0, width * height, shard.data_ptr(), True)
     else:
         cc = r.render_shard_device(cam, pcount, width, height, SHARD_BLOCK_ROWS, rank, world, shard.data_ptr(), True)
@@ -558,7 +580,22 @@ def main():
             pipelined = {"error": repr(e)[:300]}
 
     multi_check = None
-    if world > 1 and rank == 0 and frame is not None:
+    collective_info = None
+    if collective and rank == 0:
+        gms = []
+        for a, b in gather_events[-args.steps:]:
+            try:
+                gms.append(a.elapsed_time(b))
+            except Exception:
+                pass
+        collective_info = {"backend": args.backend, "world_size": world, "forced_at_world_size_1": bool(args.force_collective),
+                           "reserved_cus": int(os.environ.get("PRT_RESERVE_CUS", "0")), "frames_in_flight": F,
+                           "gathers_timed": len(gms),
+                           "gather_and_assemble_ms_mean": round(float(np.mean(gms)), 4) if gms else None,
+                           "gather_and_assemble_ms_max": round(float(np.max(gms)), 4) if gms else None,
+                           "note": "device time from the gather's enqueue to the end of the assembly on the side stream (they run beside "
+                                   "the next frame's render kernels, so this is latency, not time added to a frame)"}
+    if collective and rank == 0 and frame is not None:
         # the assembled multi-GPU frame must be bit-identical to what one GPU computes for the same pixels
         lat = 16
         one, _ = r.render_lattice(cam, params, width, height, lat)
@@ -572,6 +609,9 @@ def main():
             "metric": "Mrays/s at 1920x1080x8spp, 1M-tri OBJ" if args.workload == "C4" else "Mrays/s (%s)" % args.workload,
             "value": round(value, 3), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            # `value` divides the reference's ray_count (which the device reproduces exactly) by the time; the device does not
+            # trace the shadow rays that cannot change the image: the rate over the rays it really traces, for the same frames
+            "value_traced_rays_only": round(value * rays_traced / max(1, int(cc.ray_count)), 3) if world == 1 else None,
             "ranks_seen": ranks_seen,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": descr, "seed": SEED, "triangles": int(info.triangle_count), "width": width, "height": height,
@@ -585,10 +625,11 @@ def main():
                        "rays_counted_not_traced_per_frame": rays_elided if world == 1 else None,
                        "value_traced_rays_only": round(value * rays_traced / max(1, int(cc.ray_count)), 3) if world == 1 else None,
                        "parallelism": "pixel rows sharded in %d-row blocks over %d GPU(s)%s" % (
-                           SHARD_BLOCK_ROWS, world, (", RCCL gather to rank 0" if args.backend == "nccl" else ", gloo gather (rehearsal)") if world > 1 else ""),
+                           SHARD_BLOCK_ROWS, world, (", RCCL gather to rank 0" if args.backend == "nccl" else ", gloo gather (rehearsal)") if collective else ""),
                        "pipeline": pipeline_name, "frames_in_flight": F},
             "render_ms_device": round(float(np.mean(render_ms)), 4),
             "roofline": roofline, "cpu_baseline": cpu_baseline, "parity": parity, "multi_gpu_check": multi_check,
+            "collective": collective_info,
             "extra": {"other_workloads": other, "two_frames_in_flight_one_gpu": pipelined},
         }
         print(json.dumps(out), flush=True)
@@ -596,7 +637,7 @@ def main():
         pool.shutdown()
     for rr in renderers:
         rr.close()
-    if world > 1:
+    if collective:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -12,7 +12,9 @@
  * host mirror (par_raytracer_amd/host/) re-implements on top of these entry points.
  *
  * Everything here is plain C: pointers, sizes and POD structs; no C++ or torch types.
- * Return convention: 0 = ok, negative = error (message via prt_last_error); nothing aborts.
+ * Return convention: 0 = ok, negative = error (message via prt_last_error); nothing aborts: a C++ exception inside
+ * the library (std::bad_alloc, std::length_error, std::system_error ...) is caught at the entry point and comes back as
+ * PRT_ERR_EXCEPTION.
  * Threading: one host thread per context at a time; one HIP device and one stream per context.
  */
 #ifndef PRT_H_
@@ -25,7 +27,11 @@
 extern "C" {
 #endif
 
-#define PRT_ABI_VERSION 4
+#define PRT_ABI_VERSION 5
+/* Error codes (every entry point that returns int): -1 bad argument, -2 no scene uploaded, -5 / -6 internal limits of the
+ * wavefront pipeline, -7 park lists kept overflowing, -8 near-tied hits unresolved, -10 a HIP runtime call failed,
+ * -11 too many frames in flight (prt_multi_submit), -12 a C++ exception was caught at the entry point. */
+enum { PRT_ERR_ARGUMENT = -1, PRT_ERR_NO_SCENE = -2, PRT_ERR_HIP = -10, PRT_ERR_IN_FLIGHT = -11, PRT_ERR_EXCEPTION = -12 };
 
 /* ---- scene description: the reference's pointer graph flattened to POD arrays ---------------- */
 
@@ -243,16 +249,31 @@ int prt_render_pixel_list(prt_ctx * ctx, const prt_camera * cam, const prt_param
  * kernels), a small kernel there puts the rows in place, and one copy takes the frame to the host buffer rgba_out
  * (width * height * 4 floats).  The frame is bit-identical to what prt_render gives on one device.  The same ordinal may be
  * listed more than once (rehearsal of the n-device path on one GPU: the peer copy is then a copy within the device).
- * prt_multi_context(m, i) is device i's ordinary context (options, scene info, stats). */
+ * prt_multi_context(m, i) is device i's ordinary context (options, scene info, stats).
+ *
+ * Frames in flight (ABI 5).  A persistent render kernel leaves its GPU partly idle while its last rays drain, and the copies,
+ * assembly and download of frame k need no compute unit that frame k + 1 could not use.  The handle therefore has
+ * prt_multi_depth() lanes (2 unless the environment says PRT_MULTI_DEPTH=1..4 at creation): a lane is one context per device
+ * - lane 0 the contexts above, the others clones that share the uploaded scene's device arrays and own only their streams
+ * and workspaces - with worker threads that live as long as the handle (one per lane and device; nothing is created per
+ * frame).  prt_multi_submit hands a frame to a free lane and returns at once with a ticket (PRT_ERR_IN_FLIGHT if every lane
+ * is busy); the lane renders, and its shards travel to device 0, while the caller does something else - submits the next
+ * frame, say; prt_multi_wait(ticket) blocks until that frame is assembled and in rgba_out (which must stay valid until
+ * then) and frees the lane.  Tickets may be waited for in any order.  prt_multi_render is submit + wait.  All calls on one
+ * handle come from one host thread at a time. */
 typedef struct prt_multi prt_multi;
 prt_multi * prt_multi_create(const int * device_ids, int n_dev);
-void prt_multi_destroy(prt_multi * m);
+void prt_multi_destroy(prt_multi * m);                            /* waits for frames still in flight */
 const char * prt_multi_last_error(const prt_multi * m);           /* m may be NULL: last creation error */
 int prt_multi_device_count(const prt_multi * m);
+int prt_multi_depth(const prt_multi * m);                         /* frames that can be in flight at once */
 prt_ctx * prt_multi_context(prt_multi * m, int i);
-int prt_multi_upload_scene(prt_multi * m, const prt_scene_desc * scene);
+int prt_multi_upload_scene(prt_multi * m, const prt_scene_desc * scene);   /* not while a frame is in flight */
 int prt_multi_render(prt_multi * m, const prt_camera * cam, const prt_params * params, uint32_t width, uint32_t height,
                      float * rgba_out, prt_counters * counters);
+int prt_multi_submit(prt_multi * m, const prt_camera * cam, const prt_params * params, uint32_t width, uint32_t height,
+                     float * rgba_out, uint64_t * ticket);
+int prt_multi_wait(prt_multi * m, uint64_t ticket, prt_counters * counters);
 
 /* Introspection for DESIGN.md / bench.py: sizes of what upload built. */
 typedef struct prt_scene_info {
@@ -297,6 +318,12 @@ int prt_debug_check_bvh_lbvh(prt_ctx * ctx, const prt_scene_desc * scene, uint64
  * must be uploaded (the diffuse-direction kind reads its table). */
 int prt_debug_device_kat(prt_ctx * ctx, int kind, const void * in, size_t in_bytes, void * out, size_t out_bytes,
                          uint32_t n, const prt_camera * cam);
+
+/* Test hook of the exception guard every entry point runs under ("nothing aborts"): throws, inside a guarded entry point,
+ * 1 std::bad_alloc, 2 a real std::length_error (a vector asked for more than max_size), 3 std::runtime_error, 4 an int -
+ * and returns what the caller of any entry point would get: PRT_ERR_EXCEPTION, with the message in prt_last_error(ctx).
+ * kind 0 returns 0.  ctx may be NULL (no GPU needed). */
+int prt_debug_throw(prt_ctx * ctx, int kind);
 
 #ifdef __cplusplus
 }

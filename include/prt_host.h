@@ -59,6 +59,12 @@ float prt_host_tonemap(const float * rgba, uint32_t width, uint32_t height, uint
 uint8_t * prt_host_load_texture(const char * filename, uint32_t * size_x, uint32_t * size_y, uint32_t * channels);
 void prt_host_free_texture(uint8_t * texels);
 
+/* Every entry point above runs under an exception guard: a C++ exception inside the host mirror (std::bad_alloc ...) comes
+ * back as the function's error value (NULL, -12) with the message in prt_host_last_error / prt_host_render_error; nothing
+ * aborts.  Test hook: throws kind 1 std::bad_alloc, 2 std::length_error, 3 std::runtime_error, 4 an int inside a guarded
+ * entry point and returns -12 (0 for kind 0). */
+int prt_host_debug_throw(int kind);
+
 #ifdef __cplusplus
 }
 #endif

@@ -104,11 +104,11 @@ BUILD_EXPERIMENTAL, BUILD_BVH4 = 1, 2
 PRT_SYMBOLS = ["prt_create", "prt_destroy", "prt_last_error", "prt_abi_version", "prt_set_option", "prt_build_flags", "prt_upload_scene", "prt_render",
                "prt_render_device", "prt_shard_rows", "prt_render_shard_device", "prt_render_shard", "prt_render_pixel_list", "prt_get_scene_info", "prt_get_render_stats", "prt_debug_check_bvh", "prt_debug_check_bvh_lbvh", "prt_debug_device_kat",
                "prt_multi_create", "prt_multi_destroy", "prt_multi_last_error", "prt_multi_device_count", "prt_multi_context",
-               "prt_multi_upload_scene", "prt_multi_render"]
+               "prt_multi_upload_scene", "prt_multi_render", "prt_multi_depth", "prt_multi_submit", "prt_multi_wait", "prt_debug_throw"]
 PRT_HOST_SYMBOLS = ["prt_host_load_obj", "prt_host_free_scene", "prt_host_scene_desc", "prt_host_scene_hierarchy_seconds",
                     "prt_host_scene_parse_seconds", "prt_host_last_error", "prt_host_make_camera",
                     "prt_host_default_params", "prt_host_render", "prt_host_render_error", "prt_host_write_image", "prt_host_tonemap",
-                    "prt_host_load_texture", "prt_host_free_texture"]
+                    "prt_host_load_texture", "prt_host_free_texture", "prt_host_debug_throw"]
 
 
 class LibraryMissing(RuntimeError):
@@ -171,6 +171,11 @@ def hip_lib() -> C.CDLL:
         lib.prt_multi_upload_scene.argtypes = [C.c_void_p, C.POINTER(PrtSceneDesc)]
         lib.prt_multi_render.argtypes = [C.c_void_p, C.POINTER(PrtCamera), C.POINTER(PrtParams), C.c_uint32, C.c_uint32,
                                          C.c_void_p, C.POINTER(PrtCounters)]
+        lib.prt_multi_depth.argtypes = [C.c_void_p]
+        lib.prt_multi_submit.argtypes = [C.c_void_p, C.POINTER(PrtCamera), C.POINTER(PrtParams), C.c_uint32, C.c_uint32,
+                                         C.c_void_p, C.POINTER(C.c_uint64)]
+        lib.prt_multi_wait.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(PrtCounters)]
+        lib.prt_debug_throw.argtypes = [C.c_void_p, C.c_int]
         _hip = lib
     return _hip
 

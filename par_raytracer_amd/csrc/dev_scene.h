@@ -170,6 +170,9 @@ struct DevCounters {          // device-side accumulators (atomics, one add per 
     // pool pipeline: the most entries any pass wanted to put on its park lists ([0] closest-hit rays + finalise steps, [1] shadow
     // rays); above the lists' capacities the frame is incomplete and render_pixels renders it again with longer lists
     unsigned long long park_peak[2];
+    // ... and whether any PASS wanted more than ITS lists held (a call's passes clamp the lists to their own worst case: the
+    // peak of one pass says nothing about the capacity of another): the largest such demand, 0 when every pass fitted
+    unsigned long long park_over[2];
     unsigned long long elided_shadow_rays;     // shadow rays counted (they are in ray_count) but not traced: they could not change the image
     unsigned long long near_tie_unresolved;    // resolve_near_ties gave up widening its candidate set (the render call fails)
 };

@@ -22,6 +22,16 @@
 //
 // Results are those of the wavefront pipeline bit for bit: same shade_entry(), same traversal, same per-sample
 // RNG keys; only the order in which independent samples are processed differs.
+//
+// Round 4: BLOCK-SHARED pools (template parameter SHARED).  A round that is private to a wave is thin where there is little
+// work per wave - a 1/8-frame shard of a multi-GPU run, the adaptive mode's one ray per pixel - and every thin round ends with
+// a wave that issues its node steps for a handful of lanes (a 1/8 shard: 32 % of the node loop's lane slots hold no ray).
+// With SHARED the UNIT that owns a pool is the workgroup: its four waves top up one list together, pull the rays of the
+// trace phase from it by an LDS counter (ds_add_rtn per refill, slots by ballot rank as before), shade its hits 64 at a
+// time and append to the next list through LDS counters; the phases are separated by workgroup barriers.  A round is then
+// four times as wide at the same state in flight, its tail is shared by four waves - the waves that run dry first wait at
+// the barrier, where they issue nothing, instead of walking half-empty - and everything else (lists in HBM, per-sample
+// state, parking, the adopting EXACT launch, which keeps wave-private pools) is unchanged.
 #pragma once
 
 #include "kernels_wave.h"
@@ -29,11 +39,11 @@
 namespace prt {
 
 struct PoolBuffers {
-    float4 * cq;                 // [waves][2][3][cap]   closest-hit lists, double buffered: (o, sample) (d, level | pending << 8) (T, -)
-    float4 * hits;               // [waves][cap]         (t, v, w, tri) by list position
-    float4 * sq;                 // [waves][3][scap]     shadow list: (o, sample) (radiance, w) (d, -), see WaveBuffers::sq_*
+    float4 * cq;                 // [units][2][3][cap]   closest-hit lists, double buffered: (o, sample) (d, level | pending << 8) (T, -)
+    float4 * hits;               // [units][cap]         (t, v, w, tri) by list position
+    float4 * sq;                 // [units][3][scap]     shadow list: (o, sample) (radiance, w) (d, -), see WaveBuffers::sq_*
     unsigned int * head;         // global sample counter (adopting launch: counter into the park list)
-    unsigned int cap, scap;      // slots per wave; multiples of 64
+    unsigned int cap, scap;      // slots per unit (a wave; a workgroup when the pools are block-shared); multiples of 64
     unsigned int topup_min;      // top up when at least this many slots are free
     // Rays the fast kernel (EXACT = false) cannot finish - the hit has company within a few ulp and the reference's visit order
     // decides (dev_trace.h resolve_near_ties), or a push did not fit the LDS stack column - are PARKED, list entry and all,
@@ -48,49 +58,69 @@ struct PoolBuffers {
     unsigned int park_cap, spark_cap;
     unsigned int adopt;          // EXACT kernels: 1 = top up from the park list, not from the sample counter
     // adaptive mode (k_pool<ADAPT>): the unit in the pool is a PIXEL that runs its samples one after the other
-    unsigned int * fin;          // [waves][cap]         pixels whose current sample has no ray left; finalised after the next trace phase
+    unsigned int * fin;          // [units][cap]         pixels whose current sample has no ray left; finalised after the next trace phase
     float4 * scratch;            // [n_pixels][max_spp]  every sample's colour (RenderPixel's scratch_buffer, main.cpp:232)
     float4 * jobsum;             // [n_pixels]           (running colour sum .xyz, samples finished so far as int bits)
     float4 * final_rgb;          // [n_pixels]           the pixel's colour when it is done
+    // diagnostics (COUNT kernels, option DEBUG_UTIL): per wave of the fast kernel, the 100 MHz wall clock at (start of its main
+    // loop, the moment the sample counter ran dry for it, its exit); NULL otherwise
+    unsigned long long * wave_times;
 };
 
-// Emitter of k_pool: appends to the wave's private lists, slots by rank among the appending lanes.
-template <bool ADAPT>
+// Emitter of k_pool: appends to the unit's lists, slots by rank among the appending lanes.  Per-wave pools (SHARED = false):
+// the fill counts are wave-uniform registers.  Block-shared pools: they are LDS words that every wave of the block adds to -
+// one ds_add_rtn per wave and call, the lanes' slots follow from the returned base and the ballot rank as before.
+template <bool ADAPT, bool SHARED>
 struct PoolEmit {
     enum { KEEPS_RNG = ADAPT ? 1 : 0 };      // adaptive mode: the pixel's next sample continues the RNG stream of the one that ended
     float4 * co, * cd, * ct;     // next closest list
     float4 * so, * sc, * sd;     // next shadow list
     unsigned int * fin;          // ADAPT: pixels to finalise after the next trace phase
-    unsigned int m_c, m_s, m_f;  // wave-uniform fill counts
+    unsigned int m_c, m_s, m_f;  // wave-uniform fill counts (SHARED: unused, the counts are s_cnt[0..2])
+    unsigned int * s_cnt;        // SHARED: LDS, [0] closest [1] shadow [2] finalise entries of the lists being filled
     unsigned int m_elided;       // wave-uniform: shadow rays counted, not traced (their radiance-if-unoccluded is zero)
+    // first slot of this wave's `n` new entries of list `which` (0 closest, 1 shadow, 2 finalise); called wave-converged
+    PRT_D unsigned int reserve(int which, unsigned int n) {
+        if (SHARED) {
+            if (n == 0u) return 0u;
+            unsigned int base = 0;
+            if (lane_id() == 0u) base = atomicAdd(&s_cnt[which], n);
+            return (unsigned int)__builtin_amdgcn_readfirstlane((int)base);
+        }
+        unsigned int & m = which == 0 ? m_c : which == 1 ? m_s : m_f;
+        const unsigned int base = m;
+        m += n;
+        return base;
+    }
     PRT_D void elided(bool dead) { m_elided += (unsigned int)__popcll(__ballot(dead)); }
     PRT_D void shadow(bool want, unsigned int s, f3 o, f3 d, f3 contrib, float w, int kind) {
         const unsigned long long mask = __ballot(want);
         const unsigned int prefix = __builtin_amdgcn_mbcnt_hi((unsigned int)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)mask, 0u));
+        const unsigned int base = reserve(1, (unsigned int)__popcll(mask));
         if (want) {
-            const unsigned int slot = m_s + prefix;
+            const unsigned int slot = base + prefix;
             so[slot] = make_float4(o.x, o.y, o.z, as_f((int)s));
             if (kind == WF_KIND_SHADOW_DIST) sd[slot] = make_float4(d.x, d.y, d.z, 0.0f);
             sc[slot] = make_float4(contrib.x, contrib.y, contrib.z, w);
         }
-        m_s += (unsigned int)__popcll(mask);
     }
-    PRT_D void closest(bool want, unsigned int s, f3 o, f3 d, f3 T, int level, unsigned int pending, bool sample_ended) {
+    // returns the list slot of this lane's ray (meaningful where `want`)
+    PRT_D unsigned int closest(bool want, unsigned int s, f3 o, f3 d, f3 T, int level, unsigned int pending, bool sample_ended) {
         if (ADAPT) {
             const unsigned long long ended = __ballot(sample_ended);
             const unsigned int rank = __builtin_amdgcn_mbcnt_hi((unsigned int)(ended >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)ended, 0u));
-            if (sample_ended) fin[m_f + rank] = s;
-            m_f += (unsigned int)__popcll(ended);
+            const unsigned int fbase = reserve(2, (unsigned int)__popcll(ended));
+            if (sample_ended) fin[fbase + rank] = s;
         }
         const unsigned long long mask = __ballot(want);
         const unsigned int prefix = __builtin_amdgcn_mbcnt_hi((unsigned int)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)mask, 0u));
+        const unsigned int slot = reserve(0, (unsigned int)__popcll(mask)) + prefix;
         if (want) {
-            const unsigned int slot = m_c + prefix;
             co[slot] = make_float4(o.x, o.y, o.z, as_f((int)s));
             cd[slot] = make_float4(d.x, d.y, d.z, as_f(level | (int)(pending << 8)));
             ct[slot] = make_float4(T.x, T.y, T.z, 0.0f);
         }
-        m_c += (unsigned int)__popcll(mask);
+        return slot;
     }
 };
 
@@ -106,6 +136,17 @@ enum { POOL_SPEC_PENDING_BIT = 0x800000 };     // in a list entry's `pending` fi
 enum { POOL_PARKED_SHADOW_BLOCKS = 64 };         // k_pool_parked_shadows' fixed grid
 
 PRT_D void pool_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }
+// Between the phases of a round: what one phase wrote to the unit's lists (global memory, through the compute unit's own L1)
+// the next phase reads.  Wave-private pools: program order plus a fence.  Block-shared pools: a workgroup barrier as well -
+// and every condition around a call of this must be block-uniform.
+template <bool SHARED> PRT_D void pool_sync() {
+    if (SHARED) __syncthreads(); else pool_fence();
+}
+// LDS control words of a block-shared pool
+enum { PCTL_TRACE_NEXT = 0,      // rays of the trace phase handed out so far
+       PCTL_TOPUP_BASE = 1,      // the sample counter's value this top-up got
+       PCTL_CNT = 4,             // [2][4]: (closest, shadow, finalise, started-ahead) entries of the lists being filled, by parity of `cur`
+       PCTL_WORDS = 12 };
 
 // Everything the kernel is told, in device memory.  Passed by value these ~130 dwords are loaded into SGPRs at kernel
 // entry and stay live through every loop; the kernel then spills ~170 SGPRs into VGPR lanes and reloads them with
@@ -148,6 +189,7 @@ PRT_D PoolArgs pool_args(const PoolArgs * args) {
     A.Q.cq = as_global(A.Q.cq); A.Q.hits = as_global(A.Q.hits); A.Q.sq = as_global(A.Q.sq); A.Q.head = as_global(A.Q.head);
     A.Q.park = as_global(A.Q.park); A.Q.spark = as_global(A.Q.spark); A.Q.park_count = as_global(A.Q.park_count);
     A.Q.fin = as_global(A.Q.fin); A.Q.scratch = as_global(A.Q.scratch); A.Q.jobsum = as_global(A.Q.jobsum); A.Q.final_rgb = as_global(A.Q.final_rgb);
+    A.Q.wave_times = as_global(A.Q.wave_times);
     return A;
 }
 
@@ -164,13 +206,16 @@ template <int BLOCK> PRT_D void pool_stack_spill(LdsSpillStack<BLOCK> & stack, P
 // One launch prepares a whole render: dst[0] for the fast kernel, dst[1] - the same arguments with the park list as the
 // source of work - for the adopting EXACT launch behind it, and the render's counters (sample counter, park counts, the
 // adopting launch's counter) zeroed.
-__global__ void k_pool_store_args(PoolArgs a, PoolArgs * dst, unsigned int * zero, unsigned int n_zero, unsigned int * adopt_head) {
+__global__ void k_pool_store_args(PoolArgs a, PoolArgs * dst, unsigned int * zero, unsigned int n_zero, unsigned int * adopt_head,
+                                  unsigned int adopt_cap_div) {
     if (threadIdx.x < n_zero) zero[threadIdx.x] = 0u;
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         dst[0] = a;
         if (adopt_head) {
             a.Q.adopt = 1;
             a.Q.head = adopt_head;
+            a.Q.cap /= adopt_cap_div;             // the fast kernel's pools were block-shared: the adopting launch's are a wave's share of one
+            a.Q.scap /= adopt_cap_div;
             dst[1] = a;
         }
     }
@@ -180,17 +225,17 @@ __global__ void k_pool_store_args(PoolArgs a, PoolArgs * dst, unsigned int * zer
 // EXACT: the slow variant - stack columns that continue in global memory, near ties decided inside the traversal loop
 // (resolve_near_ties).  It runs as the adopting second launch of a render (PoolBuffers::park); the fast variant parks what
 // it cannot finish.
-template <int BLOCK, int WAVES, bool LDSTAB, bool RING, bool COUNT, bool TEX, bool ADAPT, int RINGMEM, bool EXACT>
+// SHARED: the workgroup, not the wave, owns a pool (see the head of this file); never together with EXACT.
+template <int BLOCK, int WAVES, bool LDSTAB, bool RING, bool COUNT, bool TEX, bool ADAPT, int RINGMEM, bool EXACT, bool SHARED>
 __global__ __launch_bounds__(BLOCK, WAVES) void k_pool(const PoolArgs * args, DevCounters * ctr) {
+    static_assert(!(SHARED && EXACT), "the adopting EXACT launch keeps wave-private pools");
     extern __shared__ int s_stack[];
     constexpr int LDS_MATS = 32, LDS_LIGHTS = 4;
     __shared__ float4 s_diffuse[LDSTAB ? 1024 : 1];
     __shared__ DevMaterial s_mats[LDS_MATS];
     __shared__ DevLight s_lights[LDS_LIGHTS];
     __shared__ unsigned long long s_red[2];
-#ifdef PRT_POOL_PREFETCH
-    __shared__ float4 s_pref[BLOCK / 64][2][64];     // experiment: the next 64 list entries of each wave, filled by LDS-direct loads
-#endif
+    __shared__ unsigned int s_ctl[SHARED ? PCTL_WORDS : 1];
     {
         const PoolArgs A0 = pool_args(args);
         const DevScene & sc = A0.sc;
@@ -207,22 +252,29 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_pool(const PoolArgs * args, De
         }
     }
     if (threadIdx.x < 2) s_red[threadIdx.x] = 0ull;
+    if (SHARED && threadIdx.x < (unsigned int)PCTL_WORDS) s_ctl[threadIdx.x] = 0u;
     __syncthreads();
 
     const unsigned int slot_id = blockIdx.x * BLOCK + threadIdx.x;
     const unsigned int lane = lane_id();
-    const unsigned int wave = (unsigned int)__builtin_amdgcn_readfirstlane((int)(slot_id >> 6));      // scalar: the list pointers stay in SGPRs
+    // the unit that owns the lists: this wave, or this workgroup.  Scalar: the list pointers stay in SGPRs
+    const unsigned int wave = SHARED ? blockIdx.x : (unsigned int)__builtin_amdgcn_readfirstlane((int)(slot_id >> 6));
+    constexpr unsigned int ULANES = SHARED ? (unsigned int)BLOCK : 64u;                            // lanes of a unit
+    const unsigned int ulane = SHARED ? threadIdx.x : lane;                                        // this lane's index in its unit
+    const bool lead_wave = !SHARED || (unsigned int)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) == 0u;   // adds the unit's counts
     typedef typename PoolStack<BLOCK, EXACT>::type Stack;
     Stack stack;
     stack.attach(s_stack, threadIdx.x);
     stack.cap = ((PoolArgsPtr)args)->P.stack_lds_entries;
     pool_stack_spill(stack, (PoolArgsPtr)args);
 
-    unsigned int n_f = 0;                      // wave-uniform (ADAPT): pixels waiting to be finalised
-    unsigned int n_spec = 0;                   // wave-uniform (ADAPT): of those, pixels whose next camera ray is already in the closest list
+    // the unit's state: wave-uniform, and with SHARED block-uniform - every wave of the block derives the same values from the
+    // same LDS words behind the same barriers, so that the barriers below are reached by all of them
+    unsigned int n_f = 0;                      // (ADAPT) pixels waiting to be finalised
+    unsigned int n_spec = 0;                   // (ADAPT) of those, pixels whose next camera ray is already in the closest list
     int cur = 0;
-    unsigned int n_c = 0, n_s = 0;             // wave-uniform: rays in the current closest / shadow list
-    bool fetch_done = false;                   // wave-uniform: the sample counter ran past n_samples
+    unsigned int n_c = 0, n_s = 0;             // rays in the current closest / shadow list
+    bool fetch_done = false;                   // the sample counter ran past n_samples
     unsigned long long rays = 0ull;            // wave-uniform
     unsigned int shaded_w = 0;                 // wave-uniform
     unsigned int elided_w = 0;                 // wave-uniform: shadow rays counted, not traced
@@ -244,6 +296,8 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_pool(const PoolArgs * args, De
 
     unsigned long long ph_topup = 0ull, ph_trace = 0ull, ph_shade = 0ull, ph_final = 0ull;      // COUNT: wave-cycles per phase
     const unsigned long long ph_begin = COUNT ? __builtin_readcyclecounter() : 0ull;
+    const unsigned long long wt_begin = COUNT ? wall_clock64() : 0ull;
+    unsigned long long wt_dry = 0ull;
     for (;;) {
         const unsigned long long ph_t0 = COUNT ? __builtin_readcyclecounter() : 0ull;
         // ---- top up: fresh samples into the free closest-hit slots ------------------------------------------
@@ -305,7 +359,12 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_pool(const PoolArgs * args, De
           } else if (n_c + n_f - n_spec + Q.topup_min <= cap) {
             const unsigned int want = cap - (n_c + n_f - n_spec);
             unsigned int base = 0;
-            if (lane == 0) base = atomicAdd(Q.head, want);
+            if (SHARED) {
+                if (threadIdx.x == 0) s_ctl[PCTL_TOPUP_BASE] = atomicAdd(Q.head, want);
+                __syncthreads();
+                base = s_ctl[PCTL_TOPUP_BASE];
+                __syncthreads();                                   // ... and nobody overwrites the word before every wave has read it
+            } else if (lane == 0) base = atomicAdd(Q.head, want);
             base = (unsigned int)__builtin_amdgcn_readfirstlane((int)base);
             if (base >= B.n_samples) {
                 fetch_done = true;
@@ -313,7 +372,7 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_pool(const PoolArgs * args, De
                 unsigned int cnt = B.n_samples - base;
                 if (cnt <= want) fetch_done = true; else cnt = want;
                 const DevCamera cam = A.cam;
-                for (unsigned int k = lane; k < cnt; k += 64u) {
+                for (unsigned int k = ulane; k < cnt; k += ULANES) {
                     const unsigned int sid = base + k;
                     const unsigned int gsid = B.sample_base + sid;
                     SampleState S;
@@ -339,13 +398,14 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_pool(const PoolArgs * args, De
             }
           }
         }
+        if (COUNT && fetch_done && wt_dry == 0ull) wt_dry = wall_clock64();
         const unsigned int total = n_c + n_s;
         if (total == 0u && n_f == 0u) {
             if (fetch_done) break;
             continue;
         }
-        pool_fence();
-        rays += total;                                                     // debug->ray_count++  raytracer.cpp:161
+        pool_sync<SHARED>();
+        if (lead_wave) rays += total;                                      // debug->ray_count++  raytracer.cpp:161
         const unsigned long long ph_t1 = COUNT ? __builtin_readcyclecounter() : 0ull;
 
         // ---- trace: every ray of the pool ------------------------------------------------------------------
@@ -362,67 +422,35 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_pool(const PoolArgs * args, De
             int ray = -1;
             float4 payload = make_float4(0, 0, 0, 0);
             int sample = 0;
-            unsigned int next = 0;                                         // wave-uniform: rays handed out so far
-#ifdef PRT_POOL_PREFETCH
-            // Experiment (profiles/r02_experiments.txt): the next 64 list entries travel to LDS by LDS-direct loads
-            // (global_load_lds_dwordx4: no registers, nobody waits) while the wave traverses; a refill then reads LDS.
-            float4 * const pfA = &s_pref[threadIdx.x >> 6][0][0];
-            float4 * const pfB = &s_pref[threadIdx.x >> 6][1][0];
-            unsigned int win_base = 0, win_cnt = 0;                        // wave-uniform: entries [win_base, win_base + win_cnt) are in the window
-            auto prefetch = [&](unsigned int base) {
-                const unsigned int cnt = total - base < 64u ? total - base : 64u;
-                const unsigned int idx = base + lane;
-                if (lane < cnt) {
-                    const float4 * a = idx < n_c ? co + idx : sq_o + (idx - n_c);
-                    const float4 * b = idx < n_c ? cd + idx : sq_c + (idx - n_c);
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)a, (__attribute__((address_space(3))) void *)pfA, 16, 0, 0);
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)b, (__attribute__((address_space(3))) void *)pfB, 16, 0, 0);
-                }
-                win_base = base;
-                win_cnt = cnt;
-            };
-            if (total) prefetch(0u);
-#endif
+            unsigned int next = 0;                                         // wave-uniform: rays handed out so far (SHARED: where this wave's last refill began)
+            bool dry = total == 0u;                                        // wave-uniform: the list has no ray left to hand out
             for (;;) {
                 const unsigned long long idle = __ballot(ray < 0);
-                if (idle != 0ull && next < total) {
+                if (idle != 0ull && !dry) {
                     if (COUNT && lane == 0) st.wrefills++;
-#ifdef PRT_POOL_PREFETCH
-                    const unsigned int avail = win_base + win_cnt - next;                      // what is left of the window
-#else
-                    const unsigned int avail = total - next;
-#endif
                     const unsigned int prefix = __builtin_amdgcn_mbcnt_hi((unsigned int)(idle >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)idle, 0u));
                     const unsigned int n_idle = (unsigned int)__popcll(idle);
+                    if (SHARED) {
+                        // the block's list: this wave's idle lanes claim the next n_idle entries (the counter may run past the end)
+                        unsigned int b = 0;
+                        if (lane == 0) b = atomicAdd(&s_ctl[PCTL_TRACE_NEXT], n_idle);
+                        next = (unsigned int)__builtin_amdgcn_readfirstlane((int)b);
+                        if (next > total) next = total;
+                    }
+                    const unsigned int avail = total - next;
                     const unsigned int take = n_idle < avail ? n_idle : avail;
-#ifdef PRT_POOL_PREFETCH
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                            // the window has landed
-#endif
                     if (ray < 0 && prefix < take) {
                         const unsigned int idx = next + prefix;
                         float4 ro, rd;
                         int kind;
-#ifdef PRT_POOL_PREFETCH
-                        const float4 e0 = pfA[idx - win_base], e1 = pfB[idx - win_base];
-#endif
                         if (idx < n_c) {
-#ifdef PRT_POOL_PREFETCH
-                            ro = e0;
-                            rd = e1;
-#else
                             ro = co[idx];
                             rd = cd[idx];
-#endif
                             kind = WF_KIND_CLOSEST;
                         } else {
                             const unsigned int j = idx - n_c;
-#ifdef PRT_POOL_PREFETCH
-                            ro = e0;
-                            payload = e1;
-#else
                             ro = sq_o[j];
                             payload = sq_c[j];
-#endif
                             if (payload.w < 0.0f) {          // directional light: the direction is a per-light constant
                                 const DevLight & L = lights[(unsigned int)(-payload.w) - 1u];
                                 const f3 lv = mk3(L.facing[0], L.facing[1], L.facing[2]) * -1.0f;   // raytracer.cpp:240
@@ -440,13 +468,11 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_pool(const PoolArgs * args, De
                         ray = (int)idx;
                     }
                     next += take;
-#ifdef PRT_POOL_PREFETCH
-                    if (next == win_base + win_cnt && next < total) prefetch(next);             // the window is used up: fetch the next one
-#endif
+                    dry = next == total;
                 }
                 if (__ballot(ray >= 0) == 0ull) break;
 
-                const int leave_below = next == total ? 1 : keep_min;
+                const int leave_below = dry ? 1 : keep_min;
                 while (ray >= 0) {
                     const int walkers = __popcll(__ballot(trav_walking(r)));
                     const int wfrac = (walkers * node_frac) >> 3;
@@ -507,7 +533,7 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_pool(const PoolArgs * args, De
                 }
             }
         }
-        pool_fence();
+        pool_sync<SHARED>();
         const unsigned long long ph_t2 = COUNT ? __builtin_readcyclecounter() : 0ull;
 
         // ---- shade: every closest hit of the pool, 64 per pass ----------------------------------------------
@@ -524,13 +550,23 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_pool(const PoolArgs * args, De
             tb.materials = sc.material_count <= (unsigned int)LDS_MATS ? s_mats : sc.materials;
             tb.lights = sc.light_count <= (unsigned int)LDS_LIGHTS ? s_lights : sc.lights;
             const int nxt = cur ^ 1;
-            PoolEmit<ADAPT> emit;
+            PoolEmit<ADAPT, SHARED> emit;
             emit.co = cq_base + (size_t)nxt * 3u * cap;
             emit.cd = emit.co + cap;
             emit.ct = emit.cd + cap;
             emit.so = sq_o; emit.sc = sq_c; emit.sd = sq_d;
             emit.fin = fin;
             emit.m_c = 0; emit.m_s = 0; emit.m_f = 0; emit.m_elided = 0;
+            // block-shared: the fill counts of the lists this phase writes live in LDS, one set per parity of `cur`; this set was
+            // zeroed a round ago (below), the other one - read by every wave at the end of the previous round - is zeroed now,
+            // and so is the trace phase's hand-out counter (the barrier behind the trace phase has passed)
+            emit.s_cnt = SHARED ? &s_ctl[PCTL_CNT + 4 * nxt] : nullptr;
+            if (SHARED && threadIdx.x < 4u) {
+                s_ctl[PCTL_CNT + 4 * cur + threadIdx.x] = 0u;
+                if (threadIdx.x == 0) s_ctl[PCTL_TRACE_NEXT] = 0u;
+            }
+            // the unit's list entries are shaded 64 at a time; a block-shared list by the block's waves in turn
+            const unsigned int b_first = SHARED ? (threadIdx.x >> 6) * 64u : 0u;
             if (ADAPT) {
                 // ---- finalise: pixels whose sample ended one round ago; its last shadow rays have landed by now.
                 // RenderPixel's loops (main.cpp:236-258) one step at a time: store the sample, apply the stopping rule,
@@ -540,7 +576,7 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_pool(const PoolArgs * args, De
                 float4 * const scratch = Q.scratch;
 #define POOL_SCRATCH_AT(k, j) ((size_t)(j) * P.max_spp + (k))
                 const unsigned long long ph_f0 = COUNT ? __builtin_readcyclecounter() : 0ull;
-                for (unsigned int b0 = 0; b0 < n_f; b0 += 64u) {
+                for (unsigned int b0 = b_first; b0 < n_f; b0 += ULANES) {
                     const unsigned int i = b0 + lane;
                     const bool live = i < n_f;
                     bool go_on = false;
@@ -667,10 +703,10 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_pool(const PoolArgs * args, De
                     emit.closest(go_on, j, ray_o, ray_d, mk3(1.0f, 1.0f, 1.0f), 0, (unsigned int)WF_PENDING_FRESH_BIT, false);
                 }
                 emit.m_f = 0;                                                       // the list is consumed; shading refills it from 0
-                pool_fence();
+                pool_sync<SHARED>();                                                // (block-shared: by every wave, before any wave refills it)
                 if (COUNT) ph_final += __builtin_readcyclecounter() - ph_f0;
             }
-            for (unsigned int b0 = 0; b0 < n_c; b0 += 64u) {
+            for (unsigned int b0 = b_first; b0 < n_c; b0 += ULANES) {
                 const unsigned int i = b0 + lane;
                 const bool live = i < n_c;
                 unsigned int s = 0;
@@ -709,10 +745,10 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_pool(const PoolArgs * args, De
                 // max_spp - 1 only the variance rule can end the pixel, and it rarely does.  So the jitter is drawn now (the
                 // RNG state is final when a sample ends: shadow rays draw nothing) and the ray joins the list, marked; the
                 // finalise step calls it off if the pixel ends, and a called-off ray is not shaded and not counted.
-                pool_fence();
-                const unsigned int ended = emit.m_f;
+                pool_sync<SHARED>();
+                const unsigned int ended = SHARED ? emit.s_cnt[2] : emit.m_f;
                 unsigned int started = 0;
-                for (unsigned int b0 = 0; b0 < ended; b0 += 64u) {
+                for (unsigned int b0 = b_first; b0 < ended; b0 += ULANES) {
                     const unsigned int i = b0 + lane;
                     bool go = false;
                     unsigned int j = 0;
@@ -741,24 +777,30 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_pool(const PoolArgs * args, De
                         }
                     }
                     const unsigned long long m = __ballot(go);
+                    const unsigned int slot = emit.closest(go, j, ray_o, ray_d, mk3(1.0f, 1.0f, 1.0f), 0, (unsigned int)POOL_SPEC_PENDING_BIT | (unsigned int)WF_PENDING_FRESH_BIT, false);
                     if (go) {
-                        const unsigned int slot = emit.m_c + __builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m, 0u));
                         Q.final_rgb[j] = make_float4(off_x, off_y, as_f((int)slot), 0.0f);
                         Q.jobsum[j].w = as_f(as_i(Q.jobsum[j].w) | POOL_JOB_SPEC_FLYING);
                     }
-                    emit.closest(go, j, ray_o, ray_d, mk3(1.0f, 1.0f, 1.0f), 0, (unsigned int)POOL_SPEC_PENDING_BIT | (unsigned int)WF_PENDING_FRESH_BIT, false);
                     started += (unsigned int)__popcll(m);
                 }
-                n_spec = started;
+                if (SHARED) { if (started && lane == 0) atomicAdd(&emit.s_cnt[3], started); }
+                else n_spec = started;
             }
             rays += emit.m_elided;                                             // counted as the reference counts them (raytracer.cpp:161)
             elided_w += emit.m_elided;
-            n_c = emit.m_c;
-            n_s = emit.m_s;
-            n_f = emit.m_f;
+            if (SHARED) {
+                __syncthreads();                                               // every wave's appends are counted
+                n_c = emit.s_cnt[0]; n_s = emit.s_cnt[1]; n_f = emit.s_cnt[2];
+                if (ADAPT) n_spec = emit.s_cnt[3];
+            } else {
+                n_c = emit.m_c;
+                n_s = emit.m_s;
+                n_f = emit.m_f;
+            }
             cur = nxt;
         }
-        pool_fence();
+        if (!SHARED) pool_fence();
         if (COUNT) {
             const unsigned long long ph_t3 = __builtin_readcyclecounter();
             ph_topup += ph_t1 - ph_t0; ph_trace += ph_t2 - ph_t1; ph_shade += ph_t3 - ph_t2;
@@ -793,6 +835,11 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_pool(const PoolArgs * args, De
             const unsigned long long ph_all = __builtin_readcyclecounter() - ph_begin;
             atomicAdd(&ctr->phase_cycles[3], ph_all);
             if (!EXACT) {
+                unsigned long long * const wt = ((PoolArgsPtr)args)->Q.wave_times;
+                if (wt) {
+                    unsigned long long * const w3 = as_global(wt) + 3u * (size_t)(slot_id >> 6);
+                    w3[0] = wt_begin; w3[1] = wt_dry; w3[2] = wall_clock64();
+                }
                 atomicMax(&ctr->wave_cycles_max, ph_all);
                 atomicAdd(&ctr->wave_cycles_sum, ph_all);
                 atomicAdd(&ctr->wave_count, 1ull);
@@ -817,6 +864,10 @@ __global__ __launch_bounds__(256) void k_pool_parked_shadows(const PoolArgs * ar
     if (gid == 0) {
         atomicMax(&ctr->park_peak[0], (unsigned long long)A.Q.park_count[0]);
         atomicMax(&ctr->park_peak[1], (unsigned long long)A.Q.park_count[1]);
+        // decided HERE, per launch, against the capacities this launch's lists really have (a later pass of the same call may
+        // have shorter ones: its clamp is its own worst case)
+        if (A.Q.park_count[0] > A.Q.park_cap) atomicMax(&ctr->park_over[0], (unsigned long long)A.Q.park_count[0]);
+        if (A.Q.park_count[1] > A.Q.spark_cap) atomicMax(&ctr->park_over[1], (unsigned long long)A.Q.park_count[1]);
     }
     TraceStats st;
     st.nodes = st.tris = st.wnodes = st.wleaves = st.wtris = st.wrefills = st.wrays = st.max_sp = st.culled = 0;

@@ -11,6 +11,10 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <condition_variable>
+#include <mutex>
+#include <new>
+#include <stdexcept>
 #include <string>
 #include <thread>
 #include <vector>
@@ -36,6 +40,12 @@ using namespace prt;
 #ifndef PRT_ADAPT_WAVES
 #define PRT_ADAPT_WAVES 4         // waves per SIMD of the untextured adaptive kernel (128 VGPRs)
 #endif
+#ifndef PRT_POOL_SHARED_DEFAULT
+#define PRT_POOL_SHARED_DEFAULT 1 // block-shared pools (kernels_pool.h) for fixed-spp renders when the option POOL_SHARED is not set
+#endif
+#ifndef PRT_POOL_BLOCK
+#define PRT_POOL_BLOCK 256        // threads per workgroup of the fixed-spp pool kernel (experiments: 320, 640 with block-shared pools)
+#endif
 #ifndef PRT_POOL_WAVES
 #define PRT_POOL_WAVES 5          // waves per SIMD of the fixed-spp pool kernel: 96 VGPRs (6 = 80 VGPRs spills, profiles/r03_ab_bvh8.txt)
 #endif
@@ -44,12 +54,10 @@ using namespace prt;
 // of round 3.
 #if !defined(PRT_BVH8)
 typedef Bvh4Result BvhWide;
-static const int kBvhNodeDwords = 16;
 #define PRT_BUILD_WIDE build_bvh4q
 #define PRT_BUILD_WIDE_FROM_RADIX build_bvh4q_from_radix_tree
 #else
 typedef Bvh8Result BvhWide;
-static const int kBvhNodeDwords = BVH8_NODE_DWORDS;
 #define PRT_BUILD_WIDE build_bvh8q
 #define PRT_BUILD_WIDE_FROM_RADIX build_bvh8q_from_radix_tree
 #endif
@@ -71,9 +79,12 @@ template <typename T>
 struct DevBuf {
     T * p = nullptr;
     size_t n = 0;
+    bool borrowed = false;               // p belongs to another DevBuf (clone_context: the scene arrays of the context cloned)
+    void borrow(const DevBuf & o) { release(); p = o.p; n = o.n; borrowed = o.p != nullptr; }
     hipError_t ensure(size_t count) {
         if (count <= n && p) return hipSuccess;
-        if (p) (void)hipFree(p);
+        if (p && !borrowed) (void)hipFree(p);
+        borrowed = false;
         p = nullptr;
         n = 0;
         hipError_t e = hipMalloc((void **)&p, std::max<size_t>(count, 1) * sizeof(T));
@@ -86,7 +97,8 @@ struct DevBuf {
         return hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
     }
     void release() {
-        if (p) (void)hipFree(p);
+        if (p && !borrowed) (void)hipFree(p);
+        borrowed = false;
         p = nullptr;
         n = 0;
     }
@@ -151,9 +163,11 @@ struct prt_ctx {
     prt_render_stats last_stats;          // of the last render call (prt_get_render_stats)
     DevBuf<float4> pool_park;             // pool pipeline: rays parked for the slow launches (kernels_pool.h PoolBuffers::park)
     size_t pool_park_cap = 1u << 18, pool_spark_cap = 1u << 18;     // entries; enlarged when a frame needed more (render_pixels)
-    size_t park_cap_used = 0, spark_cap_used = 0;                     // what the last launch_pool really gave its lists (<= the worst case)
+    DevCounters * host_counters = nullptr;                            // pinned: the render's counters arrive here on the context's stream
     DevBuf<unsigned int> pool_fin;        // adaptive mode: per-wave lists of pixels to finalise
     DevBuf<PoolArgs> pool_args;           // k_pool's arguments (read per phase from memory, kernels_pool.h)
+    DevBuf<unsigned long long> wave_times;  // DEBUG_UTIL + counting render: (start, counter dry, exit) wall clock of every wave of the fast kernel
+    unsigned int wave_times_n = 0;
     DevBuf<float4> adapt_f4;              // adaptive mode: scratch [max_spp][n] + running sums [n] + final colours [n]
     int cu_count = 0;                     // compute units this context may fill (all of the device's minus PRT_RESERVE_CUS)
     int reserved_cus = 0;
@@ -512,9 +526,9 @@ int render_wavefront(prt_ctx * ctx, const DevCamera & cam, const DevParams & P, 
 // workspace, without the global queues), plus cap (+ cap * lights shadow) ray slots per resident wave.
 // RINGMEM = 0: no sample can make more than 15 RNG draws (and the scene is opaque, untextured, fixed spp): the
 // general-RNG variant runs without its draw ring in memory (dev_rng.h).
-template <int BLOCK, int WAVES, bool LDSTAB, bool RING, bool COUNT, bool TEX, bool ADAPT, int RINGMEM, bool EXACT>
+template <int BLOCK, int WAVES, bool LDSTAB, bool RING, bool COUNT, bool TEX, bool ADAPT, int RINGMEM, bool EXACT, bool SHARED = false>
 int launch_pool_kernel(prt_ctx * ctx, unsigned int grid, size_t lds, const PoolArgs * d_args) {
-    hipLaunchKernelGGL((k_pool<BLOCK, WAVES, LDSTAB, RING, COUNT, TEX, ADAPT, RINGMEM, EXACT>), dim3(grid), dim3(BLOCK), lds, ctx->stream, d_args, ctx->counters.p);
+    hipLaunchKernelGGL((k_pool<BLOCK, WAVES, LDSTAB, RING, COUNT, TEX, ADAPT, RINGMEM, EXACT, SHARED>), dim3(grid), dim3(BLOCK), lds, ctx->stream, d_args, ctx->counters.p);
     HIP_TRY(ctx, hipGetLastError());       // a template variant that cannot launch (LDS, registers) is reported here, by name of its cause
     return 0;
 }
@@ -530,9 +544,16 @@ int launch_pool(prt_ctx * ctx, bool count, const DevCamera & cam, DevParams P, u
     // Option POOL_EXACT (tests): the EXACT kernel does the whole render.
     const bool exact_only = opt.pool_exact != 0;
     int per_cu = 0;
-    hipError_t oe = exact_only ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_pool<BLOCK, WAVES, LDSTAB, RING, false, TEX, ADAPT, RINGMEM, true>, BLOCK, lds)
-                  : count      ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_pool<BLOCK, WAVES, LDSTAB, RING, true, TEX, ADAPT, RINGMEM, false>, BLOCK, lds)
-                               : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_pool<BLOCK, WAVES, LDSTAB, RING, false, TEX, ADAPT, RINGMEM, false>, BLOCK, lds);
+    // Block-shared pools (kernels_pool.h, round 4): the workgroup owns a pool, not the wave.  Option POOL_SHARED: 1 / 0 force it
+    // on / off; the EXACT kernels (the adopting launch, POOL_EXACT) always keep wave-private pools.
+    // Default (profiles/r04_ab_shared_pools.txt, same-process A/B): ON for fixed spp - the full C4 frame 1.5 - 2 % faster, its
+    // 1/2 .. 1/16 shards 1.5 - 3.5 % -, OFF for the adaptive mode, whose short rounds lose 11 % to the four waves waiting for
+    // each other at every phase boundary.
+    const bool shared = !exact_only && (opt.pool_shared >= 0 ? opt.pool_shared != 0 : (PRT_POOL_SHARED_DEFAULT != 0 && !ADAPT));
+    hipError_t oe = exact_only ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_pool<BLOCK, WAVES, LDSTAB, RING, false, TEX, ADAPT, RINGMEM, true, false>, BLOCK, lds)
+                  : shared     ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_pool<BLOCK, WAVES, LDSTAB, RING, false, TEX, ADAPT, RINGMEM, false, true>, BLOCK, lds)
+                  : count      ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_pool<BLOCK, WAVES, LDSTAB, RING, true, TEX, ADAPT, RINGMEM, false, false>, BLOCK, lds)
+                               : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_pool<BLOCK, WAVES, LDSTAB, RING, false, TEX, ADAPT, RINGMEM, false, false>, BLOCK, lds);
     if (oe != hipSuccess || per_cu < 1) per_cu = 1;
     per_cu = std::min(per_cu, 8);
     if (opt.pool_blocks_per_cu >= 0) per_cu = std::max(1, std::min(per_cu, (int)opt.pool_blocks_per_cu));
@@ -545,12 +566,16 @@ int launch_pool(prt_ctx * ctx, bool count, const DevCamera & cam, DevParams P, u
     // waves, 64..512
     unsigned int cap = (n_samples / waves / 2u + 63u) / 64u * 64u;
     cap = std::max(64u, std::min(512u, cap));
+    if (shared && opt.pool_shared_cap >= 0) cap = (unsigned int)std::max(64ll, std::min(1024ll, opt.pool_shared_cap / 64 * 64));
     // adaptive mode: a pixel stays in its pool for all its samples (up to 50 x several rounds), so what a wave takes it keeps;
     // smaller pools leave more of the frame on the counter for the waves whose pixels end early (C4: 512 slots 195 ms,
     // 256 168 ms, 64 - 192 161 - 164 ms, profiles/r02_adaptive_pool_capacity.txt; round 3, once the variance rule no longer
     // walks the stored samples: 512 160, 256 145, 192 133 - 138, 128 129 - 133, 64 138 ms, profiles/r03_adaptive.txt)
     if (ADAPT) cap = std::min(cap, 128u);
     if (opt.pool_cap >= 0) cap = (unsigned int)std::max(64ll, std::min(4096ll, opt.pool_cap / 64 * 64));
+    // block-shared: the same slots, owned by the block's waves together (`cap` is per UNIT from here on)
+    const unsigned int units = shared ? grid : waves;
+    if (shared) cap *= (unsigned int)(BLOCK / 64);
     const unsigned int n_lights = std::max(1u, ctx->scene.light_count);
     const unsigned int scap = cap * n_lights;
 
@@ -560,7 +585,7 @@ int launch_pool(prt_ctx * ctx, bool count, const DevCamera & cam, DevParams P, u
     const unsigned int fr4 = TEX ? 7u : (RING && RINGMEM == 1) ? 5u : 4u;       // kernels_wave.h wframe_save
     HIP_TRY(ctx, w.f4.ensure((size_t)levels * fr4 * N));
     HIP_TRY(ctx, w.rng.ensure(RING ? 2 * N : N));
-    HIP_TRY(ctx, ctx->pool_f4.ensure((size_t)waves * (7u * (size_t)cap + 3u * (size_t)scap)));
+    HIP_TRY(ctx, ctx->pool_f4.ensure((size_t)units * (7u * (size_t)cap + 3u * (size_t)scap)));
     // [0] sample counter, [1] parked closest-hit / finalise entries, [2] parked shadow rays, [3] the adopting launch's counter
     HIP_TRY(ctx, ctx->wf_counts.ensure(16));          // zeroed by k_pool_store_args below
     // Park lists: sized for what scenes with coincident geometry need in practice, never for the worst case (every sample's
@@ -576,8 +601,6 @@ int launch_pool(prt_ctx * ctx, bool count, const DevCamera & cam, DevParams P, u
     }
     const size_t worst_spark = N * n_lights * std::min<size_t>(hits_per_sample, 1u << 20);
     const size_t park_cap = std::min<size_t>(ctx->pool_park_cap, N + (ADAPT ? N : 0)), spark_cap = std::min<size_t>(ctx->pool_spark_cap, worst_spark);
-    ctx->park_cap_used = park_cap;
-    ctx->spark_cap_used = spark_cap;
     HIP_TRY(ctx, ctx->pool_park.ensure(3 * (park_cap + spark_cap)));
     // the EXACT launch's lanes continue their LDS stack columns in memory; k_pool_parked_shadows has full-height columns
     const unsigned int grid2 = exact_only ? grid : std::max(1u, std::min(grid, (unsigned int)ctx->cu_count));
@@ -604,8 +627,8 @@ int launch_pool(prt_ctx * ctx, bool count, const DevCamera & cam, DevParams P, u
     PoolBuffers Q;
     memset(&Q, 0, sizeof(Q));
     Q.cq = ctx->pool_f4.p;
-    Q.hits = Q.cq + (size_t)waves * 6u * cap;
-    Q.sq = Q.hits + (size_t)waves * cap;
+    Q.hits = Q.cq + (size_t)units * 6u * cap;
+    Q.sq = Q.hits + (size_t)units * cap;
     Q.head = ctx->wf_counts.p;
     Q.cap = cap;
     Q.scap = scap;
@@ -616,9 +639,16 @@ int launch_pool(prt_ctx * ctx, bool count, const DevCamera & cam, DevParams P, u
     Q.spark_cap = (unsigned int)spark_cap;
     Q.adopt = 0;
     Q.fin = nullptr; Q.scratch = nullptr; Q.jobsum = nullptr; Q.final_rgb = nullptr;
+    Q.wave_times = nullptr;
+    ctx->wave_times_n = 0;
+    if (count && opt.debug_util && !exact_only) {
+        HIP_TRY(ctx, ctx->wave_times.ensure(3u * (size_t)waves));
+        Q.wave_times = ctx->wave_times.p;
+        ctx->wave_times_n = waves;
+    }
     if (ADAPT) {
         // n_samples counts PIXELS here: the unit in the pool is a pixel that runs its samples one after the other
-        HIP_TRY(ctx, ctx->pool_fin.ensure((size_t)waves * cap));
+        HIP_TRY(ctx, ctx->pool_fin.ensure((size_t)units * cap));
         HIP_TRY(ctx, ctx->adapt_f4.ensure(((size_t)P.max_spp + 2u) * N));
         Q.fin = ctx->pool_fin.p;
         Q.scratch = ctx->adapt_f4.p;
@@ -626,7 +656,7 @@ int launch_pool(prt_ctx * ctx, bool count, const DevCamera & cam, DevParams P, u
         Q.final_rgb = Q.jobsum + N;
     }
     Q.topup_min = ADAPT ? std::max(64u, cap / 2u) : std::max(64u, cap / 4u);
-    if (opt.pool_topup >= 0) Q.topup_min = (unsigned int)std::max(1ll, std::min((long long)cap, opt.pool_topup));
+    if (opt.pool_topup >= 0) Q.topup_min = (unsigned int)std::max(1ll, std::min((long long)cap, opt.pool_topup * (shared ? BLOCK / 64 : 1)));   // the option counts per wave
     int keep_min = 40, node_min = 32;
     if (opt.keep_min >= 0) keep_min = std::max(1, std::min(64, (int)opt.keep_min));
     if (opt.node_min >= 0) node_min = std::max(0, std::min(64, (int)opt.node_min));
@@ -644,16 +674,22 @@ int launch_pool(prt_ctx * ctx, bool count, const DevCamera & cam, DevParams P, u
     if (opt.node_frac >= 0) A.node_frac = std::max(0, std::min(8, (int)opt.node_frac));
     A.multi_light = multi_light;
     HIP_TRY(ctx, ctx->pool_args.ensure(2));
+    // the adopting launch's units are waves whatever the fast kernel's were: a quarter of a shared pool's slots each, in the
+    // same buffers (grid2 <= grid, so its waves' lists fit where the blocks' lists lie)
     hipLaunchKernelGGL(k_pool_store_args, dim3(1), dim3(64), 0, ctx->stream, A, ctx->pool_args.p, ctx->wf_counts.p, 16u,
-                       exact_only ? (unsigned int *)nullptr : ctx->wf_counts.p + 3);
+                       exact_only ? (unsigned int *)nullptr : ctx->wf_counts.p + 3, shared ? (unsigned int)(BLOCK / 64) : 1u);
     HIP_TRY(ctx, hipGetLastError());
     int rc;
     if (exact_only) {
         return count ? launch_pool_kernel<BLOCK, WAVES, LDSTAB, RING, true, TEX, ADAPT, RINGMEM, true>(ctx, grid, lds, ctx->pool_args.p)
                      : launch_pool_kernel<BLOCK, WAVES, LDSTAB, RING, false, TEX, ADAPT, RINGMEM, true>(ctx, grid, lds, ctx->pool_args.p);
     }
-    rc = count ? launch_pool_kernel<BLOCK, WAVES, LDSTAB, RING, true, TEX, ADAPT, RINGMEM, false>(ctx, grid, lds, ctx->pool_args.p)
-               : launch_pool_kernel<BLOCK, WAVES, LDSTAB, RING, false, TEX, ADAPT, RINGMEM, false>(ctx, grid, lds, ctx->pool_args.p);
+    if (shared)
+        rc = count ? launch_pool_kernel<BLOCK, WAVES, LDSTAB, RING, true, TEX, ADAPT, RINGMEM, false, true>(ctx, grid, lds, ctx->pool_args.p)
+                   : launch_pool_kernel<BLOCK, WAVES, LDSTAB, RING, false, TEX, ADAPT, RINGMEM, false, true>(ctx, grid, lds, ctx->pool_args.p);
+    else
+        rc = count ? launch_pool_kernel<BLOCK, WAVES, LDSTAB, RING, true, TEX, ADAPT, RINGMEM, false>(ctx, grid, lds, ctx->pool_args.p)
+                   : launch_pool_kernel<BLOCK, WAVES, LDSTAB, RING, false, TEX, ADAPT, RINGMEM, false>(ctx, grid, lds, ctx->pool_args.p);
     if (rc) return rc;
     if (count) hipLaunchKernelGGL(k_pool_parked_shadows<true>, dim3(POOL_PARKED_SHADOW_BLOCKS), dim3(256), 0, ctx->stream, ctx->pool_args.p, ctx->counters.p);
     else hipLaunchKernelGGL(k_pool_parked_shadows<false>, dim3(POOL_PARKED_SHADOW_BLOCKS), dim3(256), 0, ctx->stream, ctx->pool_args.p, ctx->counters.p);
@@ -770,7 +806,9 @@ int render_pixels_once(prt_ctx * ctx, const prt_camera * cam_in, const prt_param
     // the compact 2-register RNG only covers opaque scenes with <= 15 draws per sample; textured scenes always take the
     // general variant (an alpha map can make any hit translucent)
     const bool ring = adaptive || ctx->any_translucent || ctx->textured || max_rng_draws(P.bounce_depth, P.reflection_samples, P.spec_samples) > 15;
+#if defined(PRT_EXPERIMENTAL)
     const int levels = (int)P.bounce_depth + 1;
+#endif
 
     unsigned int pipeline = params->pipeline & PRT_PIPELINE_MASK;
     if (adaptive) {
@@ -976,8 +1014,8 @@ int render_pixels_once(prt_ctx * ctx, const prt_camera * cam_in, const prt_param
                             : launch_pool<256, PRT_ADAPT_WAVES, false, true, false, true, 1>(ctx, count_visits, cam, P, n_samples, stack_entries);
             else
                 rc = ctx->textured ? launch_pool<256, 4, false, true, true, false>(ctx, count_visits, cam, P, n_samples, stack_entries)
-                   : !ring ? launch_pool<256, PRT_POOL_WAVES, false, true, false, false, 0>(ctx, count_visits, cam, P, n_samples, stack_entries)
-                           : launch_pool<256, PRT_POOL_WAVES, false, true, false, false, 1>(ctx, count_visits, cam, P, n_samples, stack_entries);
+                   : !ring ? launch_pool<PRT_POOL_BLOCK, PRT_POOL_WAVES, false, true, false, false, 0>(ctx, count_visits, cam, P, n_samples, stack_entries)
+                           : launch_pool<PRT_POOL_BLOCK, PRT_POOL_WAVES, false, true, false, false, 1>(ctx, count_visits, cam, P, n_samples, stack_entries);
             launches += 1;
         } else {
             unsigned long long rays = 0;
@@ -1008,20 +1046,23 @@ int render_pixels_once(prt_ctx * ctx, const prt_camera * cam_in, const prt_param
             trace_ms_accum += tms;
         }
     }
+    // the counters travel on the context's own stream into pinned memory, in front of the event the host waits for: no
+    // synchronous copy through the null stream, which CU-masked (blocking) streams of other contexts would be ordered against
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->host_counters, ctx->counters.p, sizeof(DevCounters), hipMemcpyDeviceToHost, stream));
     HIP_TRY(ctx, hipEventRecord(ctx->ev[1], stream));
     HIP_TRY(ctx, hipEventSynchronize(ctx->ev[1]));
 
     *park_overflow = false;
-    DevCounters h;
-    HIP_TRY(ctx, hipMemcpy(&h, ctx->counters.p, sizeof(h), hipMemcpyDeviceToHost));
-    if (pipeline == PRT_PIPELINE_POOL && (h.park_peak[0] > ctx->park_cap_used || h.park_peak[1] > ctx->spark_cap_used)) {
-        // a park list was too short for this frame (kernels_pool.h PoolBuffers::park): rays were dropped.  Longer lists, then
-        // the caller renders the frame again.  The peaks are compared with what launch_pool really gave the lists - the
-        // context's capacity clamped to the frame's worst case - so a peak above them always finds room the next time.
-        if (opt.debug_util) fprintf(stderr, "[prt] park lists too short (%llu of %zu rays, %llu of %zu shadow rays): enlarging\n",
-                                    (unsigned long long)h.park_peak[0], ctx->park_cap_used, (unsigned long long)h.park_peak[1], ctx->spark_cap_used);
-        ctx->pool_park_cap = std::max<size_t>(ctx->pool_park_cap, (size_t)h.park_peak[0] + (size_t)h.park_peak[0] / 2);
-        ctx->pool_spark_cap = std::max<size_t>(ctx->pool_spark_cap, (size_t)h.park_peak[1] + (size_t)h.park_peak[1] / 2);
+    DevCounters h = *ctx->host_counters;
+    if (pipeline == PRT_PIPELINE_POOL && (h.park_over[0] || h.park_over[1])) {
+        // a park list was too short for one of this call's launches (kernels_pool.h PoolBuffers::park): rays were dropped.  The
+        // device decided that per launch, against the capacity that launch's lists had (every pass clamps them to its own
+        // worst case).  Longer lists, then the caller renders the frame again: a capacity above the largest demand seen is
+        // above every pass's demand, and a pass whose clamp is smaller than that cannot want more than its clamp.
+        if (opt.debug_util) fprintf(stderr, "[prt] park lists too short (a pass wanted %llu ray / %llu shadow-ray entries): enlarging\n",
+                                    (unsigned long long)h.park_over[0], (unsigned long long)h.park_over[1]);
+        ctx->pool_park_cap = std::max<size_t>(ctx->pool_park_cap, (size_t)h.park_over[0] + (size_t)h.park_over[0] / 2);
+        ctx->pool_spark_cap = std::max<size_t>(ctx->pool_spark_cap, (size_t)h.park_over[1] + (size_t)h.park_over[1] / 2);
         *park_overflow = true;
         return 0;
     }
@@ -1070,6 +1111,24 @@ int render_pixels_once(prt_ctx * ctx, const prt_camera * cam_in, const prt_param
             fprintf(stderr, "[prt] k_pool waves: %llu, main loop mean %.3f of the longest wave's (what the others idle at the end of the frame: %.1f%%)\n",
                     (unsigned long long)h.wave_count, (double)h.wave_cycles_sum / (double)h.wave_count / (double)h.wave_cycles_max,
                     100.0 * (1.0 - (double)h.wave_cycles_sum / (double)h.wave_count / (double)h.wave_cycles_max));
+        if (opt.debug_util && ctx->wave_times_n && pipeline == PRT_PIPELINE_POOL) {
+            // where the end of the frame goes: every wave's (start, sample counter dry, exit) on the 100 MHz wall clock
+            std::vector<unsigned long long> wt(3u * (size_t)ctx->wave_times_n);
+            if (hipMemcpy(wt.data(), ctx->wave_times.p, wt.size() * 8, hipMemcpyDeviceToHost) == hipSuccess) {
+                unsigned long long t0 = ~0ull;
+                for (size_t i = 0; i < wt.size(); i += 3) t0 = std::min(t0, wt[i]);
+                std::vector<double> start, dry, end, chain;
+                for (size_t i = 0; i < wt.size(); i += 3) {
+                    start.push_back((double)(wt[i] - t0) * 1e-5);
+                    end.push_back((double)(wt[i + 2] - t0) * 1e-5);
+                    if (wt[i + 1]) { dry.push_back((double)(wt[i + 1] - t0) * 1e-5); chain.push_back((double)(wt[i + 2] - wt[i + 1]) * 1e-5); }
+                }
+                auto pct = [](std::vector<double> & v, double q) { if (v.empty()) return 0.0; std::sort(v.begin(), v.end()); return v[std::min(v.size() - 1, (size_t)(q * (double)v.size()))]; };
+                fprintf(stderr, "[prt] k_pool waves on the wall clock (ms since the first wave started; last pass): start p50 %.3f max %.3f | counter dry p10 %.3f p50 %.3f p90 %.3f max %.3f | exit p10 %.3f p50 %.3f p90 %.3f p99 %.3f max %.3f | exit - dry p50 %.3f p90 %.3f max %.3f\n",
+                        pct(start, 0.5), pct(start, 1.0), pct(dry, 0.1), pct(dry, 0.5), pct(dry, 0.9), pct(dry, 1.0),
+                        pct(end, 0.1), pct(end, 0.5), pct(end, 0.9), pct(end, 0.99), pct(end, 1.0), pct(chain, 0.5), pct(chain, 0.9), pct(chain, 1.0));
+            }
+        }
         if (opt.debug_util && h.phase_cycles[3] && h.phase_cycles[4])
             fprintf(stderr, "[prt] k_pool adaptive finalise step (store the sample, variance rule, next camera ray): %.1f%% of the main loop\n",
                     100.0 * (double)h.phase_cycles[4] / (double)h.phase_cycles[3]);
@@ -1104,6 +1163,27 @@ int render_pixels(prt_ctx * ctx, const prt_camera * cam_in, const prt_params * p
 }  // namespace
 
 // =============================================================================================================
+// "Nothing aborts" (include/prt.h): the entry points below use std::vector / std::string / std::thread / new, and an
+// exception that leaves an extern "C" function is std::terminate - an abort of the CALLER's process.  Every entry point
+// that can allocate therefore runs its body inside PRT_API_TRY ... PRT_API_CATCH_*: std::bad_alloc, std::length_error,
+// std::system_error and anything else become PRT_ERR_EXCEPTION (-12) with the message in prt_last_error.
+namespace {
+int api_exception(std::string * err, const char * where) noexcept {
+    char what[256] = "unknown C++ exception";
+    try { throw; }
+    catch (const std::bad_alloc &) { snprintf(what, sizeof(what), "out of host memory (std::bad_alloc)"); }
+    catch (const std::exception & e) { snprintf(what, sizeof(what), "C++ exception: %s", e.what()); }
+    catch (...) {}
+    try { if (err) *err = std::string(where) + ": " + what; } catch (...) {}      // the message itself may not fit: keep the code
+    return PRT_ERR_EXCEPTION;
+}
+}  // namespace
+#define PRT_API_TRY try {
+#define PRT_API_CATCH_RC(ctx, where) } catch (...) { prt_ctx * c_ = (ctx); return api_exception(c_ ? &c_->error : &g_create_error, where); }
+#define PRT_API_CATCH_RC_MULTI(m, where) } catch (...) { prt_multi * m_ = (m); return api_exception(m_ ? &m_->error : &g_create_error, where); }
+#define PRT_API_CATCH_PTR(where) } catch (...) { (void)api_exception(&g_create_error, where); return nullptr; }
+#define PRT_API_CATCH_VOID } catch (...) {}
+
 extern "C" {
 
 int prt_abi_version(void) { return PRT_ABI_VERSION; }
@@ -1122,6 +1202,7 @@ int prt_build_flags(void) {
 const char * prt_last_error(const prt_ctx * ctx) { return ctx ? ctx->error.c_str() : g_create_error.c_str(); }
 
 prt_ctx * prt_create(int device_id) {
+    PRT_API_TRY
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess || n <= 0) {
@@ -1187,6 +1268,7 @@ prt_ctx * prt_create(int device_id) {
     ctx->chain[0].stream = ctx->stream;
     if (ctx->opt.pool_park_cap >= 0) ctx->pool_park_cap = ctx->pool_spark_cap = (size_t)std::max(1ll, ctx->opt.pool_park_cap);   // tests: start tiny, grow
     if (e == hipSuccess) e = ctx->counters.ensure(1);          // DevScene::near_tie_unresolved points into it
+    if (e == hipSuccess) e = hipHostMalloc((void **)&ctx->host_counters, sizeof(DevCounters), hipHostMallocDefault);
     for (int c = 1; c < PRT_MAX_CHAINS && e == hipSuccess; ++c) e = make_stream(&ctx->chain[c].stream);
     for (int c = 0; c < PRT_MAX_CHAINS && e == hipSuccess; ++c) {
         prt_ctx::ChainWs & w = ctx->chain[c];
@@ -1202,15 +1284,17 @@ prt_ctx * prt_create(int device_id) {
         return nullptr;
     }
     return ctx;
+    PRT_API_CATCH_PTR("prt_create")
 }
 
 void prt_destroy(prt_ctx * ctx) {
+    PRT_API_TRY
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     ctx->nodes.release(); ctx->tris.release(); ctx->shade.release(); ctx->diffuse_dirs.release(); ctx->spec_dirs.release();
     ctx->tri_rank.release(); ctx->materials.release(); ctx->lights.release();
-    ctx->sample_rgb.release(); ctx->frame_out.release(); ctx->counters.release(); ctx->ring_ws.release(); ctx->pixel_list.release(); ctx->wf_counts.release(); ctx->stack_spill.release(); ctx->pool_f4.release(); ctx->pool_park.release(); ctx->pool_fin.release(); ctx->pool_args.release(); ctx->adapt_f4.release();
+    ctx->sample_rgb.release(); ctx->frame_out.release(); ctx->counters.release(); ctx->ring_ws.release(); ctx->pixel_list.release(); ctx->wf_counts.release(); ctx->stack_spill.release(); ctx->pool_f4.release(); ctx->pool_park.release(); ctx->pool_fin.release(); ctx->pool_args.release(); ctx->adapt_f4.release(); ctx->wave_times.release();
     ctx->textures.release(); ctx->texels.release(); ctx->srgb_lut.release(); ctx->tri_uv.release(); ctx->tri_tan.release();
     ctx->ref_spheres.release();
     for (int c = 0; c < PRT_MAX_CHAINS; ++c) {
@@ -1224,11 +1308,14 @@ void prt_destroy(prt_ctx * ctx) {
         if (c >= 1 && w.stream) (void)hipStreamDestroy(w.stream);
     }
     for (int i = 0; i < 4; ++i) if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
+    if (ctx->host_counters) (void)hipHostFree(ctx->host_counters);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
+    PRT_API_CATCH_VOID
 }
 
 int prt_set_option(prt_ctx * ctx, const char * name, const char * value) {
+    PRT_API_TRY
     if (!ctx || !name) return -1;
     const char * bare = !strncasecmp(name, "PRT_", 4) ? name + 4 : name;
     if (!strcasecmp(bare, "RESERVE_CUS")) { ctx->error = "prt_set_option: RESERVE_CUS shapes the context's streams and is read at creation only (environment PRT_RESERVE_CUS)"; return -1; }
@@ -1239,15 +1326,19 @@ int prt_set_option(prt_ctx * ctx, const char * name, const char * value) {
     }
     ctx->tuned.clear();                 // a knob may change which pipeline wins the try-out
     return 0;
+    PRT_API_CATCH_RC(ctx, "prt_set_option")
 }
 
 int prt_get_render_stats(const prt_ctx * ctx, prt_render_stats * stats) {
+    PRT_API_TRY
     if (!ctx || !stats) return -1;
     *stats = ctx->last_stats;
     return 0;
+    PRT_API_CATCH_RC(nullptr, "prt_get_render_stats")
 }
 
 int prt_upload_scene(prt_ctx * ctx, const prt_scene_desc * s) {
+    PRT_API_TRY
     if (!ctx) return -1;
     if (!s || (s->index_count % 3) != 0) { ctx->error = "prt_upload_scene: null scene or index_count not a multiple of 3"; return -1; }
     if (s->material_count == 0) { ctx->error = "prt_upload_scene: at least one material is required"; return -1; }
@@ -1554,17 +1645,21 @@ int prt_upload_scene(prt_ctx * ctx, const prt_scene_desc * s) {
     ctx->scene_epoch++;
     ctx->tuned.clear();
     return 0;
+    PRT_API_CATCH_RC(ctx, "prt_upload_scene")
 }
 
 int prt_get_scene_info(const prt_ctx * ctx, prt_scene_info * info) {
+    PRT_API_TRY
     if (!ctx || !info) return -1;
     if (!ctx->has_scene) return -2;
     *info = ctx->info;
     return 0;
+    PRT_API_CATCH_RC(nullptr, "prt_get_scene_info")
 }
 
 int prt_render_device(prt_ctx * ctx, const prt_camera * cam, const prt_params * params, uint32_t width, uint32_t height,
                       uint32_t start_idx, uint32_t end_idx, void * d_rgba_out, prt_counters * counters) {
+    PRT_API_TRY
     if (!ctx) return -1;
     if ((!d_rgba_out && end_idx != start_idx) || end_idx < start_idx || (uint64_t)end_idx > (uint64_t)width * height) {
         ctx->error = "prt_render: bad output pointer or pixel range";
@@ -1572,10 +1667,12 @@ int prt_render_device(prt_ctx * ctx, const prt_camera * cam, const prt_params * 
     }
     PixelSet px = { end_idx - start_idx, start_idx, 1, 0, 1, nullptr };
     return render_pixels(ctx, cam, params, width, height, px, (float4 *)d_rgba_out, counters);
+    PRT_API_CATCH_RC(ctx, "prt_render_device")
 }
 
 int prt_render(prt_ctx * ctx, const prt_camera * cam, const prt_params * params, uint32_t width, uint32_t height,
                uint32_t start_idx, uint32_t end_idx, float * rgba_out, prt_counters * counters) {
+    PRT_API_TRY
     if (!ctx) return -1;
     if ((!rgba_out && end_idx != start_idx) || end_idx < start_idx) { ctx->error = "prt_render: bad output pointer or pixel range"; return -1; }
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -1585,6 +1682,7 @@ int prt_render(prt_ctx * ctx, const prt_camera * cam, const prt_params * params,
     if (rc) return rc;
     if (n) HIP_TRY(ctx, hipMemcpy(rgba_out, ctx->frame_out.p, n * sizeof(float4), hipMemcpyDeviceToHost));
     return 0;
+    PRT_API_CATCH_RC(ctx, "prt_render")
 }
 
 uint32_t prt_shard_rows(uint32_t height, uint32_t block_rows, uint32_t rank, uint32_t nranks) {
@@ -1596,16 +1694,19 @@ uint32_t prt_shard_rows(uint32_t height, uint32_t block_rows, uint32_t rank, uin
 
 int prt_render_shard_device(prt_ctx * ctx, const prt_camera * cam, const prt_params * params, uint32_t width, uint32_t height,
                             uint32_t block_rows, uint32_t rank, uint32_t nranks, void * d_rgba_out, prt_counters * counters) {
+    PRT_API_TRY
     if (!ctx) return -1;
     if (!block_rows || !nranks || rank >= nranks) { ctx->error = "prt_render_shard: bad arguments"; return -1; }
     if (!d_rgba_out && prt_shard_rows(height, block_rows, rank, nranks)) { ctx->error = "prt_render_shard: null output"; return -1; }
     PixelSet px = { prt_shard_rows(height, block_rows, rank, nranks) * width, 0, block_rows, rank, nranks, nullptr };
     if (nranks == 1) { px.block_rows = 1; }
     return render_pixels(ctx, cam, params, width, height, px, (float4 *)d_rgba_out, counters);
+    PRT_API_CATCH_RC(ctx, "prt_render_shard_device")
 }
 
 int prt_render_shard(prt_ctx * ctx, const prt_camera * cam, const prt_params * params, uint32_t width, uint32_t height,
                      uint32_t block_rows, uint32_t rank, uint32_t nranks, float * rgba_out, prt_counters * counters) {
+    PRT_API_TRY
     if (!ctx) return -1;
     const size_t n = (size_t)prt_shard_rows(height, block_rows, rank, nranks) * width;
     if (!rgba_out && n) { ctx->error = "prt_render_shard: null output"; return -1; }
@@ -1615,10 +1716,12 @@ int prt_render_shard(prt_ctx * ctx, const prt_camera * cam, const prt_params * p
     if (rc) return rc;
     if (n) HIP_TRY(ctx, hipMemcpy(rgba_out, ctx->frame_out.p, n * sizeof(float4), hipMemcpyDeviceToHost));
     return 0;
+    PRT_API_CATCH_RC(ctx, "prt_render_shard")
 }
 
 int prt_render_pixel_list(prt_ctx * ctx, const prt_camera * cam, const prt_params * params, uint32_t width, uint32_t height,
                           const uint32_t * pixel_ids, uint32_t n_pixels, float * rgba_out, prt_counters * counters) {
+    PRT_API_TRY
     if (!ctx) return -1;
     if ((!pixel_ids || !rgba_out) && n_pixels) { ctx->error = "prt_render_pixel_list: null pixel list or output"; return -1; }
     for (uint32_t i = 0; i < n_pixels; ++i)
@@ -1633,10 +1736,12 @@ int prt_render_pixel_list(prt_ctx * ctx, const prt_camera * cam, const prt_param
     if (rc) return rc;
     if (n_pixels) HIP_TRY(ctx, hipMemcpy(rgba_out, ctx->frame_out.p, (size_t)n_pixels * sizeof(float4), hipMemcpyDeviceToHost));
     return 0;
+    PRT_API_CATCH_RC(ctx, "prt_render_pixel_list")
 }
 
 int prt_debug_device_kat(prt_ctx * ctx, int kind, const void * in, size_t in_bytes, void * out, size_t out_bytes, uint32_t n,
                          const prt_camera * cam_in) {
+    PRT_API_TRY
     if (!ctx) return -1;
     if (!ctx->has_scene) { ctx->error = "prt_debug_device_kat: upload a scene first"; return -2; }
     if (!in || !out || !n) { ctx->error = "prt_debug_device_kat: null buffers"; return -1; }
@@ -1670,6 +1775,7 @@ int prt_debug_device_kat(prt_ctx * ctx, int kind, const void * in, size_t in_byt
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     HIP_TRY(ctx, hipMemcpy(out, d_out, out_bytes, hipMemcpyDeviceToHost));
     return 0;
+    PRT_API_CATCH_RC(ctx, "prt_debug_device_kat")
 }
 
 // Host-only self check of the acceleration structure (no GPU needed; used by the CPU test-suite): builds the
@@ -1827,6 +1933,7 @@ static int check_bvh_wide(const std::vector<float> & verts, uint32_t n_tris, con
 #endif
 
 int prt_debug_check_bvh(const prt_scene_desc * s, uint64_t * out) {
+    PRT_API_TRY
     if (!s || !out || s->index_count % 3) return -1;
     const uint32_t n_tris = s->index_count / 3;
     std::vector<float> verts((size_t)n_tris * 9);
@@ -1842,10 +1949,12 @@ int prt_debug_check_bvh(const prt_scene_desc * s, uint64_t * out) {
     BvhWide bvh;
     PRT_BUILD_WIDE(verts.data(), n_tris, BVH_LEAF_MAX, 4, &bvh, 1.0f, &opt.bvh);
     return check_bvh_wide(verts, n_tris, bvh, out);
+    PRT_API_CATCH_RC(nullptr, "prt_debug_check_bvh")
 }
 
 // The same check on the tree of the GPU LBVH builder (needs a context: the radix tree is built on its device).
 int prt_debug_check_bvh_lbvh(prt_ctx * ctx, const prt_scene_desc * s, uint64_t * out) {
+    PRT_API_TRY
     if (!ctx || !s || !out || s->index_count % 3) return -1;
     const uint32_t n_tris = s->index_count / 3;
     std::vector<float> verts((size_t)n_tris * 9);
@@ -1856,7 +1965,10 @@ int prt_debug_check_bvh_lbvh(prt_ctx * ctx, const prt_scene_desc * s, uint64_t *
     int rc = build_bvh_lbvh(ctx, verts.data(), n_tris, BVH_LEAF_MAX, &bvh);
     if (rc) return rc;
     return check_bvh_wide(verts, n_tris, bvh, out);
+    PRT_API_CATCH_RC(ctx, "prt_debug_check_bvh_lbvh")
 }
+
+}  // extern "C"
 
 // =============================================================================================================
 // Several devices behind one handle (prt_create(const int * device_ids, int n_dev)) - the product's
@@ -1865,6 +1977,15 @@ int prt_debug_check_bvh_lbvh(prt_ctx * ctx, const prt_scene_desc * s, uint64_t *
 // travel to device 0 over the fabric as peer-to-peer copies - DMA engines over xGMI, no compute unit involved, so they
 // do not compete with the persistent render kernels for wave slots the way a collective's kernels do -, one small kernel
 // on device 0 puts the rows where they belong, and ONE copy takes the frame to the host.
+//
+// Round 4: FRAMES IN FLIGHT.  A persistent kernel leaves its GPU partly idle while its last rays drain (a 1/8 shard of the
+// headline frame: 2.1 ms at one frame at a time, 1.75 ms per frame with two in flight, profiles/r03_shards_frames_in_flight.txt),
+// and the copies / assembly / download of frame k need no compute unit that frame k + 1 could not use.  The handle
+// therefore holds `depth` LANES (default 2, PRT_MULTI_DEPTH): a lane is one context per device - lane 0 the contexts
+// prt_multi_context() returns, the others CLONES that share the uploaded scene's device arrays and own only their streams
+// and workspaces - plus the lane's shard / staging / frame buffers.  prt_multi_submit() hands a frame to a free lane and
+// returns; the lane's worker threads - one per device, created ONCE with the handle, not per frame - render and send
+// their shards; prt_multi_wait() assembles and downloads.  prt_multi_render() is submit + wait.
 __global__ void k_assemble_shards(const float4 * staging, float4 * frame, unsigned int width, unsigned int height,
                                   unsigned int block_rows, unsigned int n_dev, unsigned int max_shard_rows) {
     const unsigned int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1875,144 +1996,348 @@ __global__ void k_assemble_shards(const float4 * staging, float4 * frame, unsign
     frame[i] = staging[((size_t)g * max_shard_rows + local_row) * width + x];
 }
 
-struct prt_multi {
-    std::vector<prt_ctx *> ctx;
+enum { PRT_MULTI_BLOCK_ROWS = 8, PRT_MULTI_MAX_DEPTH = 4 };
+
+struct MultiLane {
+    std::vector<prt_ctx *> ctx;              // per device; lane 0: the handle's own contexts, else clones of them
     std::vector<DevBuf<float4> > shard;      // per device: its packed shard (device g's memory)
     DevBuf<float4> staging, frame;           // device 0: every shard side by side; the assembled frame
     std::vector<hipEvent_t> done;            // per device: its peer copy has landed
+    // the frame in flight on this lane (written by submit under the handle's mutex, read by the lane's workers)
+    bool busy = false;
+    uint64_t ticket = 0;
+    prt_camera cam;
+    prt_params params;
+    uint32_t width = 0, height = 0;
+    float * rgba_out = nullptr;
+    unsigned int pending = 0;                // workers that have not finished this frame yet
+    std::vector<uint64_t> job;               // per device: generation of the job handed to its worker
+    std::vector<int> rc;
+    std::vector<std::string> err;
+    std::vector<prt_counters> ctr;
+};
+
+struct prt_multi {
+    std::vector<int> devices;
+    std::vector<MultiLane> lane;
+    std::vector<std::thread> workers;        // lanes x devices, alive as long as the handle
+    std::mutex mu;
+    std::condition_variable cv_work, cv_done;
+    bool quit = false;
+    uint64_t next_ticket = 1;
     std::string error;
 };
 
-enum { PRT_MULTI_BLOCK_ROWS = 8 };
+namespace {
+
+// A second context on src's device that SHARES the uploaded scene's device arrays (it does not own them: src must
+// outlive it and must not be re-uploaded while it exists) and has streams, events and workspaces of its own.
+prt_ctx * clone_context(prt_ctx * src) {
+    prt_ctx * c = prt_create(src->device);
+    if (!c) return nullptr;
+    c->opt = src->opt;
+    c->nodes.borrow(src->nodes); c->tris.borrow(src->tris); c->shade.borrow(src->shade); c->diffuse_dirs.borrow(src->diffuse_dirs);
+    c->tri_rank.borrow(src->tri_rank); c->materials.borrow(src->materials); c->lights.borrow(src->lights);
+    c->textures.borrow(src->textures); c->texels.borrow(src->texels); c->srgb_lut.borrow(src->srgb_lut);
+    c->tri_uv.borrow(src->tri_uv); c->tri_tan.borrow(src->tri_tan); c->ref_spheres.borrow(src->ref_spheres);
+    c->scene = src->scene;
+    c->scene.near_tie_unresolved = &c->counters.p->near_tie_unresolved;      // its own counters
+    c->scene.spec_dirs = nullptr;
+    c->spec_table_samples = 0;              // its own specular direction table, built at its first render
+    c->material_ns = src->material_ns;
+    c->info = src->info;
+    c->scene_abs_max = src->scene_abs_max;
+    c->any_translucent = src->any_translucent; c->point_lights = src->point_lights; c->textured = src->textured;
+    c->stack_bound = src->stack_bound;
+    c->pool_park_cap = src->pool_park_cap; c->pool_spark_cap = src->pool_spark_cap;
+    c->has_scene = src->has_scene;
+    c->scene_epoch = 1;
+    return c;
+}
+
+void multi_worker(prt_multi * m, unsigned int f, unsigned int g) {
+    MultiLane & L = m->lane[f];
+    uint64_t seen = 0;
+    for (;;) {
+        {
+            std::unique_lock<std::mutex> lk(m->mu);
+            m->cv_work.wait(lk, [&] { return m->quit || L.job[g] != seen; });
+            if (m->quit) return;
+            seen = L.job[g];
+        }
+        int rc = 0;
+        std::string err;
+        prt_counters ctr;
+        memset(&ctr, 0, sizeof(ctr));
+        try {
+            const unsigned int n = (unsigned int)L.ctx.size();
+            prt_ctx * c = L.ctx[g], * c0 = L.ctx[0];
+            const size_t rows = prt_shard_rows(L.height, PRT_MULTI_BLOCK_ROWS, g, n);
+            const uint32_t max_rows = prt_shard_rows(L.height, PRT_MULTI_BLOCK_ROWS, 0, n);      // rank 0 owns the most rows
+            hipError_t e = hipSetDevice(c->device);
+            if (e == hipSuccess) e = L.shard[g].ensure(std::max<size_t>(1, rows * L.width));
+            if (e != hipSuccess) { rc = PRT_ERR_HIP; err = std::string("shard buffer: ") + hipGetErrorString(e); }
+            if (!rc) {
+                rc = prt_render_shard_device(c, &L.cam, &L.params, L.width, L.height, PRT_MULTI_BLOCK_ROWS, g, n, L.shard[g].p, &ctr);
+                if (rc) err = prt_last_error(c);
+            }
+            if (!rc && n > 1) {
+                // the shard's trip to device 0, queued on the rendering context's own stream: a shard that is done travels
+                // while the others still render
+                if (rows) e = hipMemcpyPeerAsync(L.staging.p + (size_t)g * max_rows * L.width, c0->device, L.shard[g].p, c->device,
+                                                 rows * L.width * sizeof(float4), c->stream);
+                if (e == hipSuccess) e = hipEventRecord(L.done[g], c->stream);
+                if (e != hipSuccess) { rc = PRT_ERR_HIP; err = std::string("peer copy: ") + hipGetErrorString(e); }
+            }
+        } catch (...) {
+            rc = api_exception(&err, "prt_multi worker");
+        }
+        {
+            std::lock_guard<std::mutex> lk(m->mu);
+            L.rc[g] = rc;
+            try { L.err[g] = err; } catch (...) {}
+            L.ctr[g] = ctr;
+            if (--L.pending == 0) m->cv_done.notify_all();
+        }
+    }
+}
+
+void multi_release_lane(MultiLane & L, bool destroy_ctx) {
+    for (size_t g = 0; g < L.ctx.size(); ++g) {
+        if (!L.ctx[g]) continue;
+        (void)hipSetDevice(L.ctx[g]->device);
+        if (L.ctx[g]->stream) (void)hipStreamSynchronize(L.ctx[g]->stream);
+        if (g < L.shard.size()) L.shard[g].release();
+        if (g < L.done.size() && L.done[g]) { (void)hipEventDestroy(L.done[g]); L.done[g] = nullptr; }
+    }
+    if (!L.ctx.empty() && L.ctx[0]) {
+        (void)hipSetDevice(L.ctx[0]->device);
+        L.staging.release();
+        L.frame.release();
+    }
+    if (destroy_ctx)
+        for (size_t g = 0; g < L.ctx.size(); ++g) { prt_destroy(L.ctx[g]); L.ctx[g] = nullptr; }
+}
+
+// Every stream of every lane drained: after a failure nothing of the failed frame is still writing into staging / frame.
+void multi_quiesce(prt_multi * m) {
+    for (MultiLane & L : m->lane)
+        for (prt_ctx * c : L.ctx)
+            if (c && c->stream) { (void)hipSetDevice(c->device); (void)hipStreamSynchronize(c->stream); }
+}
+
+}  // namespace
+
+extern "C" {
 
 prt_multi * prt_multi_create(const int * device_ids, int n_dev) {
+    PRT_API_TRY
     if (!device_ids || n_dev < 1) { g_create_error = "prt_multi_create: no devices"; return nullptr; }
     prt_multi * m = new prt_multi;
+    m->devices.assign(device_ids, device_ids + n_dev);
+    long long depth = 2;
+    if (const char * v = getenv("PRT_MULTI_DEPTH")) depth = atoll(v);        // creation only, like every PRT_* variable
+    depth = std::max(1ll, std::min((long long)PRT_MULTI_MAX_DEPTH, depth));
+    m->lane.resize((size_t)depth);
+    for (MultiLane & L : m->lane) {
+        L.ctx.assign((size_t)n_dev, nullptr);
+        L.shard.resize((size_t)n_dev);
+        L.done.assign((size_t)n_dev, nullptr);
+        L.job.assign((size_t)n_dev, 0);
+        L.rc.assign((size_t)n_dev, 0);
+        L.err.resize((size_t)n_dev);
+        L.ctr.resize((size_t)n_dev);
+    }
     for (int g = 0; g < n_dev; ++g) {
         prt_ctx * c = prt_create(device_ids[g]);
         if (!c) { prt_multi_destroy(m); return nullptr; }
-        m->ctx.push_back(c);
+        m->lane[0].ctx[(size_t)g] = c;
     }
-    m->shard.resize((size_t)n_dev);
-    m->done.assign((size_t)n_dev, nullptr);
-    for (int g = 0; g < n_dev; ++g) {
-        if (hipSetDevice(m->ctx[(size_t)g]->device) != hipSuccess || hipEventCreateWithFlags(&m->done[(size_t)g], hipEventDisableTiming) != hipSuccess) {
-            g_create_error = "prt_multi_create: event creation failed";
-            prt_multi_destroy(m);
-            return nullptr;
-        }
-        // direct loads / stores between the devices where the fabric offers them (the copies work either way)
-        if (g > 0 && m->ctx[(size_t)g]->device != m->ctx[0]->device) {
-            int can = 0;
-            if (hipDeviceCanAccessPeer(&can, m->ctx[0]->device, m->ctx[(size_t)g]->device) == hipSuccess && can) {
-                (void)hipSetDevice(m->ctx[0]->device);
-                (void)hipDeviceEnablePeerAccess(m->ctx[(size_t)g]->device, 0);
-                (void)hipGetLastError();             // "already enabled" is fine
+    for (MultiLane & L : m->lane)
+        for (int g = 0; g < n_dev; ++g) {
+            prt_ctx * c0 = m->lane[0].ctx[0], * c = m->lane[0].ctx[(size_t)g];
+            if (hipSetDevice(c->device) != hipSuccess || hipEventCreateWithFlags(&L.done[(size_t)g], hipEventDisableTiming) != hipSuccess) {
+                g_create_error = "prt_multi_create: event creation failed";
+                prt_multi_destroy(m);
+                return nullptr;
+            }
+            // direct loads / stores between the devices where the fabric offers them (the copies work either way)
+            if (&L == &m->lane[0] && g > 0 && c->device != c0->device) {
+                int can = 0;
+                if (hipDeviceCanAccessPeer(&can, c0->device, c->device) == hipSuccess && can) {
+                    (void)hipSetDevice(c0->device);
+                    (void)hipDeviceEnablePeerAccess(c->device, 0);
+                    (void)hipGetLastError();             // "already enabled" is fine
+                }
             }
         }
-    }
+    // the workers: one per (lane, device), for the life of the handle (round 3 created and joined n threads per frame)
+    for (unsigned int f = 0; f < (unsigned int)depth; ++f)
+        for (unsigned int g = 0; g < (unsigned int)n_dev; ++g) m->workers.emplace_back(multi_worker, m, f, g);
     return m;
+    PRT_API_CATCH_PTR("prt_multi_create")
 }
 
 void prt_multi_destroy(prt_multi * m) {
+    PRT_API_TRY
     if (!m) return;
-    for (size_t g = 0; g < m->ctx.size(); ++g) {
-        (void)hipSetDevice(m->ctx[g]->device);
-        if (g < m->shard.size()) m->shard[g].release();
-        if (g < m->done.size() && m->done[g]) (void)hipEventDestroy(m->done[g]);
+    {
+        std::unique_lock<std::mutex> lk(m->mu);
+        // frames still in flight finish first (their buffers and contexts go away below)
+        m->cv_done.wait(lk, [&] { for (MultiLane & L : m->lane) if (L.pending) return false; return true; });
+        m->quit = true;
     }
-    if (!m->ctx.empty()) {
-        (void)hipSetDevice(m->ctx[0]->device);
-        m->staging.release();
-        m->frame.release();
-    }
-    for (size_t g = 0; g < m->ctx.size(); ++g) prt_destroy(m->ctx[g]);
+    m->cv_work.notify_all();
+    for (std::thread & t : m->workers) if (t.joinable()) t.join();
+    for (size_t f = m->lane.size(); f-- > 0;) multi_release_lane(m->lane[f], true);      // the clones before the contexts they borrow from
     delete m;
+    PRT_API_CATCH_VOID
 }
 
 const char * prt_multi_last_error(const prt_multi * m) { return m ? m->error.c_str() : g_create_error.c_str(); }
-int prt_multi_device_count(const prt_multi * m) { return m ? (int)m->ctx.size() : 0; }
-prt_ctx * prt_multi_context(prt_multi * m, int i) { return m && i >= 0 && (size_t)i < m->ctx.size() ? m->ctx[(size_t)i] : nullptr; }
+int prt_multi_device_count(const prt_multi * m) { return m ? (int)m->devices.size() : 0; }
+int prt_multi_depth(const prt_multi * m) { return m ? (int)m->lane.size() : 0; }
+prt_ctx * prt_multi_context(prt_multi * m, int i) { return m && i >= 0 && (size_t)i < m->devices.size() ? m->lane[0].ctx[(size_t)i] : nullptr; }
 
 int prt_multi_upload_scene(prt_multi * m, const prt_scene_desc * scene) {
+    PRT_API_TRY
     if (!m) return -1;
-    for (size_t g = 0; g < m->ctx.size(); ++g) {
-        const int rc = prt_upload_scene(m->ctx[g], scene);
-        if (rc) { m->error = prt_last_error(m->ctx[g]); return rc; }
+    {
+        std::lock_guard<std::mutex> lk(m->mu);
+        for (MultiLane & L : m->lane)
+            if (L.busy) { m->error = "prt_multi_upload_scene: a frame is still in flight (prt_multi_wait it first)"; return PRT_ERR_IN_FLIGHT; }
     }
+    // the other lanes' contexts borrow lane 0's scene arrays: they go before those are replaced, and come back after
+    for (size_t f = 1; f < m->lane.size(); ++f)
+        for (size_t g = 0; g < m->lane[f].ctx.size(); ++g) { prt_destroy(m->lane[f].ctx[g]); m->lane[f].ctx[g] = nullptr; }
+    for (size_t g = 0; g < m->devices.size(); ++g) {
+        const int rc = prt_upload_scene(m->lane[0].ctx[g], scene);
+        if (rc) { m->error = prt_last_error(m->lane[0].ctx[g]); return rc; }
+    }
+    for (size_t f = 1; f < m->lane.size(); ++f)
+        for (size_t g = 0; g < m->devices.size(); ++g) {
+            m->lane[f].ctx[g] = clone_context(m->lane[0].ctx[g]);
+            if (!m->lane[f].ctx[g]) { m->error = std::string("prt_multi_upload_scene: ") + g_create_error; return PRT_ERR_HIP; }
+        }
     return 0;
+    PRT_API_CATCH_RC_MULTI(m, "prt_multi_upload_scene")
 }
 
 #define MULTI_TRY(m, call)                                                                                   \
     do {                                                                                                     \
         hipError_t e_ = (call);                                                                              \
-        if (e_ != hipSuccess) { (m)->error = std::string(#call) + ": " + hipGetErrorString(e_); return -10; } \
+        if (e_ != hipSuccess) { (m)->error = std::string(#call) + ": " + hipGetErrorString(e_); multi_quiesce(m); return PRT_ERR_HIP; } \
     } while (0)
 
-int prt_multi_render(prt_multi * m, const prt_camera * cam, const prt_params * params, uint32_t width, uint32_t height,
-                     float * rgba_out, prt_counters * counters) {
-    if (!m || m->ctx.empty()) return -1;
-    if (!rgba_out && width && height) { m->error = "prt_multi_render: null output"; return -1; }
-    const unsigned int n = (unsigned int)m->ctx.size();
-    std::vector<prt_counters> ctr(n);
-    for (unsigned int g = 0; g < n; ++g) memset(&ctr[g], 0, sizeof(prt_counters));
-    if (n == 1) {
-        const int rc = prt_render(m->ctx[0], cam, params, width, height, 0, width * height, rgba_out, &ctr[0]);
-        if (rc) { m->error = prt_last_error(m->ctx[0]); return rc; }
-        if (counters) *counters = ctr[0];
-        return 0;
+int prt_multi_submit(prt_multi * m, const prt_camera * cam, const prt_params * params, uint32_t width, uint32_t height,
+                     float * rgba_out, uint64_t * ticket) {
+    PRT_API_TRY
+    if (!m || m->devices.empty()) return -1;
+    if (!cam || !params || !ticket) { m->error = "prt_multi_submit: null camera, params or ticket"; return -1; }
+    if (!rgba_out && width && height) { m->error = "prt_multi_submit: null output"; return -1; }
+    const unsigned int n = (unsigned int)m->devices.size();
+    MultiLane * L = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(m->mu);
+        for (MultiLane & c : m->lane)
+            if (!c.busy && c.ctx[0]) { L = &c; break; }
+        if (!L) { m->error = "prt_multi_submit: every lane has a frame in flight (prt_multi_wait the oldest ticket first)"; return PRT_ERR_IN_FLIGHT; }
+        L->busy = true;                      // reserved; the workers start below, when the buffers are there
     }
-    const size_t n_px = (size_t)width * height;
-    const uint32_t max_rows = prt_shard_rows(height, PRT_MULTI_BLOCK_ROWS, 0, n);       // rank 0 owns the most rows
-    prt_ctx * c0 = m->ctx[0];
-    MULTI_TRY(m, hipSetDevice(c0->device));
-    MULTI_TRY(m, m->staging.ensure((size_t)n * max_rows * width));
-    MULTI_TRY(m, m->frame.ensure(n_px));
-    // one host thread per device renders its shard (the render call blocks its caller), then queues the shard's trip to
-    // device 0 on its own stream: a shard that is done travels while the others still render
-    std::vector<int> rc(n, 0);
-    std::vector<std::string> err(n);
-    std::vector<std::thread> pool;
-    for (unsigned int g = 0; g < n; ++g) {
-        pool.emplace_back([&, g]() {
-            prt_ctx * c = m->ctx[g];
-            const size_t rows = prt_shard_rows(height, PRT_MULTI_BLOCK_ROWS, g, n);
-            hipError_t e = hipSetDevice(c->device);
-            if (e == hipSuccess) e = m->shard[g].ensure(std::max<size_t>(1, rows * width));
-            if (e != hipSuccess) { rc[g] = -10; err[g] = std::string("shard buffer: ") + hipGetErrorString(e); return; }
-            rc[g] = prt_render_shard_device(c, cam, params, width, height, PRT_MULTI_BLOCK_ROWS, g, n, m->shard[g].p, &ctr[g]);
-            if (rc[g]) { err[g] = prt_last_error(c); return; }
-            if (rows) e = hipMemcpyPeerAsync(m->staging.p + (size_t)g * max_rows * width, c0->device, m->shard[g].p, c->device,
-                                             rows * width * sizeof(float4), c->stream);
-            if (e == hipSuccess) e = hipEventRecord(m->done[g], c->stream);
-            if (e != hipSuccess) { rc[g] = -10; err[g] = std::string("peer copy: ") + hipGetErrorString(e); }
-        });
+    const uint32_t max_rows = prt_shard_rows(height, PRT_MULTI_BLOCK_ROWS, 0, n);
+    prt_ctx * c0 = L->ctx[0];
+    hipError_t e = hipSetDevice(c0->device);
+    if (e == hipSuccess && n > 1) e = L->staging.ensure((size_t)n * max_rows * width);
+    if (e == hipSuccess && n > 1) e = L->frame.ensure((size_t)width * height);
+    if (e != hipSuccess) {
+        std::lock_guard<std::mutex> lk(m->mu);
+        L->busy = false;
+        m->error = std::string("prt_multi_submit: buffers on device 0: ") + hipGetErrorString(e);
+        return PRT_ERR_HIP;
     }
-    for (size_t t = 0; t < pool.size(); ++t) pool[t].join();
+    {
+        std::lock_guard<std::mutex> lk(m->mu);
+        L->cam = *cam; L->params = *params; L->width = width; L->height = height; L->rgba_out = rgba_out;
+        L->ticket = m->next_ticket++;
+        L->pending = n;
+        for (unsigned int g = 0; g < n; ++g) { L->rc[g] = 0; L->err[g].clear(); L->job[g]++; }
+        *ticket = L->ticket;
+    }
+    m->cv_work.notify_all();
+    return 0;
+    PRT_API_CATCH_RC_MULTI(m, "prt_multi_submit")
+}
+
+int prt_multi_wait(prt_multi * m, uint64_t ticket, prt_counters * counters) {
+    PRT_API_TRY
+    if (!m || m->devices.empty()) return -1;
+    const unsigned int n = (unsigned int)m->devices.size();
+    MultiLane * L = nullptr;
+    {
+        std::unique_lock<std::mutex> lk(m->mu);
+        for (MultiLane & c : m->lane)
+            if (c.busy && c.ticket == ticket) { L = &c; break; }
+        if (!L) { m->error = "prt_multi_wait: no frame with this ticket is in flight"; return -1; }
+        m->cv_done.wait(lk, [&] { return L->pending == 0; });
+    }
+    // from here on the lane's workers are idle: its fields are this thread's
+    struct Release { prt_multi * m; MultiLane * L; ~Release() { std::lock_guard<std::mutex> lk(m->mu); L->busy = false; } } release = { m, L };
     for (unsigned int g = 0; g < n; ++g)
-        if (rc[g]) { m->error = err[g]; return rc[g]; }
+        if (L->rc[g]) { m->error = L->err[g]; multi_quiesce(m); return L->rc[g]; }
+    prt_ctx * c0 = L->ctx[0];
+    const size_t n_px = (size_t)L->width * L->height;
     MULTI_TRY(m, hipSetDevice(c0->device));
-    for (unsigned int g = 0; g < n; ++g) MULTI_TRY(m, hipStreamWaitEvent(c0->stream, m->done[g], 0));
-    if (n_px) {
-        hipLaunchKernelGGL(k_assemble_shards, dim3((unsigned int)((n_px + 255) / 256)), dim3(256), 0, c0->stream, m->staging.p, m->frame.p,
-                           width, height, (unsigned int)PRT_MULTI_BLOCK_ROWS, n, max_rows);
-        MULTI_TRY(m, hipGetLastError());
-        MULTI_TRY(m, hipMemcpyAsync(rgba_out, m->frame.p, n_px * sizeof(float4), hipMemcpyDeviceToHost, c0->stream));
+    if (n == 1) {
+        // one device: its "shard" is the frame (the render call returned with its stream drained)
+        if (n_px) MULTI_TRY(m, hipMemcpy(L->rgba_out, L->shard[0].p, n_px * sizeof(float4), hipMemcpyDeviceToHost));
+    } else {
+        const uint32_t max_rows = prt_shard_rows(L->height, PRT_MULTI_BLOCK_ROWS, 0, n);
+        for (unsigned int g = 0; g < n; ++g) MULTI_TRY(m, hipStreamWaitEvent(c0->stream, L->done[g], 0));
+        if (n_px) {
+            hipLaunchKernelGGL(k_assemble_shards, dim3((unsigned int)((n_px + 255) / 256)), dim3(256), 0, c0->stream, L->staging.p, L->frame.p,
+                               L->width, L->height, (unsigned int)PRT_MULTI_BLOCK_ROWS, n, max_rows);
+            MULTI_TRY(m, hipGetLastError());
+            MULTI_TRY(m, hipMemcpyAsync(L->rgba_out, L->frame.p, n_px * sizeof(float4), hipMemcpyDeviceToHost, c0->stream));
+        }
+        MULTI_TRY(m, hipStreamSynchronize(c0->stream));
     }
-    MULTI_TRY(m, hipStreamSynchronize(c0->stream));
     if (counters) {
         prt_counters sum;
         memset(&sum, 0, sizeof(sum));
         for (unsigned int g = 0; g < n; ++g) {
-            sum.ray_count += ctr[g].ray_count; sum.node_visits += ctr[g].node_visits; sum.tri_tests += ctr[g].tri_tests;
-            sum.shaded_hits += ctr[g].shaded_hits; sum.trace_kernel_launches += ctr[g].trace_kernel_launches;
-            sum.render_ms = std::max(sum.render_ms, ctr[g].render_ms);                   // the devices run concurrently
-            sum.trace_kernel_ms = std::max(sum.trace_kernel_ms, ctr[g].trace_kernel_ms);
-            sum.pipeline = ctr[g].pipeline;
+            const prt_counters & c = L->ctr[g];
+            sum.ray_count += c.ray_count; sum.node_visits += c.node_visits; sum.tri_tests += c.tri_tests;
+            sum.shaded_hits += c.shaded_hits; sum.trace_kernel_launches += c.trace_kernel_launches;
+            sum.render_ms = std::max(sum.render_ms, c.render_ms);                   // the devices run concurrently
+            sum.trace_kernel_ms = std::max(sum.trace_kernel_ms, c.trace_kernel_ms);
+            sum.pipeline = c.pipeline;
         }
         *counters = sum;
     }
     return 0;
+    PRT_API_CATCH_RC_MULTI(m, "prt_multi_wait")
+}
+
+int prt_multi_render(prt_multi * m, const prt_camera * cam, const prt_params * params, uint32_t width, uint32_t height,
+                     float * rgba_out, prt_counters * counters) {
+    PRT_API_TRY
+    uint64_t ticket = 0;
+    const int rc = prt_multi_submit(m, cam, params, width, height, rgba_out, &ticket);
+    if (rc) return rc;
+    return prt_multi_wait(m, ticket, counters);
+    PRT_API_CATCH_RC_MULTI(m, "prt_multi_render")
+}
+
+// Test hook of the exception guard (tests/test_host_side.py): throws the given kind of C++ exception inside a guarded
+// entry point and returns what the caller of any entry point would get.  ctx may be NULL (no GPU needed).
+int prt_debug_throw(prt_ctx * ctx, int kind) {
+    PRT_API_TRY
+    if (kind == 1) throw std::bad_alloc();
+    if (kind == 2) { std::vector<float> v; v.resize(v.max_size() + 1); return (int)v.size(); }     // the real thing: std::length_error
+    if (kind == 3) throw std::runtime_error("thrown on request");
+    if (kind == 4) throw 42;
+    return 0;
+    PRT_API_CATCH_RC(ctx, "prt_debug_throw")
 }
 
 }  // extern "C"

@@ -18,6 +18,7 @@
 
 #include "../../include/prt_host.h"
 #include "prt_scene.h"
+#include "host_guard.h"
 #include "scene_flatten.h"
 
 RenderReport gLastRenderReport;
@@ -113,7 +114,15 @@ extern "C" u64 prt_host_scene_id(const prt_host_scene * hs);
 extern "C" int prt_host_render(const prt_host_scene * scene, const prt_camera * cam, const prt_params * params, uint32_t width,
                                uint32_t height, int n_gpus, float * rgba_out, prt_counters * counters) {
     if (!scene || !cam || !params || !rgba_out) return -1;
-    return RenderFlat(prt_host_scene_id(scene), prt_host_scene_desc(scene), cam, params, width, height, n_gpus, rgba_out, counters);
+    std::string err;
+    try {
+        return RenderFlat(prt_host_scene_id(scene), prt_host_scene_desc(scene), cam, params, width, height, n_gpus, rgba_out, counters);
+    } catch (...) {
+        // nothing leaves a C entry point as an exception (host_guard.h); RenderFlat's lock is released by now
+        HostApiException(&err, "prt_host_render");
+    }
+    try { std::lock_guard<std::mutex> lock(gRenderMutex); gRenderError = err; } catch (...) {}
+    return -12;
 }
 
 extern "C" const char * prt_host_render_error(void) {

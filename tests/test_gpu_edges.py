@@ -299,6 +299,44 @@ def test_multi_device_handle_gathers_on_the_device_and_matches_one_device():
                 assert lib.prt_multi_render(m, C.byref(cam), C.byref(p), w, h, out.ctypes.data, C.byref(ctr)) == 0, lib.prt_multi_last_error(m)
                 assert ctr.ray_count == wc.ray_count
                 assert np.array_equal(out.view(np.uint32), want.view(np.uint32)), n
+            # ---- the two-deep form: frame k + 1 is submitted while frame k is still in flight; persistent workers, clones of
+            # the contexts for the second lane.  Two different frames (seeds), so that a mix-up of lanes would show.
+            assert lib.prt_multi_depth(m) == 2
+            p2 = api.default_params(3, 100)
+            outs = [np.zeros((h * w, 4), dtype=np.float32) for _ in range(2)]
+            tickets = [C.c_uint64(0), C.c_uint64(0)]
+            assert lib.prt_multi_submit(m, C.byref(cam), C.byref(p), w, h, outs[0].ctypes.data, C.byref(tickets[0])) == 0, lib.prt_multi_last_error(m)
+            assert lib.prt_multi_submit(m, C.byref(cam), C.byref(p2), w, h, outs[1].ctypes.data, C.byref(tickets[1])) == 0, lib.prt_multi_last_error(m)
+            assert tickets[0].value != tickets[1].value
+            spare = C.c_uint64(0)
+            assert lib.prt_multi_submit(m, C.byref(cam), C.byref(p), w, h, out.ctypes.data, C.byref(spare)) == -11      # both lanes busy
+            assert b"in flight" in lib.prt_multi_last_error(m)
+            assert lib.prt_multi_upload_scene(m, hs.desc) == -11                                                        # not under a frame
+            c2 = capi.PrtCounters()
+            assert lib.prt_multi_wait(m, tickets[1], C.byref(c2)) == 0, lib.prt_multi_last_error(m)                     # any order
+            assert lib.prt_multi_wait(m, tickets[0], C.byref(ctr)) == 0, lib.prt_multi_last_error(m)
+            assert lib.prt_multi_wait(m, tickets[0], None) == -1                                                        # already collected
+            assert ctr.ray_count == wc.ray_count and np.array_equal(outs[0].view(np.uint32), want.view(np.uint32)), n
+            assert c2.ray_count != wc.ray_count and not np.array_equal(outs[1].view(np.uint32), want.view(np.uint32))
+            if n == 3:
+                r2 = api.Renderer(0)
+                r2.upload(hs)
+                want2, wc2 = r2.render(cam, p2, w, h)
+                r2.close()
+                assert c2.ray_count == wc2.ray_count and np.array_equal(outs[1].view(np.uint32), want2.view(np.uint32))
+            # a stream of frames through both lanes
+            for k in range(6):
+                t = C.c_uint64(0)
+                assert lib.prt_multi_submit(m, C.byref(cam), C.byref(p), w, h, outs[k & 1].ctypes.data, C.byref(t)) == 0
+                if k:
+                    assert lib.prt_multi_wait(m, prev, C.byref(ctr)) == 0 and ctr.ray_count == wc.ray_count
+                    assert np.array_equal(outs[(k - 1) & 1].view(np.uint32), want.view(np.uint32))
+                prev = t
+            assert lib.prt_multi_wait(m, prev, None) == 0
+            # a re-upload drops and re-creates the second lane's clones
+            assert lib.prt_multi_upload_scene(m, hs.desc) == 0, lib.prt_multi_last_error(m)
+            assert lib.prt_multi_render(m, C.byref(cam), C.byref(p), w, h, out.ctypes.data, C.byref(ctr)) == 0
+            assert np.array_equal(out.view(np.uint32), want.view(np.uint32))
         finally:
             lib.prt_multi_destroy(m)
     assert not lib.prt_multi_create(None, 0)
@@ -365,6 +403,31 @@ def test_park_lists_sized_for_a_few_pixels_with_many_shadow_rays():
         r.close()
     assert gc.ray_count == wc.ray_count
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+def test_park_lists_are_judged_pass_by_pass():
+    """A call that runs in several passes clamps its park lists to each pass's own worst case.  Round 3 compared the call's
+    largest demand with the LAST pass's clamp: a long first pass that parked nearly every ray (two-entry stack columns over
+    coincident geometry) followed by a 64-pixel last pass was reported as an overflow that no enlargement could cure, and the
+    call failed with -7 after four attempts.  The device now decides per launch, against that launch's capacities."""
+    from par_raytracer_amd import api
+    w, h = 160, 120
+    s, hs, cam = _setup("coincident", w, h)
+    p = api.default_params(4, 31, bounce_depth=3, pipeline=PIPELINES["pool"])
+    r = api.Renderer(0)
+    try:
+        r.upload(hs)
+        want, wc = r.render(cam, p, w, h)
+        r.set_option("STACK_CAP", 2)
+        r.set_option("PASS_SAMPLES", (w * h - 64) * 4)              # two passes: all but 64 pixels, then 64 pixels
+        got, gc = r.render(cam, p, w, h)
+        st = r.render_stats()
+        r.set_option("POOL_PARK_CAP", 8)                             # and with lists that really are too short at first
+        got2, gc2 = r.render(cam, p, w, h)
+    finally:
+        r.close()
+    assert gc.trace_kernel_launches == 2 and gc.ray_count == wc.ray_count == gc2.ray_count
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32)) and np.array_equal(got2.view(np.uint32), want.view(np.uint32))
 
 
 def test_near_tie_resolution_that_gives_up_is_reported():

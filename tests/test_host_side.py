@@ -34,7 +34,7 @@ def test_hip_library_exports_every_declared_symbol():
     assert set(names) == set(capi.PRT_SYMBOLS), "capi.PRT_SYMBOLS out of sync with include/prt.h"
     for n in names:
         assert hasattr(lib, n), "libprt_hip.so does not export %s" % n
-    assert lib.prt_abi_version() == 4
+    assert lib.prt_abi_version() == 5
 
 
 def test_host_library_exports_every_declared_symbol():
@@ -96,6 +96,68 @@ def test_error_paths_without_a_gpu_or_scene():
     lib.prt_multi_destroy(None)
     assert lib.prt_set_option(None, b"STACK_CAP", b"2") == -1
     assert lib.prt_build_flags() & ~(capi.BUILD_EXPERIMENTAL | capi.BUILD_BVH4) == 0
+    # the two-deep form of the n-device handle
+    assert lib.prt_multi_depth(None) == 0
+    assert lib.prt_multi_submit(None, None, None, 1, 1, None, None) == -1
+    assert lib.prt_multi_wait(None, 1, None) == -1
+
+
+def test_no_cpp_exception_leaves_an_entry_point():
+    """include/prt.h: "nothing aborts".  The libraries are C++ (std::vector, std::string, std::thread, new) behind extern "C":
+    an exception that left an entry point would be std::terminate in the CALLER's process - round 3 lost a GPU test run to an
+    abort whose message pytest's capture swallowed.  Every entry point that can allocate now runs under a
+    guard; the hook throws inside one - std::bad_alloc, a REAL std::length_error from a vector asked for more than max_size,
+    std::runtime_error, a non-std exception - and must come back with PRT_ERR_EXCEPTION (-12) and a message, in both
+    libraries.  Run in a child process as well: if the guard were missing this is the test that would abort."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from par_raytracer_amd import capi\n"
+            "hip, host = capi.hip_lib(), capi.host_lib()\n"
+            "host.prt_host_last_error.restype = __import__('ctypes').c_char_p\n"
+            "for kind, word in ((1, b'bad_alloc'), (2, b'C++ exception'), (3, b'thrown on request'), (4, b'unknown C++ exception')):\n"
+            "    assert hip.prt_debug_throw(None, kind) == -12, kind\n"
+            "    assert word in hip.prt_last_error(None), (kind, hip.prt_last_error(None))\n"
+            "    assert host.prt_host_debug_throw(kind) == -12, kind\n"
+            "    assert word in host.prt_host_last_error(), (kind, host.prt_host_last_error())\n"
+            "assert hip.prt_debug_throw(None, 0) == 0 and host.prt_host_debug_throw(0) == 0\n"
+            "print('guarded')\n") % ROOT
+    out = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert out.returncode == 0 and b"guarded" in out.stdout, (out.returncode, out.stderr.decode()[-2000:])
+    # and in this process
+    lib = capi.hip_lib()
+    assert lib.prt_debug_throw(None, 1) == -12 and b"bad_alloc" in lib.prt_last_error(None)
+
+
+def test_every_extern_c_function_with_a_body_is_guarded():
+    """Source-level check that goes with the test above: in csrc/prt_api.hip and host/host_capi.cpp every extern "C" function
+    whose body is more than a one-line accessor opens with the guard macro."""
+    def bodies(path, prefix):
+        text = open(path).read()
+        out = {}
+        for m in re.finditer(r"^[A-Za-z_][\w \*]*\b(%s\w+)\(" % prefix, text, flags=re.M):
+            i = text.index("(", m.start())
+            depth = 0
+            while True:
+                depth += {"(": 1, ")": -1}.get(text[i], 0)
+                if depth == 0:
+                    break
+                i += 1
+            rest = text[i + 1:].lstrip()
+            if not rest.startswith("{"):
+                continue                                        # a declaration
+            out[m.group(1)] = rest[1:200]
+        return out
+    hip = bodies(os.path.join(ROOT, "par_raytracer_amd", "csrc", "prt_api.hip"), "prt_")
+    host = bodies(os.path.join(ROOT, "par_raytracer_amd", "host", "host_capi.cpp"), "prt_host_")
+    accessors = {"prt_abi_version", "prt_build_flags", "prt_last_error", "prt_shard_rows", "prt_multi_last_error", "prt_multi_device_count",
+                 "prt_multi_depth", "prt_multi_context", "prt_host_last_error", "prt_host_scene_desc", "prt_host_scene_id",
+                 "prt_host_scene_hierarchy_seconds", "prt_host_scene_parse_seconds", "prt_host_free_texture"}
+    assert len(hip) >= 24 and len(host) >= 8
+    for name, body in list(hip.items()) + list(host.items()):
+        if name in accessors:
+            continue
+        assert body.lstrip().startswith(("PRT_API_TRY", "HOST_API_TRY")), "%s has no exception guard" % name
 
 
 def test_shard_rows_partition_the_frame():
