@@ -130,6 +130,91 @@ def launch_ranks(n):
     return rc
 
 
+REF_BIN = os.path.join(ROOT, "oracle", "_ref", "ref_harness")
+
+
+def physical_cpus_socket0():
+    """One logical CPU per physical core of socket 0 (no torch, no oracle import: runs before anything touches the GPU)."""
+    seen, cpus = set(), []
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+    except Exception:
+        allowed = list(range(os.cpu_count() or 1))
+    for c in allowed:
+        base = "/sys/devices/system/cpu/cpu%d/topology/" % c
+        try:
+            pkg = int(open(base + "physical_package_id").read())
+            core = int(open(base + "core_id").read())
+        except Exception:
+            pkg, core = 0, c
+        if pkg != 0 or (pkg, core) in seen:
+            continue
+        seen.add((pkg, core))
+        cpus.append(c)
+    return cpus or allowed[:1]
+
+
+def time_reference_on_host(obj_dir, cam_pos, cam_dir, fov, width, height, spp, depth, core_seconds, lattice_arg):
+    """cpu_baseline kind "reference": the UNMODIFIED reference (oracle/_ref/ref_harness = /root/reference/main.cpp compiled
+    in the build container with build.sh:6's flags; the binary travels to the GPU box, the sources do not) on a sparse pixel
+    lattice of the SAME frame, one process per physical core of socket 0, each pinned, each rendering the lattice rows
+    ly % T == k - the reference's own scaling model (one MPI rank per core, main.cpp:311-347).  Runs BEFORE this process
+    imports torch or touches HIP: the children are started by a process that has not initialised the GPU.
+    Returns None when the binary is absent or does not run here (the port is the baseline then)."""
+    import subprocess
+    if not os.path.exists(REF_BIN):
+        return None
+    cpus = physical_cpus_socket0()[:64]
+    T = len(cpus)
+    base = [REF_BIN, "-w", str(width), "-h", str(height), "--fov", repr(float(fov)),
+            "--camera_position"] + [repr(float(v)) for v in cam_pos] + ["--camera_facing"] + [repr(float(v)) for v in cam_dir] + \
+           ["--bounce_depth", str(depth), "--reflection_samples", "1", "--specular_samples", "1",
+            "-d", obj_dir.rstrip("/") + "/", "--obj", "scene.obj", "--spp", str(spp), "--seed", str(SEED), "--light-mode", "0"]
+    tmp = tempfile.mkdtemp(prefix="prt_bench_ref_")
+
+    def run(lattice, procs):
+        ps = []
+        for k in range(procs):
+            cmd = base + ["--lattice", str(lattice), "--rows", str(k), str(procs), "--stats", os.path.join(tmp, "s%d.json" % k),
+                          "--out", os.path.join(tmp, "o%d.f32" % k)]
+            cpu = cpus[k % T]
+            ps.append(subprocess.Popen(cmd, cwd=tmp, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE,
+                                       preexec_fn=(lambda c=cpu: os.sched_setaffinity(0, {c}))))
+        stats, img = [], None
+        for k, pr in enumerate(ps):
+            _, err = pr.communicate(timeout=3600)
+            if pr.returncode != 0:
+                raise RuntimeError("ref_harness exited %d: %s" % (pr.returncode, err.decode()[-500:]))
+            with open(os.path.join(tmp, "s%d.json" % k)) as f:
+                st = json.load(f)
+            stats.append(st)
+            part = np.fromfile(os.path.join(tmp, "o%d.f32" % k), dtype=np.float32).reshape(st["lattice_height"], st["lattice_width"], 4)
+            if img is None:
+                img = np.zeros_like(part)
+            img[k::procs] = part[k::procs]
+        return stats, img
+
+    try:
+        lattice = lattice_arg
+        if lattice <= 0:
+            probe = max(8, int(round((width * height / 400.0) ** 0.5)))
+            st, _ = run(probe, 1)                                  # ~400 pixels on one core: seconds
+            px = st[0]["lattice_width"] * st[0]["lattice_height"]
+            per_px = st[0]["render_seconds"] / max(1, px)
+            lattice = int(max(1, min(probe, round((width * height / (core_seconds / max(per_px, 1e-9))) ** 0.5))))
+        t0 = time.perf_counter()
+        stats, img = run(lattice, T)
+        wall = time.perf_counter() - t0
+    except Exception as e:                                         # not runnable here (no MPI library, ...): fall back to the port
+        log("reference binary present but not usable here (%r): cpu_baseline falls back to the port" % (e,))
+        return None
+    rays = sum(s["ray_count"] for s in stats)
+    render_s = max(s["render_seconds"] for s in stats)            # the ranks run side by side: the slowest one ends the frame
+    return {"lattice": lattice, "image": img, "ray_count": int(rays), "render_seconds": float(render_s), "wall_seconds_with_scene_load": float(wall),
+            "cores": T, "cpus": cpus, "core_seconds": float(sum(s["render_seconds"] for s in stats)),
+            "sphere_check_count": int(sum(s["sphere_check_count"] for s in stats)), "mesh_check_count": int(sum(s["mesh_check_count"] for s in stats))}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -139,6 +224,10 @@ def main():
     ap.add_argument("--pipeline", type=int, default=0)
     ap.add_argument("--cpu-lattice", type=int, default=0, help="lattice stride of the CPU baseline (0 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline", default="auto", choices=["auto", "reference", "port"],
+                    help="what is timed on the host cores: the unmodified reference (oracle/_ref/ref_harness, one pinned process per "
+                         "core) or the CPU restatement (oracle/prt_oracle.cpp, one pinned thread per core); auto = the reference "
+                         "where its binary is present and runs, else the port")
     ap.add_argument("--cpu-seconds", type=float, default=120.0, help="CPU work of the baseline sample in core-seconds (the lattice is chosen to match)")
     ap.add_argument("--no-other-workloads", action="store_true", help="skip extra.other_workloads (C2, C3, C5, C4-adaptive)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -180,6 +269,26 @@ def main():
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
 
+    scene_name, width, height, spp, depth, descr = WORKLOADS[args.workload]
+    # ---- the reference itself, timed on this host's cores (N = 1 only) - BEFORE torch / HIP are touched: its processes are
+    # children of a process that has not initialised the GPU
+    pre = None
+    ref_run = None
+    if world == 1 and rank == 0 and not collective:
+        from par_raytracer_amd import scenes as _scenes
+        t0 = time.time()
+        _sc = _scenes.make_scene(scene_name)
+        _dir = tempfile.mkdtemp(prefix="prt_bench_%s_" % scene_name)
+        _scenes.write_obj(_sc, _dir, "scene.obj")
+        pre = (_dir, list(_sc.camera_position), list(_sc.camera_facing), float(_sc.fov), time.time() - t0)
+        if not args.no_cpu_baseline and args.cpu_baseline in ("auto", "reference"):
+            ref_run = time_reference_on_host(_dir, pre[1], pre[2], pre[3], width, height, spp, depth, args.cpu_seconds, args.cpu_lattice)
+            if ref_run is None and args.cpu_baseline == "reference":
+                raise SystemExit("--cpu-baseline reference: oracle/_ref/ref_harness is missing or does not run on this host")
+            if ref_run:
+                log("reference on %d pinned cores: lattice %d, %d rays in %.1f s (%.4f Mrays/s)" % (
+                    ref_run["cores"], ref_run["lattice"], ref_run["ray_count"], ref_run["render_seconds"], ref_run["ray_count"] / ref_run["render_seconds"] / 1e6))
+
     import torch
     import torch.distributed as dist
 
@@ -212,11 +321,12 @@ def main():
         # (torch streams are non-blocking), so the frames in flight never serialise against it.
         torch.cuda.set_stream(torch.cuda.Stream(device=dev))
 
-    scene_name, width, height, spp, depth, descr = WORKLOADS[args.workload]
-
     # ---- scene: rank 0 writes the OBJ once, every rank loads it (as every MPI rank of the reference does)
     t0 = time.time()
-    if rank == 0:
+    if pre is not None:
+        meta = list(pre[:4])
+        t0 -= pre[4]
+    elif rank == 0:
         scene = scenes.make_scene(scene_name)
         obj_dir = tempfile.mkdtemp(prefix="prt_bench_%s_" % scene_name)
         scenes.write_obj(scene, obj_dir, "scene.obj")
@@ -464,7 +574,7 @@ def main():
         cpus = cpus[:64]
         cores = len(cpus)
         orc.set_worker_cpus(cpus)
-        lattice = args.cpu_lattice
+        lattice = ref_run["lattice"] if ref_run else args.cpu_lattice      # the reference's lattice, when it ran: same pixels for all three
         if lattice <= 0:
             # a bounded sample: --cpu-seconds core-seconds of CPU work (default 40).  Probe a very sparse lattice first, then scale.
             probe = max(8, int(round((width * height / 400.0) ** 0.5)))
@@ -480,7 +590,7 @@ def main():
         cpu_baseline = {"value": round(cpu_mrays, 4), "unit": "Mrays/s", "cores": cores, "kind": "port",
                         "cpu_model": cpu_model, "pinned_to_cpus": cpus,
                         "pinned_to": "tests/test_oracle_golden.py: the port reproduces the compiled, unmodified reference bit for bit "
-                                     "(float framebuffer and all three DebugCounters) on 26 fixtures; the reference itself never leaves the build container",
+                                     "(float framebuffer and all three DebugCounters) on 26 fixtures; the reference binary (oracle/_ref) was absent or did not run on this host, so the port stands in for it",
                         "sample": "every %dth pixel in x and y of the same %dx%d x %d spp frame (%d pixels, %d rays, %.1f s wall on %d pinned threads = %.0f core-seconds)" % (
                             lattice, width, height, spp, cpu_img.shape[0] * cpu_img.shape[1], octr.ray_count, octr.render_seconds, cores,
                             octr.render_seconds * cores),
@@ -488,7 +598,31 @@ def main():
         parity = {"pixels": int(cpu_img.shape[0] * cpu_img.shape[1]), "max_abs_diff_rgb": float(diff.max()),
                   "pixels_over_1e-4": int((diff.max(axis=2) > 1e-4).sum()),
                   "ray_count_gpu": int(gctr.ray_count), "ray_count_cpu": int(octr.ray_count),
-                  "ray_count_equal": bool(gctr.ray_count == octr.ray_count)}
+                  "ray_count_equal": bool(gctr.ray_count == octr.ray_count), "against": "port"}
+        if ref_run:
+            # the unmodified reference ran on this host before the GPU was touched (time_reference_on_host): IT is the baseline
+            # and the parity reference; the port, on the same lattice, is checked against it once more - at the headline's size
+            ref_img = ref_run["image"]
+            ref_mrays = ref_run["ray_count"] / ref_run["render_seconds"] / 1e6
+            port_record = {"value": cpu_baseline["value"], "cores": cores, "speedup_gpu_over_cpu": cpu_baseline["speedup_gpu_over_cpu"],
+                           "equals_reference_bitwise": bool(np.array_equal(ref_img.view(np.uint32), cpu_img.view(np.uint32))),
+                           "ray_count_equals_reference": bool(int(octr.ray_count) == ref_run["ray_count"])}
+            cpu_baseline = {"value": round(ref_mrays, 4), "unit": "Mrays/s", "cores": ref_run["cores"], "kind": "reference",
+                            "cpu_model": cpu_model, "pinned_to_cpus": ref_run["cpus"],
+                            "what": "oracle/_ref/ref_harness: /root/reference/main.cpp compiled unmodified in the build container (oracle/Makefile, "
+                                    "build.sh:6's flags, real MPI header); one process per physical core of socket 0, each pinned and rendering "
+                                    "the lattice rows ly % cores == k - the reference's own model of one rank per core (main.cpp:311-347)",
+                            "sample": "every %dth pixel in x and y of the same %dx%d x %d spp frame (%d pixels, %d rays; slowest process %.1f s, all "
+                                      "processes %.0f core-seconds; %.1f s wall with every process's OBJ parse and BuildHierarchy)" % (
+                                          lattice, width, height, spp, ref_img.shape[0] * ref_img.shape[1], ref_run["ray_count"], ref_run["render_seconds"],
+                                          ref_run["core_seconds"], ref_run["wall_seconds_with_scene_load"]),
+                            "speedup_gpu_over_cpu": round(value / ref_mrays, 1) if ref_mrays > 0 else None,
+                            "port_on_the_same_lattice": port_record}
+            dref = np.abs(gpu_img[:, :, :3] - ref_img[:, :, :3])
+            parity = {"pixels": int(ref_img.shape[0] * ref_img.shape[1]), "max_abs_diff_rgb": float(dref.max()),
+                      "pixels_over_1e-4": int((dref.max(axis=2) > 1e-4).sum()),
+                      "ray_count_gpu": int(gctr.ray_count), "ray_count_cpu": int(ref_run["ray_count"]),
+                      "ray_count_equal": bool(int(gctr.ray_count) == ref_run["ray_count"]), "against": "reference"}
 
     # ---- the other BASELINE configs, in the same run: time a few frames, check a lattice against the reference's own pixels
     other = None

@@ -3,8 +3,9 @@
 // TEST INFRASTRUCTURE ONLY.  This translation unit textually includes /root/reference/main.cpp
 // (via -I, nothing is copied into this repository) with `main` renamed, then calls the reference's
 // own InitParams / MakeCamera / ParseOBJ / CalculateTangents / BuildHierarchy / InitScene /
-// MakeMaterial / RenderPixel.  It exists only in the build container: /root/reference does not
-// exist on the GPU box and neither the product nor bench.py's timed legs depend on it.
+// MakeMaterial / RenderPixel.  It is BUILT only in the build container (/root/reference does not exist on the GPU box); the
+// binary travels there as a checker, and since round 4 bench.py times it on the GPU box's host cores (cpu_baseline kind
+// "reference", one pinned process per core: --rows k n) beside the port.  The product never depends on it.
 //
 // What it adds on top of the reference:
 //   * fixed samples-per-pixel: RenderSharedData{min_samples = max_samples = 1} and one RenderPixel
@@ -74,6 +75,9 @@ struct HarnessArgs {
     const char * stats = NULL;
     const char * dump_desc = NULL;
     const char * write_png = NULL;
+    u32 rows_k = 0, rows_n = 1;      // --rows k n: render only the lattice rows ly with ly % n == k (the others stay zero): n processes,
+                                     // one per core, are how bench.py times the reference on all cores of the GPU box's host, as
+                                     // `mpirun -n N` runs the reference's own ranks side by side (main.cpp:311-347)
 };
 
 HarnessArgs ParseHarnessArgs(int argc, char ** argv) {
@@ -93,6 +97,7 @@ HarnessArgs ParseHarnessArgs(int argc, char ** argv) {
         else if (s == "--stats" && has_val) a.stats = argv[++i];
         else if (s == "--dump-desc" && has_val) a.dump_desc = argv[++i];
         else if (s == "--write-png" && has_val) a.write_png = argv[++i];
+        else if (s == "--rows" && i + 2 < argc) { a.rows_k = (u32)atoi(argv[++i]); a.rows_n = (u32)atoi(argv[++i]); if (a.rows_n < 1) a.rows_n = 1; }
     }
     return a;
 }
@@ -448,6 +453,7 @@ int main(int argc, char ** argv) {
         std::vector<Vector4> pixels((size_t)lw * lh);
         double t0 = NowSeconds();
         for (u32 ly = 0; ly < lh; ++ly) {
+            if (ly % args.rows_n != args.rows_k) continue;
             for (u32 lx = 0; lx < lw; ++lx) {
                 u32 x = lx * args.lattice, y = ly * args.lattice;
                 u32 pixel = y * w + x;

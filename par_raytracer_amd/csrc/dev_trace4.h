@@ -154,12 +154,27 @@ PRT_D void cswap(float & ka, float & kb, int & la, int & lb) {
 //   plane = origin + q * 2^e  =>  t = (plane - o -+ pad) / d = q * (2^e / d) + (origin / d - (o +- pad) / d)
 // so after 3 scale products and 6 FMAs per node every plane costs one byte->float convert and one FMA.
 // The slab test may use FMA: it only has to be conservative, and the boxes are widened by `pad`.
+// Experiment PRT_TOP_LDS = n (round 4, the north star's "BVH nodes staged through LDS" on the production kernel): the first n
+// nodes of the breadth-first array - the top levels every ray walks - live in a workgroup LDS table `top` and a step at one of
+// them reads LDS instead of the vector L1.  Measured in profiles/r04_ab_top_levels_in_lds.txt; not in the shipped build.
+#if defined(PRT_TOP_LDS)
+enum { TRAV_TOP_LDS_NODES = PRT_TOP_LDS };
+#else
+enum { TRAV_TOP_LDS_NODES = 0 };
+#endif
+
 template <class STK, bool COUNT>
-PRT_D void trav_node_step(const DevScene & sc, TravRay & r, const STK & stk, TraceStats & st, float pad) {
+PRT_D void trav_node_step(const DevScene & sc, TravRay & r, const STK & stk, TraceStats & st, float pad, const uint4 * top = nullptr) {
     // 32-bit byte offset from the (scalar) array base: the loads take the SGPR-base + VGPR-offset form and no 64-bit address is
     // built per lane (-0.7 % frame time; upload caps the scene at 2^26 triangles, so nodes * 64 and triangles * 48 fit)
     const uint4 * np = reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(sc.nodes) + ((unsigned int)r.node << 6));
-    const uint4 w0 = np[0], w1 = np[1], w2 = np[2], w3 = np[3];
+    uint4 w0, w1, w2, w3;
+    if (TRAV_TOP_LDS_NODES > 0 && top && r.node < (int)TRAV_TOP_LDS_NODES) {
+        const uint4 * tp = top + 4 * r.node;
+        w0 = tp[0]; w1 = tp[1]; w2 = tp[2]; w3 = tp[3];
+    } else {
+        w0 = np[0]; w1 = np[1]; w2 = np[2]; w3 = np[3];
+    }
     if (COUNT) { st.nodes++; if (first_active_lane()) st.wnodes++; if ((unsigned int)r.sp > st.max_sp) st.max_sp = (unsigned int)r.sp; }
 #ifdef PRT_PROBE_EXTRA_LOAD
     // sensitivity probe (tools/ab_probe.sh): one more divergent vector-memory instruction per node step

@@ -38,6 +38,7 @@ enum { STACK_ENTRY_INTS = 2, BVH_NODE_BYTES = 80, STACK_LDS_CAP_DEFAULT = 13 };
 #define PRT_BVH8_STRIDE 80
 #endif
 enum { BVH_NODE_STRIDE = PRT_BVH8_STRIDE };
+enum { TRAV_TOP_LDS_NODES = 0 };          // the top-levels-in-LDS experiment exists for the 4-wide tree only (dev_trace4.h)
 
 // Per-lane traversal registers.  A ray can be suspended and resumed at any step boundary.
 struct TravRay {
@@ -182,7 +183,7 @@ PRT_D unsigned int trav_pick_slot(unsigned int rest, unsigned int oct) {
 //   plane = origin + q * 2^e  =>  t = (plane - o -+ pad) / d = q * (2^e / d) + (origin / d - (o +- pad) / d)
 // The slab test may use FMA: it only has to be conservative, and the boxes are widened by `pad`.
 template <class STK, bool COUNT>
-PRT_D void trav_node_step(const DevScene & sc, TravRay & r, const STK & stk, TraceStats & st, float pad) {
+PRT_D void trav_node_step(const DevScene & sc, TravRay & r, const STK & stk, TraceStats & st, float pad, const uint4 * /*top: dev_trace4.h's PRT_TOP_LDS experiment*/ = nullptr) {
     // 32-bit byte offset from the (scalar) array base (upload caps the scene at 2^26 triangles)
     const uint4 * np = reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(sc.nodes) + (unsigned int)r.node * (unsigned int)BVH_NODE_STRIDE);
     const uint4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3], q4 = np[4];

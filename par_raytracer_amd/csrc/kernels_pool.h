@@ -45,6 +45,7 @@ struct PoolBuffers {
     unsigned int * head;         // global sample counter (adopting launch: counter into the park list)
     unsigned int cap, scap;      // slots per unit (a wave; a workgroup when the pools are block-shared); multiples of 64
     unsigned int topup_min;      // top up when at least this many slots are free
+    unsigned int topup_max;      // ... and take at most this many samples at once (experiment POOL_FAIR: one fair share per unit)
     // Rays the fast kernel (EXACT = false) cannot finish - the hit has company within a few ulp and the reference's visit order
     // decides (dev_trace.h resolve_near_ties), or a push did not fit the LDS stack column - are PARKED, list entry and all,
     // and dropped from the pool.  After the fast kernel: k_pool_parked_shadows traces the parked shadow rays exactly and adds
@@ -236,10 +237,17 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_pool(const PoolArgs * args, De
     __shared__ DevLight s_lights[LDS_LIGHTS];
     __shared__ unsigned long long s_red[2];
     __shared__ unsigned int s_ctl[SHARED ? PCTL_WORDS : 1];
+    // experiment PRT_TOP_LDS (dev_trace4.h): the top of the tree in LDS, for the fast kernel's traversal loop only
+    constexpr int TOPN = EXACT ? 0 : (int)TRAV_TOP_LDS_NODES;
+    __shared__ uint4 s_top[TOPN > 0 ? 4 * TOPN : 1];
     {
         const PoolArgs A0 = pool_args(args);
         const DevScene & sc = A0.sc;
         if (LDSTAB) for (unsigned int k = threadIdx.x; k < 1024u; k += BLOCK) s_diffuse[k] = sc.diffuse_dirs[k];
+        if (TOPN > 0) {
+            const unsigned int n4 = 4u * (sc.node_count < (unsigned int)TOPN ? sc.node_count : (unsigned int)TOPN);
+            for (unsigned int k = threadIdx.x; k < n4; k += BLOCK) s_top[k] = reinterpret_cast<const uint4 *>(sc.nodes)[k];
+        }
         if (sc.material_count <= (unsigned int)LDS_MATS) {
             const float4 * src = reinterpret_cast<const float4 *>(sc.materials);
             float4 * dst = reinterpret_cast<float4 *>(s_mats);
@@ -357,7 +365,8 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_pool(const PoolArgs * args, De
                 }
             }
           } else if (n_c + n_f - n_spec + Q.topup_min <= cap) {
-            const unsigned int want = cap - (n_c + n_f - n_spec);
+            unsigned int want = cap - (n_c + n_f - n_spec);
+            if (want > Q.topup_max) want = Q.topup_max;
             unsigned int base = 0;
             if (SHARED) {
                 if (threadIdx.x == 0) s_ctl[PCTL_TOPUP_BASE] = atomicAdd(Q.head, want);
@@ -479,7 +488,7 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_pool(const PoolArgs * args, De
                     const int nmin = node_min < wfrac ? node_min : wfrac;
                     const unsigned int with_ray = COUNT ? (unsigned int)__popcll(__ballot(true)) : 0u;
                     while (trav_walking(r)) {
-                        trav_node_step<Stack, COUNT>(sc, r, stack, st, P.box_pad);
+                        trav_node_step<Stack, COUNT>(sc, r, stack, st, P.box_pad, TOPN > 0 ? s_top : nullptr);
                         if (COUNT && first_active_lane()) st.wrays += with_ray;
                         if (__popcll(__ballot(trav_walking(r))) < nmin) break;
                     }

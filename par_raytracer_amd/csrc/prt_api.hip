@@ -46,6 +46,9 @@ using namespace prt;
 #ifndef PRT_POOL_BLOCK
 #define PRT_POOL_BLOCK 256        // threads per workgroup of the fixed-spp pool kernel (experiments: 320, 640 with block-shared pools)
 #endif
+#ifndef PRT_DEEP_WAVES
+#define PRT_DEEP_WAVES PRT_POOL_WAVES   // waves per SIMD of the fixed-spp kernel for bounce trees of more than 15 draws (C5)
+#endif
 #ifndef PRT_POOL_WAVES
 #define PRT_POOL_WAVES 5          // waves per SIMD of the fixed-spp pool kernel: 96 VGPRs (6 = 80 VGPRs spills, profiles/r03_ab_bvh8.txt)
 #endif
@@ -178,6 +181,12 @@ struct prt_ctx {
 namespace {
 
 f3 ld3(const float * p) { return mk3(p[0], p[1], p[2]); }
+
+// Dwords of `entries` traversal-stack entries for `lanes` lanes: the ONE place that knows how many dwords an entry of this
+// build's traversal has (STACK_ENTRY_INTS: 1 for the 4-wide tree's links, 2 for the 8-wide tree's (base, masks) pairs).
+// Every stack area - the LDS columns, their spill columns, the exact kernels' full-height global columns - is sized here.
+size_t stack_dwords(size_t entries, size_t lanes) { return entries * lanes * (size_t)STACK_ENTRY_INTS; }
+
 
 // raytracer.cpp:273-288 on the host.
 float radical_inverse_vdc(uint32_t bits) {
@@ -326,7 +335,7 @@ int chain_setup(prt_ctx * ctx, Chain & c, int index, const DevParams & P, bool r
     {
         // k_trace_exact's fixed grid: full-height stack columns for the rays k_trace hands over (near ties, overflowed columns)
         const size_t exact_lanes = 64 * 256;
-        HIP_TRY(ctx, w.slow_stack.ensure((size_t)std::max(ctx->stack_bound, 4u) * exact_lanes * STACK_ENTRY_INTS));
+        HIP_TRY(ctx, w.slow_stack.ensure(stack_dwords(std::max(ctx->stack_bound, 4u), exact_lanes)));
         c.P.exact_stack = w.slow_stack.p;
         c.P.exact_stack_stride = (unsigned int)exact_lanes;
     }
@@ -536,7 +545,7 @@ int launch_pool_kernel(prt_ctx * ctx, unsigned int grid, size_t lds, const PoolA
 template <int BLOCK, int WAVES, bool LDSTAB, bool RING, bool TEX, bool ADAPT, int RINGMEM = 1>
 int launch_pool(prt_ctx * ctx, bool count, const DevCamera & cam, DevParams P, unsigned int n_samples, unsigned int stack_entries) {
     // the stack columns double as the shading phase's frame storage (WFRAME_LDS_DWORDS per lane)
-    const size_t lds = (size_t)std::max(stack_entries * (unsigned int)STACK_ENTRY_INTS, (unsigned int)((RING && RINGMEM == 1) ? WFRAME_LDS_DWORDS : WFRAME_LDS_DWORDS_NOPOS)) * BLOCK * sizeof(int);
+    const size_t lds = std::max(stack_dwords(stack_entries, BLOCK), (size_t)((RING && RINGMEM == 1) ? WFRAME_LDS_DWORDS : WFRAME_LDS_DWORDS_NOPOS) * BLOCK) * sizeof(int);
     const PrtOptions & opt = ctx->opt;
     // Three launches (kernels_pool.h PoolBuffers::park): the fast kernel, which parks the rays it cannot finish - a hit with
     // company within a few ulp, a stack column that overflowed -; k_pool_parked_shadows for the parked shadow rays; the EXACT
@@ -546,10 +555,11 @@ int launch_pool(prt_ctx * ctx, bool count, const DevCamera & cam, DevParams P, u
     int per_cu = 0;
     // Block-shared pools (kernels_pool.h, round 4): the workgroup owns a pool, not the wave.  Option POOL_SHARED: 1 / 0 force it
     // on / off; the EXACT kernels (the adopting launch, POOL_EXACT) always keep wave-private pools.
-    // Default (profiles/r04_ab_shared_pools.txt, same-process A/B): ON for fixed spp - the full C4 frame 1.5 - 2 % faster, its
-    // 1/2 .. 1/16 shards 1.5 - 3.5 % -, OFF for the adaptive mode, whose short rounds lose 11 % to the four waves waiting for
-    // each other at every phase boundary.
-    const bool shared = !exact_only && (opt.pool_shared >= 0 ? opt.pool_shared != 0 : (PRT_POOL_SHARED_DEFAULT != 0 && !ADAPT));
+    // Default (profiles/r04_ab_shared_pools.txt, same-process A/B): ON for the kernel of the default bounce tree (fixed spp, at
+    // most 15 draws per sample, opaque untextured scene: RINGMEM = 0) - the full C4 frame 1.5 - 2 % faster, its 1/2 .. 1/16
+    // shards 1.5 - 3.5 % -; OFF for the adaptive mode, whose short rounds lose 11 % to the four waves waiting for each other at
+    // every phase boundary, and for deep bounce trees (C5: 886 -> 949 ms; that variant spills 59 dwords shared, 31 private).
+    const bool shared = !exact_only && (opt.pool_shared >= 0 ? opt.pool_shared != 0 : (PRT_POOL_SHARED_DEFAULT != 0 && !ADAPT && !TEX && RINGMEM == 0));
     hipError_t oe = exact_only ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_pool<BLOCK, WAVES, LDSTAB, RING, false, TEX, ADAPT, RINGMEM, true, false>, BLOCK, lds)
                   : shared     ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_pool<BLOCK, WAVES, LDSTAB, RING, false, TEX, ADAPT, RINGMEM, false, true>, BLOCK, lds)
                   : count      ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_pool<BLOCK, WAVES, LDSTAB, RING, true, TEX, ADAPT, RINGMEM, false, false>, BLOCK, lds)
@@ -573,6 +583,14 @@ int launch_pool(prt_ctx * ctx, bool count, const DevCamera & cam, DevParams P, u
     // walks the stored samples: 512 160, 256 145, 192 133 - 138, 128 129 - 133, 64 138 ms, profiles/r03_adaptive.txt)
     if (ADAPT) cap = std::min(cap, 128u);
     if (opt.pool_cap >= 0) cap = (unsigned int)std::max(64ll, std::min(4096ll, opt.pool_cap / 64 * 64));
+    // experiment POOL_FAIR = k: every wave's pool holds k / 8 of a fair share and takes at most that at once (8 = the whole
+    // frame resident from the start, no second generation of samples; profiles/r04_ab_shared_pools.txt section 6)
+    unsigned int topup_max = 0xFFFFFFFFu;
+    if (opt.pool_fair > 0) {
+        const unsigned int fair = (unsigned int)(((unsigned long long)n_samples * (unsigned long long)opt.pool_fair / 8ull + waves - 1u) / waves);
+        cap = std::max(64u, std::min(4096u, (fair + 63u) / 64u * 64u));
+        topup_max = std::max(1u, fair);
+    }
     // block-shared: the same slots, owned by the block's waves together (`cap` is per UNIT from here on)
     const unsigned int units = shared ? grid : waves;
     if (shared) cap *= (unsigned int)(BLOCK / 64);
@@ -606,8 +624,8 @@ int launch_pool(prt_ctx * ctx, bool count, const DevCamera & cam, DevParams P, u
     const unsigned int grid2 = exact_only ? grid : std::max(1u, std::min(grid, (unsigned int)ctx->cu_count));
     const size_t exact_lanes = (size_t)POOL_PARKED_SHADOW_BLOCKS * 256, spill_lanes = (size_t)grid2 * BLOCK;
     const size_t spill_entries = ctx->stack_bound > stack_entries ? ctx->stack_bound - stack_entries : 0;
-    const size_t exact_ints = (size_t)std::max(ctx->stack_bound, 4u) * exact_lanes * STACK_ENTRY_INTS;
-    HIP_TRY(ctx, ctx->stack_spill.ensure(exact_ints + spill_entries * spill_lanes * STACK_ENTRY_INTS));
+    const size_t exact_ints = stack_dwords(std::max(ctx->stack_bound, 4u), exact_lanes);
+    HIP_TRY(ctx, ctx->stack_spill.ensure(exact_ints + stack_dwords(spill_entries, spill_lanes)));
     P.exact_stack = ctx->stack_spill.p;
     P.exact_stack_stride = (unsigned int)exact_lanes;
     P.stack_spill = spill_entries ? ctx->stack_spill.p + exact_ints : nullptr;
@@ -655,6 +673,7 @@ int launch_pool(prt_ctx * ctx, bool count, const DevCamera & cam, DevParams P, u
         Q.jobsum = Q.scratch + (size_t)P.max_spp * N;
         Q.final_rgb = Q.jobsum + N;
     }
+    Q.topup_max = topup_max == 0xFFFFFFFFu ? topup_max : topup_max * (shared ? (unsigned int)(BLOCK / 64) : 1u);
     Q.topup_min = ADAPT ? std::max(64u, cap / 2u) : std::max(64u, cap / 4u);
     if (opt.pool_topup >= 0) Q.topup_min = (unsigned int)std::max(1ll, std::min((long long)cap, opt.pool_topup * (shared ? BLOCK / 64 : 1)));   // the option counts per wave
     int keep_min = 40, node_min = 32;
@@ -735,6 +754,44 @@ int build_bvh_lbvh(prt_ctx * ctx, const float * verts, uint32_t n_tris, uint32_t
                               tree.node_box.data(), tree.leaf_box.data(), tree.sorted_ids.data(), bvh, &ctx->opt.bvh);
     if (ctx->opt.debug_util) fprintf(stderr, "[prt] LBVH: %u triangles, radix tree on the device in %.2f ms\n", n_tris, device_ms);
     return 0;
+}
+
+// Every address the traversal kernels will form from the tree is checked HERE, on the host, before the tree is uploaded: a
+// node link or a triangle range outside the arrays would be a wild read on the device - which the runtime reports by
+// aborting the process (the round-3 abort) - and is an upload error instead.  O(nodes), links only;
+// prt_debug_check_bvh is the full geometric check.
+const char * validate_bvh_links(const Bvh4Result & bvh, uint32_t n_tris) {
+    if (bvh.node_count == 0 || bvh.nodes.size() != (size_t)bvh.node_count * 16) return "4-wide BVH: node array size does not match the node count";
+    if (bvh.tri_order.size() != n_tris) return "4-wide BVH: triangle order does not cover the triangles";
+    for (uint32_t ni = 0; ni < bvh.node_count; ++ni)
+        for (int k = 0; k < 4; ++k) {
+            const int32_t link = (int32_t)bvh.nodes[(size_t)ni * 16 + 10 + k];
+            if (link >= 0) {
+                if ((uint32_t)link >= bvh.node_count || (uint32_t)link <= ni) return "4-wide BVH: child link out of range (children follow their parent in breadth-first order)";
+            } else {
+                const uint32_t leaf = (uint32_t)~link, first = leaf >> 2, cnt = (leaf & 3u) + 1u;
+                // an empty slot points at the all-zero dummy record behind the last triangle
+                if (first > n_tris || (first < n_tris && first + cnt > n_tris)) return "4-wide BVH: leaf triangle range out of range";
+            }
+        }
+    return nullptr;
+}
+const char * validate_bvh_links(const Bvh8Result & bvh, uint32_t n_tris) {
+    if (bvh.node_count == 0 || bvh.nodes.size() != (size_t)bvh.node_count * BVH8_NODE_DWORDS) return "8-wide BVH: node array size does not match the node count";
+    if (bvh.tri_order.size() != n_tris) return "8-wide BVH: triangle order does not cover the triangles";
+    for (uint32_t ni = 0; ni < bvh.node_count; ++ni) {
+        const uint32_t * d = &bvh.nodes[(size_t)ni * BVH8_NODE_DWORDS];
+        const uint32_t imask = d[3] & 0xFFu, lmask = d[3] >> 8 & 0xFFu, c0 = d[6] & 0xFFu, c1 = d[6] >> 8 & 0xFFu;
+        if (imask & lmask) return "8-wide BVH: a slot is both an internal node and a leaf";
+        uint32_t n_child = 0, n_leaf_tris = 0;
+        for (uint32_t sl = 0; sl < 8; ++sl) {
+            n_child += imask >> sl & 1u;
+            if (lmask >> sl & 1u) n_leaf_tris += 1u + (c0 >> sl & 1u) + 2u * (c1 >> sl & 1u);
+        }
+        if (n_child && ((uint64_t)d[4] + n_child > bvh.node_count || d[4] <= ni)) return "8-wide BVH: child range out of range";
+        if (n_leaf_tris && (uint64_t)d[5] + n_leaf_tris > (uint64_t)n_tris + (n_tris == 0 ? 1u : 0u)) return "8-wide BVH: leaf triangle range out of range";
+    }
+    return nullptr;
 }
 
 int render_pixels(prt_ctx * ctx, const prt_camera * cam_in, const prt_params * params, uint32_t width, uint32_t height,
@@ -940,7 +997,7 @@ int render_pixels_once(prt_ctx * ctx, const prt_camera * cam_in, const prt_param
     unsigned int stack_cap = STACK_LDS_CAP_DEFAULT;
     if (opt.stack_cap >= 0) stack_cap = (unsigned int)std::max(2ll, std::min(40ll, opt.stack_cap));   // test hook: force the spill area into use
     const unsigned int stack_entries = std::min(ctx->stack_bound, stack_cap);
-    const size_t lds = (size_t)stack_entries * BLOCK * sizeof(int) * STACK_ENTRY_INTS;
+    const size_t lds = stack_dwords(stack_entries, BLOCK) * sizeof(int);
     P.stack_lds_entries = stack_entries;
     P.stack_spill = nullptr;
     P.stack_spill_stride = 0;
@@ -955,7 +1012,7 @@ int render_pixels_once(prt_ctx * ctx, const prt_camera * cam_in, const prt_param
                                                                        : 0;                      // wavefront: per chain, see chain_setup
         if (spill_entries && spill_lanes) {
             if (spill_lanes >= (1ull << 32)) { ctx->error = "prt_render: too many lanes for the stack spill area"; return -1; }
-            HIP_TRY(ctx, ctx->stack_spill.ensure((size_t)spill_entries * spill_lanes * STACK_ENTRY_INTS));
+            HIP_TRY(ctx, ctx->stack_spill.ensure(stack_dwords(spill_entries, spill_lanes)));
             P.stack_spill = ctx->stack_spill.p;
             P.stack_spill_stride = (unsigned int)spill_lanes;
         }
@@ -1015,7 +1072,10 @@ int render_pixels_once(prt_ctx * ctx, const prt_camera * cam_in, const prt_param
             else
                 rc = ctx->textured ? launch_pool<256, 4, false, true, true, false>(ctx, count_visits, cam, P, n_samples, stack_entries)
                    : !ring ? launch_pool<PRT_POOL_BLOCK, PRT_POOL_WAVES, false, true, false, false, 0>(ctx, count_visits, cam, P, n_samples, stack_entries)
-                           : launch_pool<PRT_POOL_BLOCK, PRT_POOL_WAVES, false, true, false, false, 1>(ctx, count_visits, cam, P, n_samples, stack_entries);
+#if defined(PRT_DEEP_OPAQUE_VARIANT)
+                   : opaque ? launch_pool<PRT_POOL_BLOCK, PRT_DEEP_WAVES, false, true, false, false, 2>(ctx, count_visits, cam, P, n_samples, stack_entries)
+#endif
+                           : launch_pool<PRT_POOL_BLOCK, PRT_DEEP_WAVES, false, true, false, false, 1>(ctx, count_visits, cam, P, n_samples, stack_entries);
             launches += 1;
         } else {
             unsigned long long rays = 0;
@@ -1409,6 +1469,7 @@ int prt_upload_scene(prt_ctx * ctx, const prt_scene_desc * s) {
         PRT_BUILD_WIDE(verts.data(), n_tris, leaf_max, std::min(hw, 16u), &bvh, trav_cost, &ctx->opt.bvh);
     }
     double build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (const char * bad = validate_bvh_links(bvh, n_tris)) { ctx->error = std::string("prt_upload_scene: the builder produced a broken tree - ") + bad; return -9; }
 
     // ---- reference visit rank: leaves of the sphere tree in the order TraceRay pops them (c1 first)
     std::vector<uint32_t> rank_of_input(n_tris);
@@ -1948,6 +2009,7 @@ int prt_debug_check_bvh(const prt_scene_desc * s, uint64_t * out) {
 #endif
     BvhWide bvh;
     PRT_BUILD_WIDE(verts.data(), n_tris, BVH_LEAF_MAX, 4, &bvh, 1.0f, &opt.bvh);
+    if (validate_bvh_links(bvh, n_tris)) return -9;          // what prt_upload_scene checks before it uploads a tree
     return check_bvh_wide(verts, n_tris, bvh, out);
     PRT_API_CATCH_RC(nullptr, "prt_debug_check_bvh")
 }
@@ -1964,6 +2026,7 @@ int prt_debug_check_bvh_lbvh(prt_ctx * ctx, const prt_scene_desc * s, uint64_t *
     BvhWide bvh;
     int rc = build_bvh_lbvh(ctx, verts.data(), n_tris, BVH_LEAF_MAX, &bvh);
     if (rc) return rc;
+    if (const char * bad = validate_bvh_links(bvh, n_tris)) { ctx->error = bad; return -9; }
     return check_bvh_wide(verts, n_tris, bvh, out);
     PRT_API_CATCH_RC(ctx, "prt_debug_check_bvh_lbvh")
 }

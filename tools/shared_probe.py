@@ -64,6 +64,15 @@ if "adaptive" in what:
 if "deep" in what:
     p = api.default_params(8, 1234, pipeline=capi.PIPELINE_POOL, bounce_depth=8)
     compare("C4 8 spp depth 8", lambda: r.render_device(cam, p, w, h, 0, w * h, buf.data_ptr(), True), 3, w * h)
+if "c5" in what:
+    w5, h5 = 3840, 2160
+    cam5 = api.make_camera(s.fov, w5, h5, s.camera_position, s.camera_facing)
+    buf5 = torch.zeros((h5, w5, 4), dtype=torch.float32, device="cuda"); torch.cuda.synchronize()
+    p = api.default_params(64, 1234, pipeline=capi.PIPELINE_POOL, bounce_depth=8)
+    keep = buf
+    buf = buf5
+    compare("C5 4K x 64 spp depth 8", lambda: r.render_device(cam5, p, w5, h5, 0, w5 * h5, buf5.data_ptr(), True), 2, w5 * h5)
+    buf = keep
 if "counters" in what:
     r.set_option("DEBUG_UTIL", 1)
     for name, v in MODES:
