@@ -29,7 +29,8 @@ extern "C" {
 
 #define PRT_ABI_VERSION 5
 /* Error codes (every entry point that returns int): -1 bad argument, -2 no scene uploaded, -5 / -6 internal limits of the
- * wavefront pipeline, -7 park lists kept overflowing, -8 near-tied hits unresolved, -10 a HIP runtime call failed,
+ * wavefront pipeline, -7 park lists kept overflowing, -8 near-tied hits unresolved, -9 the BVH builder produced a tree that fails
+ * the upload check (a link or triangle range outside the arrays: refused instead of traversed), -10 a HIP runtime call failed,
  * -11 too many frames in flight (prt_multi_submit), -12 a C++ exception was caught at the entry point. */
 enum { PRT_ERR_ARGUMENT = -1, PRT_ERR_NO_SCENE = -2, PRT_ERR_HIP = -10, PRT_ERR_IN_FLIGHT = -11, PRT_ERR_EXCEPTION = -12 };
 

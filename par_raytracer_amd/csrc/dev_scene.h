@@ -126,6 +126,10 @@ struct DevParams {
     // are handed out tile by tile - 64 consecutive work items are an 8 x 8 pixel tile, not a 64 x 1 strip - so that the rays
     // a wave traces together start from one compact patch of the image (local_of_work below).  0 = off.
     unsigned int tile_pixels;
+    // Work order reversed (option WORK_REVERSE, round 4 experiment): work item wi of a call of n pixels renders what item
+    // n - 1 - wi would - the bottom of the image first, so that the samples fetched LAST, whose bounce chains are the frame's
+    // tail, are the top rows (sky in outdoor scenes: one ray and done).  n, or 0 = off.  Never with a pixel list.
+    unsigned int work_reverse_n;
     // 1: a shadow ray whose radiance-if-unoccluded is exactly zero is counted, not traced (kernels_wave.h shade_entry);
     // 0 (PRT_TRACE_DEAD_SHADOW_RAYS): traced like every other one
     unsigned int elide_dead_shadow_rays;
@@ -135,7 +139,8 @@ struct DevParams {
 };
 
 // Work item (position in the order pixels are handed out, whole call) -> local pixel (position in the call's output).
-PRT_HD unsigned int local_of_work(unsigned int wi, unsigned int width, unsigned int tile_pixels) {
+PRT_HD unsigned int local_of_work(unsigned int wi, unsigned int width, unsigned int tile_pixels, unsigned int reverse_n = 0u) {
+    if (reverse_n) wi = reverse_n - 1u - wi;
     if (wi >= tile_pixels) return wi;
     const unsigned int band_px = 8u * width;
     const unsigned int b = wi / band_px, q = wi - b * band_px;
@@ -147,7 +152,7 @@ PRT_HD unsigned int local_of_work(unsigned int wi, unsigned int width, unsigned 
 PRT_HD unsigned int pixel_of_local(const DevParams & P, unsigned int lp) {
     lp += P.local_base;                         // this pass's first work item within the call's pixel set
     if (P.pixel_list) return P.pixel_list[lp];
-    lp = local_of_work(lp, P.width, P.tile_pixels);
+    lp = local_of_work(lp, P.width, P.tile_pixels, P.work_reverse_n);
     if (P.shard_nranks <= 1) return P.first_pixel + lp;
     const unsigned int row = lp / P.width, x = lp - row * P.width;
     const unsigned int blk = row / P.shard_block_rows, r = row - blk * P.shard_block_rows;
@@ -163,6 +168,7 @@ struct DevCounters {          // device-side accumulators (atomics, one add per 
     // wave-level step counts (COUNT builds only): lane utilisation = lane-level count / (64 * wave-level count)
     unsigned long long wave_node_steps, wave_leaf_steps, wave_tri_steps, wave_refills, max_sp, culled;
     unsigned long long wave_node_step_rays;          // k_pool: lanes holding a ray, summed over its wave-level node steps
+    unsigned long long drain_node_steps, drain_node_step_rays;   // ... and the part of both taken while a round's list had nothing left to hand out
     // k_pool, COUNT builds: wave-cycles (s_memtime) spent in the top-up / trace / shade phase, in the whole main loop, and
     // (adaptive mode) in the finalise step, which is part of the shade phase
     unsigned long long phase_cycles[5];

@@ -23,6 +23,12 @@
 // Results are those of the wavefront pipeline bit for bit: same shade_entry(), same traversal, same per-sample
 // RNG keys; only the order in which independent samples are processed differs.
 //
+// Round 4, measured and NOT built in (profiles/r04_round_drains.txt): a round ends with a DRAIN - once its list is dry the wave
+// walks on with the rays in flight, fewer and fewer, until the last is done: 13 % of a C4 frame's wave-level node steps at 30 %
+// lane fill, 38 % of a 1/8 shard's, 49 % of the adaptive mode's.  Setting the last rays aside and resuming them in the next
+// round removes half of that and gains nothing: the carried ray's sample is shaded a round later, and pool slots, not lanes,
+// are what thin rounds are short of.
+//
 // Round 4: BLOCK-SHARED pools (template parameter SHARED).  A round that is private to a wave is thin where there is little
 // work per wave - a 1/8-frame shard of a multi-GPU run, the adaptive mode's one ray per pixel - and every thin round ends with
 // a wave that issues its node steps for a handful of lanes (a 1/8 shard: 32 % of the node loop's lane slots hold no ray).
@@ -303,6 +309,7 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_pool(const PoolArgs * args, De
     (void)hits; (void)sq_o; (void)sq_c; (void)sq_d; (void)ct
 
     unsigned long long ph_topup = 0ull, ph_trace = 0ull, ph_shade = 0ull, ph_final = 0ull;      // COUNT: wave-cycles per phase
+    unsigned long long dry_steps = 0ull, dry_rays = 0ull;      // COUNT: wave-level node steps taken after the round's list ran dry (the round's drain), lanes with a ray in them
     const unsigned long long ph_begin = COUNT ? __builtin_readcyclecounter() : 0ull;
     const unsigned long long wt_begin = COUNT ? wall_clock64() : 0ull;
     unsigned long long wt_dry = 0ull;
@@ -489,7 +496,7 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_pool(const PoolArgs * args, De
                     const unsigned int with_ray = COUNT ? (unsigned int)__popcll(__ballot(true)) : 0u;
                     while (trav_walking(r)) {
                         trav_node_step<Stack, COUNT>(sc, r, stack, st, P.box_pad, TOPN > 0 ? s_top : nullptr);
-                        if (COUNT && first_active_lane()) st.wrays += with_ray;
+                        if (COUNT && first_active_lane()) { st.wrays += with_ray; if (dry) { dry_steps += 1ull; dry_rays += with_ray; } }
                         if (__popcll(__ballot(trav_walking(r))) < nmin) break;
                     }
                     bool fin = trav_done(r);
@@ -837,6 +844,7 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_pool(const PoolArgs * args, De
         atomicMax(&ctr->max_sp, (unsigned long long)st.max_sp);
         atomicAdd(&ctr->culled, (unsigned long long)st.culled);
         atomicAdd(&ctr->wave_node_step_rays, (unsigned long long)st.wrays);
+        if (dry_steps) { atomicAdd(&ctr->drain_node_steps, dry_steps); atomicAdd(&ctr->drain_node_step_rays, dry_rays); }
         if (lane == 0) {
             atomicAdd(&ctr->phase_cycles[0], ph_topup);
             atomicAdd(&ctr->phase_cycles[1], ph_trace);

@@ -859,6 +859,7 @@ int render_pixels_once(prt_ctx * ctx, const prt_camera * cam_in, const prt_param
         if (rows) P.tile_pixels = px.n_pixels / (8u * width) * (8u * width);
     }
 
+    P.work_reverse_n = (opt.work_reverse > 0 && !px.d_pixel_list) ? px.n_pixels : 0u;
     const bool count_visits = (params->pipeline & PRT_FLAG_COUNT_VISITS) != 0;
     // the compact 2-register RNG only covers opaque scenes with <= 15 draws per sample; textured scenes always take the
     // general variant (an alpha map can make any hit translucent)
@@ -1091,7 +1092,7 @@ int render_pixels_once(prt_ctx * ctx, const prt_camera * cam_in, const prt_param
         if (single_launch) HIP_TRY(ctx, hipEventRecord(ctx->ev[3], stream));
         // work items of this pass -> their places in the call's output (tiled work order, dev_scene.h local_of_work)
         ResolveMap rmap;
-        rmap.base = p0; rmap.width = P.width; rmap.tile_pixels = P.tile_pixels;
+        rmap.base = p0; rmap.width = P.width; rmap.tile_pixels = P.tile_pixels; rmap.reverse_n = P.work_reverse_n;
         if (adaptive)       // k_pool<ADAPT> has already divided by each pixel's own sample count
             hipLaunchKernelGGL(k_resolve<false>, dim3((n_px + 255) / 256), dim3(256), 0, stream,
                                ctx->adapt_f4.p + ((size_t)P.max_spp + 1u) * n_samples, d_out, n_px, 1u, rmap);
@@ -1163,6 +1164,11 @@ int render_pixels_once(prt_ctx * ctx, const prt_camera * cam_in, const prt_param
                     100.0 * (double)h.node_visits / (64.0 * (double)h.wave_node_steps),
                     100.0 * ((double)h.wave_node_step_rays - (double)h.node_visits) / (64.0 * (double)h.wave_node_steps),
                     100.0 * (64.0 * (double)h.wave_node_steps - (double)h.wave_node_step_rays) / (64.0 * (double)h.wave_node_steps));
+        if (opt.debug_util && h.drain_node_steps && h.wave_node_steps)
+            fprintf(stderr, "[prt] k_pool round drains (node steps taken after a round's list ran dry): %.1f%% of the wave-level node steps, %.1f%% of their lane slots hold a ray; "
+                            "the steps before the list ran dry: %.1f%% of lane slots hold a ray\n",
+                    100.0 * (double)h.drain_node_steps / (double)h.wave_node_steps, 100.0 * (double)h.drain_node_step_rays / (64.0 * (double)h.drain_node_steps),
+                    100.0 * ((double)h.wave_node_step_rays - (double)h.drain_node_step_rays) / (64.0 * ((double)h.wave_node_steps - (double)h.drain_node_steps)));
         if (opt.debug_util && h.phase_cycles[3])
             fprintf(stderr, "[prt] k_pool wave time by phase: top-up %.1f%%, trace %.1f%%, shade %.1f%% of the main loop\n",
                     100.0 * (double)h.phase_cycles[0] / (double)h.phase_cycles[3], 100.0 * (double)h.phase_cycles[1] / (double)h.phase_cycles[3],

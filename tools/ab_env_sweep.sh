@@ -1,9 +1,10 @@
 #!/bin/bash
 # One library build, one box: bench.py (C4, pool pipeline) under several settings of one environment knob.
-#   tools/ab_env_sweep.sh <variant .so> <ENV_NAME> <value> ...        ("-" = unset)
+#   tools/ab_env_sweep.sh <tag> <ENV_NAME> <value> ...        ("-" = unset; the build is par_raytracer_amd/libprt_hip_<tag>.so,
+#   selected with PRT_HIP_LIB - "default" = libprt_hip.so, which is never overwritten)
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
-cp "$1" par_raytracer_amd/libprt_hip.so
+if [ "$1" = default ]; then export PRT_HIP_LIB=libprt_hip.so; else export PRT_HIP_LIB=libprt_hip_$1.so; fi
 name=$2; shift 2
 for val in "$@"; do
     if [ "$val" = "-" ]; then unset $name; else export $name=$val; fi

@@ -1,8 +1,8 @@
 #!/bin/bash
-# lane-utilisation counters (tools/util_probe.py) for several libprt_hip.so builds: tools/ab_util.sh <variant .so> ...
+# lane-utilisation counters (tools/util_probe.py) for several builds: tools/ab_util.sh <tag> ...   (libprt_hip_<tag>.so via PRT_HIP_LIB; "default" = the product library)
 cd "$(dirname "$0")/.."
 for v in "$@"; do
-    cp "$v" par_raytracer_amd/libprt_hip.so
+    lib=libprt_hip.so; [ "$v" != default ] && lib=libprt_hip_$v.so
     echo "== $v"
-    python tools/util_probe.py 2 4 2>&1 | grep -v "^\s*$"
+    PRT_HIP_LIB=$lib python tools/util_probe.py 2 4 2>&1 | grep -v "^\s*$"
 done

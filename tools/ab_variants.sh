@@ -1,12 +1,12 @@
 #!/bin/bash
-# A/B of libprt_hip.so builds on the GPU box: tools/ab_variants.sh <variant .so> ...   (each runs bench on both production pipelines)
+# A/B of libprt_hip.so builds on the GPU box: tools/ab_variants.sh <tag> ...   (libprt_hip_<tag>.so via PRT_HIP_LIB, "default" = the product library; each runs bench on both production pipelines)
 set -e
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
 for v in "$@"; do
-    cp "$v" par_raytracer_amd/libprt_hip.so
+    lib=libprt_hip.so; [ "$v" != default ] && lib=libprt_hip_$v.so
     for p in 4 2; do
-        python bench.py --no-cpu-baseline --pipeline $p --steps 8 --warmup 2 2>/dev/null | python -c "
+        PRT_HIP_LIB=$lib python bench.py --no-cpu-baseline --pipeline $p --steps 8 --warmup 2 2>/dev/null | python -c "
 import json,sys
 j=json.loads(sys.stdin.read().strip().splitlines()[-1])
 r=j['roofline']

@@ -1,12 +1,13 @@
 #!/bin/bash
-# Issue counters of the frame's kernel for several library builds, one box: tools/pmc_sq.sh <variant .so> ...
+# Issue counters of the frame's kernel for several library builds, one box: tools/pmc_sq.sh <tag> ...
+# (a build is par_raytracer_amd/libprt_hip_<tag>.so, selected with PRT_HIP_LIB; "default" = libprt_hip.so, which is never touched)
 # (two rocprofv3 --pmc passes of bench.py per build, counters only; summary: vector instructions per frame, vector pipe busy,
 # share of wave cycles spent waiting)
 root="$(cd "$(dirname "$0")/.." && pwd)"
 cd /tmp && export TMPDIR=/tmp
 for v in "$@"; do
-    cp "$root/$v" "$root/par_raytracer_amd/libprt_hip.so"
-    tag=$(basename "$v" .so)
+    tag="$v"
+    if [ "$v" = default ]; then export PRT_HIP_LIB=libprt_hip.so; else export PRT_HIP_LIB=libprt_hip_$v.so; fi
     out="$root/gpurun_out/pmc_sq_$tag"; rm -rf "$out"; mkdir -p "$out"
     BENCH="python3 $root/bench.py --no-cpu-baseline --no-other-workloads --pipeline 4 --steps 3 --warmup 1"
     rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVES --output-format csv -d "$out/sq1" -- $BENCH > "$out/sq1.log" 2>&1

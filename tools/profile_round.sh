@@ -5,7 +5,7 @@
 #   issue / stall counters, texture-addresser counters.  Counters only in the PMC passes (no tracing).
 root="$(cd "$(dirname "$0")/.." && pwd)"
 out="$root/gpurun_out/prof_round"
-rm -rf "$out"; mkdir -p "$out"
+rm -rf "$out"; mkdir -p "$out"       # (gpurun MERGES this directory into the local one: delete the local copy before a new round of passes)
 cd /tmp && export TMPDIR=/tmp
 BENCH="python3 $root/bench.py --no-cpu-baseline --no-other-workloads --steps 5 --warmup 1"
 echo "kernel trace" | tee -a "$out/progress.txt"

@@ -5,7 +5,7 @@ import collections, csv, glob, json, os, shutil, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(ROOT, "gpurun_out", "prof_round")
 dst = os.path.join(ROOT, "profiles")
-rnd = sys.argv[1] if len(sys.argv) > 1 else "r03"
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r04"
 
 def short(name):
     return name.replace("void prt::", "").replace("prt::", "").split("(")[0]
@@ -26,7 +26,7 @@ for tag, name in (("trace", "%s_pool_C4_kernel_stats.csv" % rnd), ("trace_other"
 
 fetch, nf = counters("fetch"); write, _ = counters("write")
 sq1, n1 = counters("sq1"); sq2, _ = counters("sq2"); ta, nta = counters("ta")
-FAST = "k_pool<256, 5, false, true, false, false, false, 0, false>"        # the timed frames' kernel (COUNT = false, EXACT = false)
+FAST = "k_pool<256, 5, false, true, false, false, false, 0, false, true>"  # the timed frames' kernel (COUNT = false, EXACT = false, SHARED = true: block-shared pools)
 import hashlib, subprocess
 lib = os.path.join(ROOT, "par_raytracer_amd", "libprt_hip.so")
 try:
