@@ -79,7 +79,8 @@ struct PoolBuffers {
 // one ds_add_rtn per wave and call, the lanes' slots follow from the returned base and the ballot rank as before.
 template <bool ADAPT, bool SHARED>
 struct PoolEmit {
-    enum { KEEPS_RNG = ADAPT ? 1 : 0 };      // adaptive mode: the pixel's next sample continues the RNG stream of the one that ended
+    enum { KEEPS_RNG = ADAPT ? 1 : 0,        // adaptive mode: the pixel's next sample continues the RNG stream of the one that ended
+           ATOMIC_RADIANCE = 0 };            // a hit's radiance by the shading lane's own read-modify-write (the phases order it against the shadow rays' atomics)
     float4 * co, * cd, * ct;     // next closest list
     float4 * so, * sc, * sd;     // next shadow list
     unsigned int * fin;          // ADAPT: pixels to finalise after the next trace phase

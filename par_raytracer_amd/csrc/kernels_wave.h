@@ -446,7 +446,9 @@ PRT_D void shade_entry_on(const DevScene & sc, const DevParams & P, const WaveBu
         // (seed word 0, draws so far) matter from the 15th draw on: a render whose samples provably stop before that
         // (RINGMEM = false) neither reads nor writes them - 32 bytes less per shaded hit
         if (RING && RM) { const ulonglong2 ra = B.rng_aux[s]; rng.seed0 = ra.x; rng.k = (u32)ra.y; }
-        if (!fresh) accum_load_owner(B.accum + s, acc_x, acc_y, acc_z);
+        // (Emit::ATOMIC_RADIANCE - the continuous-flow kernel, kernels_flow.h: a sample's shadow rays are no longer a phase apart
+        // from its next hit, so the hit's radiance is added with atomics like theirs and nothing is read here)
+        if (!fresh && !Emit::ATOMIC_RADIANCE) accum_load_owner(B.accum + s, acc_x, acc_y, acc_z);
     }
     // RINGMEM = false: the general-RNG code without its draw ring in memory, for renders whose samples provably make at
     // most 15 draws (dev_rng.h) - a compile-time NULL, so the ring code folds away
@@ -558,7 +560,10 @@ PRT_D void shade_entry_on(const DevScene & sc, const DevParams & P, const WaveBu
     }
 
     // everything this invocation adds to the sample is known now (the bounce walk below adds nothing): write the record back
-    if (live && (fresh || add.x != 0.0f || add.y != 0.0f || add.z != 0.0f)) accum_store_owner(B.accum + s, acc_x, acc_y, acc_z, add);
+    if (live && (fresh || add.x != 0.0f || add.y != 0.0f || add.z != 0.0f)) {
+        if (Emit::ATOMIC_RADIANCE && !fresh) accum_add(B.accum + s, add);       // (a fresh record holds nothing and nobody else adds to it yet: a plain store)
+        else accum_store_owner(B.accum + s, acc_x, acc_y, acc_z, add);
+    }
 
     // ---- shadow rays of this hit (raytracer.cpp:507-511, 378-411): radiance-if-unoccluded rides with the ray
     for (unsigned int li = 0; li < sc.light_count; ++li) {
@@ -704,7 +709,7 @@ PRT_D void shade_entry_lds(const DevScene & sc, const DevParams & P, const WaveB
 // Emitter of k_shade: workgroup-aggregated appends to the global next-round queues.
 template <int BLOCK>
 struct QueueEmit {
-    enum { KEEPS_RNG = 0 };           // fixed spp: a sample that has ended never draws again
+    enum { KEEPS_RNG = 0, ATOMIC_RADIANCE = 0 };           // fixed spp: a sample that has ended never draws again; a hit's radiance by the owner's read-modify-write
     const WaveBuffers & B;
     int nxt;
     unsigned int * s_cnt;

@@ -25,6 +25,11 @@
 #include "dev_scene.h"
 #include "kernels_wave.h"
 #include "kernels_pool.h"
+#if defined(PRT_FLOW_EXPERIMENT)
+// round 4's round-free experiment (three tracer waves + one shading wave per workgroup): correct, and slower than the round-based
+// kernel because one shading wave per workgroup cannot keep up (profiles/r04_flow_kernel.txt); not in the shipped library
+#include "kernels_flow.h"
+#endif
 #include "kernels_resolve.h"
 #if defined(PRT_EXPERIMENTAL)
 // the round-1 megakernel (the exact-association cross-check) and the persistent single-launch experiment: not in the
@@ -42,6 +47,9 @@ using namespace prt;
 #endif
 #ifndef PRT_POOL_SHARED_DEFAULT
 #define PRT_POOL_SHARED_DEFAULT 1 // block-shared pools (kernels_pool.h) for fixed-spp renders when the option POOL_SHARED is not set
+#endif
+#ifndef PRT_POOL_FLOW_DEFAULT
+#define PRT_POOL_FLOW_DEFAULT 0   // the pool pipeline without rounds (kernels_flow.h) for fixed-spp renders when the option POOL_FLOW is not set
 #endif
 #ifndef PRT_POOL_BLOCK
 #define PRT_POOL_BLOCK 256        // threads per workgroup of the fixed-spp pool kernel (experiments: 320, 640 with block-shared pools)
@@ -169,6 +177,10 @@ struct prt_ctx {
     DevCounters * host_counters = nullptr;                            // pinned: the render's counters arrive here on the context's stream
     DevBuf<unsigned int> pool_fin;        // adaptive mode: per-wave lists of pixels to finalise
     DevBuf<PoolArgs> pool_args;           // k_pool's arguments (read per phase from memory, kernels_pool.h)
+#if defined(PRT_FLOW_EXPERIMENT)
+    DevBuf<FlowArgs> flow_args;           // k_flow's (kernels_flow.h)
+    DevBuf<unsigned int> flow_u32;        // ... its slot id rings and free-slot stacks
+#endif
     DevBuf<unsigned long long> wave_times;  // DEBUG_UTIL + counting render: (start, counter dry, exit) wall clock of every wave of the fast kernel
     unsigned int wave_times_n = 0;
     DevBuf<float4> adapt_f4;              // adaptive mode: scratch [max_spp][n] + running sums [n] + final colours [n]
@@ -559,7 +571,13 @@ int launch_pool(prt_ctx * ctx, bool count, const DevCamera & cam, DevParams P, u
     // most 15 draws per sample, opaque untextured scene: RINGMEM = 0) - the full C4 frame 1.5 - 2 % faster, its 1/2 .. 1/16
     // shards 1.5 - 3.5 % -; OFF for the adaptive mode, whose short rounds lose 11 % to the four waves waiting for each other at
     // every phase boundary, and for deep bounce trees (C5: 886 -> 949 ms; that variant spills 59 dwords shared, 31 private).
-    const bool shared = !exact_only && (opt.pool_shared >= 0 ? opt.pool_shared != 0 : (PRT_POOL_SHARED_DEFAULT != 0 && !ADAPT && !TEX && RINGMEM == 0));
+    // (the round-free kernel, kernels_flow.h, has its own workgroup-level structure; its follow-up launches use wave-private pools)
+#if defined(PRT_FLOW_EXPERIMENT)
+    const bool flow = !ADAPT && BLOCK == 256 && !exact_only && (opt.pool_flow >= 0 ? opt.pool_flow != 0 : PRT_POOL_FLOW_DEFAULT != 0);
+#else
+    const bool flow = false;
+#endif
+    const bool shared = !flow && !exact_only && (opt.pool_shared >= 0 ? opt.pool_shared != 0 : (PRT_POOL_SHARED_DEFAULT != 0 && !ADAPT && !TEX && RINGMEM == 0));
     hipError_t oe = exact_only ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_pool<BLOCK, WAVES, LDSTAB, RING, false, TEX, ADAPT, RINGMEM, true, false>, BLOCK, lds)
                   : shared     ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_pool<BLOCK, WAVES, LDSTAB, RING, false, TEX, ADAPT, RINGMEM, false, true>, BLOCK, lds)
                   : count      ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_pool<BLOCK, WAVES, LDSTAB, RING, true, TEX, ADAPT, RINGMEM, false, false>, BLOCK, lds)
@@ -693,6 +711,62 @@ int launch_pool(prt_ctx * ctx, bool count, const DevCamera & cam, DevParams P, u
     if (opt.node_frac >= 0) A.node_frac = std::max(0, std::min(8, (int)opt.node_frac));
     A.multi_light = multi_light;
     HIP_TRY(ctx, ctx->pool_args.ensure(2));
+#if defined(PRT_FLOW_EXPERIMENT)
+    if constexpr (!ADAPT && BLOCK == 256) {
+        if (flow) {
+            // ---- no rounds (kernels_flow.h): three tracer waves and a shading wave per workgroup, ray slots and rings instead of lists.
+            // The follow-up launches are the pool kernel's (their PoolArgs `A` as built above, wave-private layout over the same buffers).
+            int fper_cu = 0;
+            hipError_t foe = count ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&fper_cu, k_flow<BLOCK, WAVES, RING, true, TEX, RINGMEM>, BLOCK, lds)
+                                   : hipOccupancyMaxActiveBlocksPerMultiprocessor(&fper_cu, k_flow<BLOCK, WAVES, RING, false, TEX, RINGMEM>, BLOCK, lds);
+            if (foe != hipSuccess || fper_cu < 1) fper_cu = 1;
+            fper_cu = std::min(fper_cu, 8);
+            if (opt.pool_blocks_per_cu >= 0) fper_cu = std::max(1, std::min(fper_cu, (int)opt.pool_blocks_per_cu));
+            const unsigned int fgrid = std::max(1u, std::min((unsigned int)fper_cu * (unsigned int)ctx->cu_count, (n_samples + BLOCK - 1) / BLOCK));
+            auto pow2 = [](unsigned int v) { unsigned int p = 64; while (p < v) p <<= 1; return p; };
+            // samples in flight per workgroup: what the block's waves would hold in their pools
+            unsigned int fcap = (n_samples / (fgrid * (BLOCK / 64)) / 2u + 63u) / 64u * 64u;
+            fcap = std::max(64u, std::min(512u, fcap));
+            if (opt.pool_cap >= 0) fcap = (unsigned int)std::max(64ll, std::min(4096ll, opt.pool_cap / 64 * 64));
+            const unsigned int slots = fcap * (BLOCK / 64);
+            const unsigned int rc = pow2(slots), rd = pow2(slots), rs = pow2(std::max(1024u, 2u * slots * n_lights));
+            HIP_TRY(ctx, ctx->pool_f4.ensure(std::max((size_t)units * (7u * (size_t)cap + 3u * (size_t)scap), (size_t)fgrid * (4u * (size_t)slots + 3u * (size_t)rs))));
+            HIP_TRY(ctx, ctx->flow_u32.ensure((size_t)fgrid * ((size_t)rc + 3u * rd + slots)));
+            HIP_TRY(ctx, ctx->flow_args.ensure(1));
+            // (pool_f4 may have moved: the wave-private layout of the follow-up launches again)
+            A.Q.cq = ctx->pool_f4.p;
+            A.Q.hits = A.Q.cq + (size_t)units * 6u * cap;
+            A.Q.sq = A.Q.hits + (size_t)units * cap;
+            FlowArgs FA;
+            memset(&FA, 0, sizeof(FA));
+            FA.pool = A;
+            FA.pool.Q.cq = ctx->pool_f4.p;                                   // [blocks][3][slots]
+            FA.pool.Q.hits = FA.pool.Q.cq + (size_t)fgrid * 3u * slots;      // [blocks][slots]
+            FA.pool.Q.sq = FA.pool.Q.hits + (size_t)fgrid * slots;           // [blocks][3][rs]
+            FA.F.crq = ctx->flow_u32.p;
+            FA.F.done = FA.F.crq + (size_t)fgrid * rc;
+            FA.F.freelist = FA.F.done + (size_t)fgrid * 3u * rd;
+            FA.F.slots = slots;
+            FA.F.rc_mask = rc - 1u; FA.F.rd_mask = rd - 1u; FA.F.rs_mask = rs - 1u;
+            FA.F.topup_min = 64u;
+            FA.F.topup_max = 256u;
+            if (opt.pool_topup >= 0) FA.F.topup_min = (unsigned int)std::max(1ll, std::min((long long)slots, opt.pool_topup));
+            FA.F.low_water = 3u * 64u;
+            FA.F.error = &ctx->counters.p->flow_error;
+            if (opt.debug_util) fprintf(stderr, "[prt] k_flow<%d,%d>: %d blocks per CU, %u workgroups, %u slots each, rings %u / %u / %u\n", BLOCK, WAVES, fper_cu, fgrid, slots, rc, rd, rs);
+            hipLaunchKernelGGL(k_flow_store_args, dim3(1), dim3(64), 0, ctx->stream, FA, A, ctx->flow_args.p, ctx->pool_args.p, ctx->wf_counts.p, 16u, ctx->wf_counts.p + 3);
+            HIP_TRY(ctx, hipGetLastError());
+            if (count) hipLaunchKernelGGL((k_flow<BLOCK, WAVES, RING, true, TEX, RINGMEM>), dim3(fgrid), dim3(BLOCK), lds, ctx->stream, ctx->flow_args.p, ctx->counters.p);
+            else hipLaunchKernelGGL((k_flow<BLOCK, WAVES, RING, false, TEX, RINGMEM>), dim3(fgrid), dim3(BLOCK), lds, ctx->stream, ctx->flow_args.p, ctx->counters.p);
+            HIP_TRY(ctx, hipGetLastError());
+            if (count) hipLaunchKernelGGL(k_pool_parked_shadows<true>, dim3(POOL_PARKED_SHADOW_BLOCKS), dim3(256), 0, ctx->stream, ctx->pool_args.p, ctx->counters.p);
+            else hipLaunchKernelGGL(k_pool_parked_shadows<false>, dim3(POOL_PARKED_SHADOW_BLOCKS), dim3(256), 0, ctx->stream, ctx->pool_args.p, ctx->counters.p);
+            HIP_TRY(ctx, hipGetLastError());
+            return count ? launch_pool_kernel<BLOCK, WAVES, LDSTAB, RING, true, TEX, ADAPT, RINGMEM, true>(ctx, grid2, lds, ctx->pool_args.p + 1)
+                         : launch_pool_kernel<BLOCK, WAVES, LDSTAB, RING, false, TEX, ADAPT, RINGMEM, true>(ctx, grid2, lds, ctx->pool_args.p + 1);
+        }
+    }
+#endif
     // the adopting launch's units are waves whatever the fast kernel's were: a quarter of a shared pool's slots each, in the
     // same buffers (grid2 <= grid, so its waves' lists fit where the blocks' lists lie)
     hipLaunchKernelGGL(k_pool_store_args, dim3(1), dim3(64), 0, ctx->stream, A, ctx->pool_args.p, ctx->wf_counts.p, 16u,
@@ -1127,6 +1201,12 @@ int render_pixels_once(prt_ctx * ctx, const prt_camera * cam_in, const prt_param
         *park_overflow = true;
         return 0;
     }
+    if (h.flow_error) {
+        char msg[160];
+        snprintf(msg, sizeof(msg), "prt_render: a wait inside the round-free pool kernel exceeded its watchdog (mask 0x%x): the frame is incomplete", h.flow_error);
+        ctx->error = msg;
+        return -5;
+    }
     if (h.near_tie_unresolved) {
         // resolve_near_ties ran out of widenings (dev_trace8.h): some hit among near-coincident candidates was decided over an
         // incomplete candidate set.  Never seen on real geometry; reported, not hidden.
@@ -1169,6 +1249,11 @@ int render_pixels_once(prt_ctx * ctx, const prt_camera * cam_in, const prt_param
                             "the steps before the list ran dry: %.1f%% of lane slots hold a ray\n",
                     100.0 * (double)h.drain_node_steps / (double)h.wave_node_steps, 100.0 * (double)h.drain_node_step_rays / (64.0 * (double)h.drain_node_steps),
                     100.0 * ((double)h.wave_node_step_rays - (double)h.drain_node_step_rays) / (64.0 * ((double)h.wave_node_steps - (double)h.drain_node_steps)));
+        if (opt.debug_util && h.flow_cycles[1] && h.flow_cycles[5])
+            fprintf(stderr, "[prt] k_flow: tracer waves wait for rays %.1f%% of their time; the shading wave tops up %.1f%%, shades %.1f%%, waits %.1f%% of its time; %llu shade batches of %.1f hits\n",
+                    100.0 * (double)h.flow_cycles[0] / (double)h.flow_cycles[1], 100.0 * (double)h.flow_cycles[2] / (double)h.flow_cycles[5],
+                    100.0 * (double)h.flow_cycles[3] / (double)h.flow_cycles[5], 100.0 * (double)h.flow_cycles[4] / (double)h.flow_cycles[5],
+                    (unsigned long long)h.flow_cycles[6], h.flow_cycles[6] ? (double)h.flow_cycles[7] / (double)h.flow_cycles[6] : 0.0);
         if (opt.debug_util && h.phase_cycles[3])
             fprintf(stderr, "[prt] k_pool wave time by phase: top-up %.1f%%, trace %.1f%%, shade %.1f%% of the main loop\n",
                     100.0 * (double)h.phase_cycles[0] / (double)h.phase_cycles[3], 100.0 * (double)h.phase_cycles[1] / (double)h.phase_cycles[3],
@@ -1361,6 +1446,10 @@ void prt_destroy(prt_ctx * ctx) {
     ctx->nodes.release(); ctx->tris.release(); ctx->shade.release(); ctx->diffuse_dirs.release(); ctx->spec_dirs.release();
     ctx->tri_rank.release(); ctx->materials.release(); ctx->lights.release();
     ctx->sample_rgb.release(); ctx->frame_out.release(); ctx->counters.release(); ctx->ring_ws.release(); ctx->pixel_list.release(); ctx->wf_counts.release(); ctx->stack_spill.release(); ctx->pool_f4.release(); ctx->pool_park.release(); ctx->pool_fin.release(); ctx->pool_args.release(); ctx->adapt_f4.release(); ctx->wave_times.release();
+#if defined(PRT_FLOW_EXPERIMENT)
+    ctx->flow_args.release(); ctx->flow_u32.release();
+#endif
+   
     ctx->textures.release(); ctx->texels.release(); ctx->srgb_lut.release(); ctx->tri_uv.release(); ctx->tri_tan.release();
     ctx->ref_spheres.release();
     for (int c = 0; c < PRT_MAX_CHAINS; ++c) {

@@ -41,6 +41,7 @@ struct PrtOptions {
     long long pool_shared = -1;             // pool pipeline: 1 = the four waves of a block share one pool, 0 = wave-private pools; -1 = the build's default
     long long pool_fair = -1;               // experiment: pool capacity and largest top-up = this many eighths of a wave's fair share of the samples
     long long work_reverse = 0;             // experiment: hand the call's pixels out last-to-first (dev_scene.h DevParams::work_reverse_n)
+    long long pool_flow = -1;               // pool pipeline without rounds (kernels_flow.h: tracer waves + a shading wave per workgroup); 1 / 0, -1 = the build's default
     long long pool_shared_cap = -1;         // ... slots per WAVE of a shared pool before the x4 (experiments)
     long long pass_samples = -1, pass_mb = -1, stack_cap = -1, no_tiles = 0;
     long long reserve_cus = 0;              // creation only: compute units the context's streams leave free
@@ -64,7 +65,7 @@ inline const OptEntry * option_table(size_t * n) {
         { "CHAINS", &PrtOptions::chains, nullptr }, { "SHADE_BLOCK", &PrtOptions::shade_block, nullptr },
         { "POOL_BLOCKS_PER_CU", &PrtOptions::pool_blocks_per_cu, nullptr }, { "POOL_CAP", &PrtOptions::pool_cap, nullptr },
         { "POOL_TOPUP", &PrtOptions::pool_topup, nullptr }, { "POOL_MAX_SAMPLES", &PrtOptions::pool_max_samples, nullptr },
-        { "POOL_PARK_CAP", &PrtOptions::pool_park_cap, nullptr }, { "POOL_SHARED", &PrtOptions::pool_shared, nullptr }, { "POOL_FAIR", &PrtOptions::pool_fair, nullptr }, { "WORK_REVERSE", &PrtOptions::work_reverse, nullptr },
+        { "POOL_PARK_CAP", &PrtOptions::pool_park_cap, nullptr }, { "POOL_SHARED", &PrtOptions::pool_shared, nullptr }, { "POOL_FAIR", &PrtOptions::pool_fair, nullptr }, { "POOL_FLOW", &PrtOptions::pool_flow, nullptr }, { "WORK_REVERSE", &PrtOptions::work_reverse, nullptr },
         { "POOL_SHARED_CAP", &PrtOptions::pool_shared_cap, nullptr }, { "PASS_SAMPLES", &PrtOptions::pass_samples, nullptr },
         { "PASS_MB", &PrtOptions::pass_mb, nullptr }, { "STACK_CAP", &PrtOptions::stack_cap, nullptr }, { "NO_TILES", &PrtOptions::no_tiles, nullptr },
         { "RESERVE_CUS", &PrtOptions::reserve_cus, nullptr }, { "RESERVE_PATTERN", &PrtOptions::reserve_pattern, nullptr }, { "LEAF_MAX", &PrtOptions::leaf_max, nullptr },
