@@ -142,6 +142,32 @@ PRT_D void trav_init(TravRay & r, f3 o, f3 d, int kind, float pad, const STK & s
     r.node = 0;
 }
 
+// A ray's traversal registers as dwords, and its stack column copied from another lane's: what a wave needs to take over a ray
+// another wave of its workgroup was tracing (kernels_pool.h: rays handed over at the end of a round).  Field k at dst[k * stride].
+#if defined(PRT_BVH4_SIX_PLANE_OFFSETS)
+#error "trav_save_regs / trav_restore_regs cover the default ray state (three plane offsets)"
+#endif
+enum { TRAV_STATE_DWORDS = 19 };
+PRT_D void trav_save_regs(const TravRay & r, float * dst, unsigned int stride) {
+    const float f[TRAV_STATE_DWORDS] = { r.o.x, r.o.y, r.o.z, r.d.x, r.d.y, r.d.z, r.ix, r.iy, r.iz, r.pnx, r.pny, r.pnz,
+                                         r.best.t, r.best.v, r.best.w, as_f(r.best.tri), as_f(r.node), as_f(r.sp), as_f(r.kind) };
+#pragma unroll
+    for (int k = 0; k < TRAV_STATE_DWORDS; ++k) dst[(size_t)k * stride] = f[k];
+}
+PRT_D void trav_restore_regs(TravRay & r, const float * src, unsigned int stride) {
+    float f[TRAV_STATE_DWORDS];
+#pragma unroll
+    for (int k = 0; k < TRAV_STATE_DWORDS; ++k) f[k] = src[(size_t)k * stride];
+    r.o = mk3(f[0], f[1], f[2]); r.d = mk3(f[3], f[4], f[5]);
+    r.ix = f[6]; r.iy = f[7]; r.iz = f[8]; r.pnx = f[9]; r.pny = f[10]; r.pnz = f[11];
+    r.best.t = f[12]; r.best.v = f[13]; r.best.w = f[14]; r.best.tri = as_i(f[15]);
+    r.node = as_i(f[16]); r.sp = as_i(f[17]); r.kind = as_i(f[18]);
+}
+template <class STK>
+PRT_D void trav_copy_stack(const STK & dst, const STK & src, int sp) {
+    for (int e = 0; e < sp; ++e) dst.push(e, src.pop(e));
+}
+
 PRT_D void cswap(float & ka, float & kb, int & la, int & lb) {
     const bool sw = kb < ka;
     const float k0 = sw ? kb : ka, k1 = sw ? ka : kb;

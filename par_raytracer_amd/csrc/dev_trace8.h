@@ -123,6 +123,29 @@ PRT_D bool trav_at_leaf(const TravRay & r) { return (r.tbits & 0xFFu) != 0u; }
 PRT_D bool trav_walking(const TravRay & r) { return (r.tbits & 0xFFu) == 0u && r.node >= 0; }    // wants a node step
 PRT_D bool trav_done(const TravRay & r) { return (r.tbits & 0xFFu) == 0u && r.node < 0; }
 
+// A ray's traversal registers as dwords, and its stack column copied from another lane's (dev_trace4.h has the commentary).
+enum { TRAV_STATE_DWORDS = 21 };
+PRT_D void trav_save_regs(const TravRay & r, float * dst, unsigned int stride) {
+    const float f[TRAV_STATE_DWORDS] = { r.o.x, r.o.y, r.o.z, r.d.x, r.d.y, r.d.z, r.ix, r.iy, r.iz, r.pnx, r.pny, r.pnz,
+                                         r.best.t, r.best.v, r.best.w, as_f(r.best.tri), as_f(r.node), as_f((int)r.tbase), as_f((int)r.tbits),
+                                         as_f(r.sp), as_f(r.kind) };
+#pragma unroll
+    for (int k = 0; k < TRAV_STATE_DWORDS; ++k) dst[(size_t)k * stride] = f[k];
+}
+PRT_D void trav_restore_regs(TravRay & r, const float * src, unsigned int stride) {
+    float f[TRAV_STATE_DWORDS];
+#pragma unroll
+    for (int k = 0; k < TRAV_STATE_DWORDS; ++k) f[k] = src[(size_t)k * stride];
+    r.o = mk3(f[0], f[1], f[2]); r.d = mk3(f[3], f[4], f[5]);
+    r.ix = f[6]; r.iy = f[7]; r.iz = f[8]; r.pnx = f[9]; r.pny = f[10]; r.pnz = f[11];
+    r.best.t = f[12]; r.best.v = f[13]; r.best.w = f[14]; r.best.tri = as_i(f[15]);
+    r.node = as_i(f[16]); r.tbase = (unsigned int)as_i(f[17]); r.tbits = (unsigned int)as_i(f[18]); r.sp = as_i(f[19]); r.kind = as_i(f[20]);
+}
+template <class STK>
+PRT_D void trav_copy_stack(const STK & dst, const STK & src, int sp) {
+    for (int e = 0; e < sp; ++e) dst.put(e, src.get(e));
+}
+
 // After a traversal ended: what its marker says.  0 for a ray that ended on an any-hit occluder (a found occluder is final
 // whatever happened before).
 template <class STK> PRT_D int trav_end_flags(const TravRay & r, const STK & stk) {

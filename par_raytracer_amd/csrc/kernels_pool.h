@@ -72,6 +72,11 @@ struct PoolBuffers {
     // diagnostics (COUNT kernels, option DEBUG_UTIL): per wave of the fast kernel, the 100 MHz wall clock at (start of its main
     // loop, the moment the sample counter ran dry for it, its exit); NULL otherwise
     unsigned long long * wave_times;
+    // block-shared pools, experiment POOL_EXCHANGE: rays in flight that a wave hands to the other waves of its block when the
+    // round's list is dry and it is down to xchg_max of them or fewer (see k_pool's trace phase)
+    unsigned int guided, guided_min;     // guided self-scheduling of the top-ups (wave-private pools): see the top-up
+    float * xchg;                // [units][4][POOL_XCHG_FIELDS][xchg_max]
+    unsigned int xchg_max;       // 0: no exchange
 };
 
 // Emitter of k_pool: appends to the unit's lists, slots by rank among the appending lanes.  Per-wave pools (SHARED = false):
@@ -154,7 +159,21 @@ template <bool SHARED> PRT_D void pool_sync() {
 enum { PCTL_TRACE_NEXT = 0,      // rays of the trace phase handed out so far
        PCTL_TOPUP_BASE = 1,      // the sample counter's value this top-up got
        PCTL_CNT = 4,             // [2][4]: (closest, shadow, finalise, started-ahead) entries of the lists being filled, by parity of `cur`
-       PCTL_WORDS = 12 };
+       // the ray exchange of a trace phase (PoolBuffers::xchg), zeroed / set again behind the barrier that ends the phase:
+       PCTL_X_TRACING = 12,      // waves of the block still tracing (a wave that hands its rays over, or has none left, leaves)
+       PCTL_X_PENDING = 13,      // waves that have left and are still writing the rays they hand over
+       PCTL_X_PUB = 14,          // [4]: rays wave w has handed over this round (published once, when all of them are written)
+       PCTL_X_TAKEN = 18,        // [4]: of those, rays other waves have taken
+       PCTL_WORDS = 22 };
+// Measured and NOT built in by default (profiles/r04_ray_exchange.txt: images identical, every workload 1 - 7 % slower - a drain
+// is bound by its longest ray, not by the vector issue its thin waves take): -DPRT_POOL_EXCHANGE_BUILD=1 compiles it, the
+// option POOL_EXCHANGE = n turns it on.
+#ifndef PRT_POOL_EXCHANGE_BUILD
+#define PRT_POOL_EXCHANGE_BUILD 0
+#endif
+enum { POOL_XCHG_MAX = 32 };     // most rays a wave hands over
+// a handed-over ray: its traversal registers, then (list index, sample, the thread whose LDS column holds its stack, payload)
+enum { POOL_XCHG_FIELDS = TRAV_STATE_DWORDS + 7 };
 
 // Everything the kernel is told, in device memory.  Passed by value these ~130 dwords are loaded into SGPRs at kernel
 // entry and stay live through every loop; the kernel then spills ~170 SGPRs into VGPR lanes and reloads them with
@@ -267,7 +286,7 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_pool(const PoolArgs * args, De
         }
     }
     if (threadIdx.x < 2) s_red[threadIdx.x] = 0ull;
-    if (SHARED && threadIdx.x < (unsigned int)PCTL_WORDS) s_ctl[threadIdx.x] = 0u;
+    if (SHARED && threadIdx.x < (unsigned int)PCTL_WORDS) s_ctl[threadIdx.x] = threadIdx.x == (unsigned int)PCTL_X_TRACING ? (unsigned int)(BLOCK / 64) : 0u;
     __syncthreads();
 
     const unsigned int slot_id = blockIdx.x * BLOCK + threadIdx.x;
@@ -372,9 +391,25 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_pool(const PoolArgs * args, De
                     rays -= cnt;                  // these rays were counted when the first launch traced them (raytracer.cpp:161: one TraceRay each)
                 }
             }
-          } else if (n_c + n_f - n_spec + Q.topup_min <= cap) {
+          } else if (n_c + n_f - n_spec + (!SHARED && Q.guided ? (Q.guided_min < Q.topup_min ? Q.guided_min : Q.topup_min) : Q.topup_min) <= cap) {
             unsigned int want = cap - (n_c + n_f - n_spec);
             if (want > Q.topup_max) want = Q.topup_max;
+            if (!SHARED && Q.guided) {
+                // guided self-scheduling (option POOL_GUIDED; adaptive mode's default): towards the end of the call no wave takes
+                // more than its share of what is left (x guided / 8), so that the last units - in adaptive mode pixels with up
+                // to max_spp samples to run one after the other - are spread over all waves instead of filling the pools of the
+                // waves that asked last (C4 adaptive 125.7 -> 123.2 ms, fixed-spp frames and shards unchanged:
+                // profiles/r04_ray_exchange.txt).  The counter is read without claiming anything; the value may be stale, the
+                // claim below is not.
+                const unsigned int taken = __hip_atomic_load(Q.head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned int left = taken < B.n_samples ? B.n_samples - taken : 0u;
+                const unsigned int n_units = gridDim.x * (unsigned int)(BLOCK / 64);
+                unsigned int lim = (unsigned int)(((unsigned long long)left * Q.guided) / (8ull * n_units));
+                if (lim < Q.guided_min) lim = Q.guided_min;
+                if (want < (lim < Q.topup_min ? lim : Q.topup_min)) want = 0u;          // not worth a top-up yet
+                else if (want > lim) want = lim;
+            }
+            if (want != 0u) {
             unsigned int base = 0;
             if (SHARED) {
                 if (threadIdx.x == 0) s_ctl[PCTL_TOPUP_BASE] = atomicAdd(Q.head, want);
@@ -413,6 +448,7 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_pool(const PoolArgs * args, De
                 }
                 n_c += cnt;
             }
+            }
           }
         }
         if (COUNT && fetch_done && wt_dry == 0ull) wt_dry = wall_clock64();
@@ -441,6 +477,12 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_pool(const PoolArgs * args, De
             int sample = 0;
             unsigned int next = 0;                                         // wave-uniform: rays handed out so far (SHARED: where this wave's last refill began)
             bool dry = total == 0u;                                        // wave-uniform: the list has no ray left to hand out
+            // the exchange (block-shared pools): see the end of this loop's head
+            const unsigned int xmax = SHARED && PRT_POOL_EXCHANGE_BUILD ? A.Q.xchg_max : 0u;      // (0 at compile time: the code below is not built)
+            const unsigned int xwave = (unsigned int)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+            float * const xbase = SHARED ? A.Q.xchg + (size_t)wave * (4u * (unsigned int)POOL_XCHG_FIELDS) * xmax : nullptr;
+            unsigned int x_spins = 0;
+            bool x_stays = false;                                           // wave-uniform: this wave found itself the last one tracing
             for (;;) {
                 const unsigned long long idle = __ballot(ray < 0);
                 if (idle != 0ull && !dry) {
@@ -487,9 +529,100 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_pool(const PoolArgs * args, De
                     next += take;
                     dry = next == total;
                 }
-                if (__ballot(ray >= 0) == 0ull) break;
+                int leave_below = dry ? 1 : keep_min;
+                if (SHARED && xmax != 0u && dry) {
+                    // ---- the exchange: a round ends with a drain - the list is dry and every wave walks its last rays down at a
+                    // falling lane fill (profiles/r04_round_drains.txt).  A wave that is down to xmax rays hands them to the
+                    // waves of its block that are still tracing and goes to the barrier; those take them into their idle lanes.
+                    // The registers travel through memory, the stack entries are copied from the giver's LDS column (it waits at
+                    // the barrier and does not touch it).  The last wave tracing cannot leave.
+                    // take: idle lanes <- rays handed over by waves that left
+                    if (__ballot(ray < 0) != 0ull) {
+                        for (unsigned int w2 = 0; w2 < (unsigned int)(BLOCK / 64); ++w2) {
+                            const unsigned int pub = __hip_atomic_load(&s_ctl[PCTL_X_PUB + w2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            if (pub == 0u) continue;
+                            const unsigned long long idle2 = __ballot(ray < 0);
+                            if (idle2 == 0ull) break;
+                            const unsigned int n_idle2 = (unsigned int)__popcll(idle2);
+                            unsigned int b = 0;
+                            if (lane == 0) b = atomicAdd(&s_ctl[PCTL_X_TAKEN + w2], n_idle2);       // (may run past `pub`: nobody adds rays to a published set)
+                            b = (unsigned int)__builtin_amdgcn_readfirstlane((int)b);
+                            if (b >= pub) continue;
+                            pool_fence();
+                            const unsigned int k = pub - b < n_idle2 ? pub - b : n_idle2;
+                            const unsigned int rank = __builtin_amdgcn_mbcnt_hi((unsigned int)(idle2 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)idle2, 0u));
+                            if (ray < 0 && rank < k) {
+                                const float * rec = xbase + (size_t)w2 * (unsigned int)POOL_XCHG_FIELDS * xmax + (b + rank);
+                                trav_restore_regs(r, rec, xmax);
+                                rec += (size_t)TRAV_STATE_DWORDS * xmax;
+                                ray = as_i(rec[0]);
+                                sample = as_i(rec[xmax]);
+                                Stack from = stack;
+                                from.attach(s_stack, (unsigned int)as_i(rec[2u * xmax]));
+                                payload = make_float4(rec[3u * xmax], rec[4u * xmax], rec[5u * xmax], rec[6u * xmax]);
+                                trav_copy_stack(stack, from, r.sp);
+                            }
+                        }
+                    }
+                    const unsigned int busy = (unsigned int)__popcll(__ballot(ray >= 0));
+                    if (!x_stays && busy <= xmax) {
+                        // leave: announce (pending first, so that the last wave waits for the records), step out, hand over
+                        unsigned int was = 0;
+                        if (lane == 0) {
+                            if (busy != 0u) atomicAdd(&s_ctl[PCTL_X_PENDING], 1u);
+                            was = atomicSub(&s_ctl[PCTL_X_TRACING], 1u);
+                        }
+                        was = (unsigned int)__builtin_amdgcn_readfirstlane((int)was);
+                        if (was != 1u) {
+                            if (busy != 0u) {
+                                const unsigned long long act = __ballot(ray >= 0);
+                                const unsigned int rank = __builtin_amdgcn_mbcnt_hi((unsigned int)(act >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)act, 0u));
+                                if (ray >= 0) {
+                                    float * rec = xbase + (size_t)xwave * (unsigned int)POOL_XCHG_FIELDS * xmax + rank;
+                                    trav_save_regs(r, rec, xmax);
+                                    rec += (size_t)TRAV_STATE_DWORDS * xmax;
+                                    rec[0] = as_f(ray);
+                                    rec[xmax] = as_f(sample);
+                                    rec[2u * xmax] = as_f((int)threadIdx.x);
+                                    rec[3u * xmax] = payload.x; rec[4u * xmax] = payload.y; rec[5u * xmax] = payload.z; rec[6u * xmax] = payload.w;
+                                }
+                                pool_fence();
+                                if (lane == 0) {
+                                    __hip_atomic_store(&s_ctl[PCTL_X_PUB + xwave], busy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                    pool_fence();
+                                    atomicSub(&s_ctl[PCTL_X_PENDING], 1u);
+                                }
+                            }
+                            break;
+                        }
+                        // the last wave tracing stays - until every wave that left has written its records and all are taken
+                        if (lane == 0) {
+                            atomicAdd(&s_ctl[PCTL_X_TRACING], 1u);
+                            if (busy != 0u) atomicSub(&s_ctl[PCTL_X_PENDING], 1u);
+                        }
+                        x_stays = true;
+                    }
+                    if (x_stays) {
+                        bool more = false;
+                        if (__hip_atomic_load(&s_ctl[PCTL_X_PENDING], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0u) more = true;
+                        for (unsigned int w2 = 0; w2 < (unsigned int)(BLOCK / 64); ++w2)
+                            if (__hip_atomic_load(&s_ctl[PCTL_X_TAKEN + w2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) <
+                                __hip_atomic_load(&s_ctl[PCTL_X_PUB + w2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) more = true;
+                        if (busy == 0u) {
+                            if (!more) break;
+                            if (++x_spins > (1u << 22)) { if (lane == 0) ctr->flow_error = 0x7801u; break; }      // (never seen; a hang would take the GPU with it)
+                            __builtin_amdgcn_s_sleep(2);
+                            continue;
+                        }
+                        // with rays of its own: come back for what is handed over every time a few lanes have fallen idle
+                        leave_below = more ? (int)busy - 3 : 1;
+                        if (leave_below < 1) leave_below = 1;
+                    } else {
+                        // (busy > xmax) come back to hand over, and on the way for what others have handed over
+                        leave_below = (int)busy - 7 > (int)xmax + 1 ? (int)busy - 7 : (int)xmax + 1;
+                    }
+                } else if (__ballot(ray >= 0) == 0ull) break;
 
-                const int leave_below = dry ? 1 : keep_min;
                 while (ray >= 0) {
                     const int walkers = __popcll(__ballot(trav_walking(r)));
                     const int wfrac = (walkers * node_frac) >> 3;
@@ -580,7 +713,9 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_pool(const PoolArgs * args, De
             emit.s_cnt = SHARED ? &s_ctl[PCTL_CNT + 4 * nxt] : nullptr;
             if (SHARED && threadIdx.x < 4u) {
                 s_ctl[PCTL_CNT + 4 * cur + threadIdx.x] = 0u;
-                if (threadIdx.x == 0) s_ctl[PCTL_TRACE_NEXT] = 0u;
+                s_ctl[PCTL_X_PUB + threadIdx.x] = 0u;
+                s_ctl[PCTL_X_TAKEN + threadIdx.x] = 0u;
+                if (threadIdx.x == 0) { s_ctl[PCTL_TRACE_NEXT] = 0u; s_ctl[PCTL_X_TRACING] = (unsigned int)(BLOCK / 64); s_ctl[PCTL_X_PENDING] = 0u; }
             }
             // the unit's list entries are shaded 64 at a time; a block-shared list by the block's waves in turn
             const unsigned int b_first = SHARED ? (threadIdx.x >> 6) * 64u : 0u;

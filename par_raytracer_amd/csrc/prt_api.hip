@@ -48,6 +48,9 @@ using namespace prt;
 #ifndef PRT_POOL_SHARED_DEFAULT
 #define PRT_POOL_SHARED_DEFAULT 1 // block-shared pools (kernels_pool.h) for fixed-spp renders when the option POOL_SHARED is not set
 #endif
+#ifndef PRT_POOL_EXCHANGE_DEFAULT
+#define PRT_POOL_EXCHANGE_DEFAULT 0   // block-shared pools: rays a wave hands over at the end of a round when the option POOL_EXCHANGE is not set (0: none)
+#endif
 #ifndef PRT_POOL_FLOW_DEFAULT
 #define PRT_POOL_FLOW_DEFAULT 0   // the pool pipeline without rounds (kernels_flow.h) for fixed-spp renders when the option POOL_FLOW is not set
 #endif
@@ -181,6 +184,7 @@ struct prt_ctx {
     DevBuf<FlowArgs> flow_args;           // k_flow's (kernels_flow.h)
     DevBuf<unsigned int> flow_u32;        // ... its slot id rings and free-slot stacks
 #endif
+    DevBuf<float> pool_xchg;                // block-shared pools: the rays waves hand to each other at the end of a round (PoolBuffers::xchg)
     DevBuf<unsigned long long> wave_times;  // DEBUG_UTIL + counting render: (start, counter dry, exit) wall clock of every wave of the fast kernel
     unsigned int wave_times_n = 0;
     DevBuf<float4> adapt_f4;              // adaptive mode: scratch [max_spp][n] + running sums [n] + final colours [n]
@@ -690,6 +694,18 @@ int launch_pool(prt_ctx * ctx, bool count, const DevCamera & cam, DevParams P, u
         Q.scratch = ctx->adapt_f4.p;
         Q.jobsum = Q.scratch + (size_t)P.max_spp * N;
         Q.final_rgb = Q.jobsum + N;
+    }
+    // guided top-ups: adaptive mode by default (a pixel is a chain of up to max_spp samples: the pixels started last are the frame's tail)
+    Q.guided = (unsigned int)std::max(0ll, std::min(64ll, opt.pool_guided >= 0 ? opt.pool_guided : (ADAPT ? 16ll : 0ll)));
+    Q.guided_min = (unsigned int)std::max(1ll, std::min(512ll, opt.pool_guided_min >= 0 ? opt.pool_guided_min : 8ll));
+    Q.xchg = nullptr; Q.xchg_max = 0;
+    {
+        const long long xm = opt.pool_exchange >= 0 ? opt.pool_exchange : PRT_POOL_EXCHANGE_DEFAULT;
+        if (shared && xm > 0 && PRT_POOL_EXCHANGE_BUILD) {
+            Q.xchg_max = (unsigned int)std::min<long long>(xm, POOL_XCHG_MAX);
+            HIP_TRY(ctx, ctx->pool_xchg.ensure((size_t)units * (BLOCK / 64) * POOL_XCHG_FIELDS * Q.xchg_max));
+            Q.xchg = ctx->pool_xchg.p;
+        }
     }
     Q.topup_max = topup_max == 0xFFFFFFFFu ? topup_max : topup_max * (shared ? (unsigned int)(BLOCK / 64) : 1u);
     Q.topup_min = ADAPT ? std::max(64u, cap / 2u) : std::max(64u, cap / 4u);
@@ -1445,7 +1461,7 @@ void prt_destroy(prt_ctx * ctx) {
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     ctx->nodes.release(); ctx->tris.release(); ctx->shade.release(); ctx->diffuse_dirs.release(); ctx->spec_dirs.release();
     ctx->tri_rank.release(); ctx->materials.release(); ctx->lights.release();
-    ctx->sample_rgb.release(); ctx->frame_out.release(); ctx->counters.release(); ctx->ring_ws.release(); ctx->pixel_list.release(); ctx->wf_counts.release(); ctx->stack_spill.release(); ctx->pool_f4.release(); ctx->pool_park.release(); ctx->pool_fin.release(); ctx->pool_args.release(); ctx->adapt_f4.release(); ctx->wave_times.release();
+    ctx->sample_rgb.release(); ctx->frame_out.release(); ctx->counters.release(); ctx->ring_ws.release(); ctx->pixel_list.release(); ctx->wf_counts.release(); ctx->stack_spill.release(); ctx->pool_f4.release(); ctx->pool_park.release(); ctx->pool_fin.release(); ctx->pool_args.release(); ctx->adapt_f4.release(); ctx->wave_times.release(); ctx->pool_xchg.release();
 #if defined(PRT_FLOW_EXPERIMENT)
     ctx->flow_args.release(); ctx->flow_u32.release();
 #endif

@@ -39,6 +39,9 @@ struct PrtOptions {
     long long chunk_min = -1, trace_blocks_per_cu = -1, keep_min = -1, node_min = -1, node_frac = -1, chains = -1, shade_block = -1;
     long long pool_blocks_per_cu = -1, pool_cap = -1, pool_topup = -1, pool_max_samples = -1, pool_park_cap = -1;
     long long pool_shared = -1;             // pool pipeline: 1 = the four waves of a block share one pool, 0 = wave-private pools; -1 = the build's default
+    long long pool_exchange = -1;           // block-shared pools: a wave down to this many rays at the end of a round hands them to the block's other waves (0: off)
+    long long pool_guided = -1;             // towards the end a wave takes at most this many eighths of its share of what is left (0: off; default: 16 in adaptive mode)
+    long long pool_guided_min = -1;         // ... but at least this many units
     long long pool_fair = -1;               // experiment: pool capacity and largest top-up = this many eighths of a wave's fair share of the samples
     long long work_reverse = 0;             // experiment: hand the call's pixels out last-to-first (dev_scene.h DevParams::work_reverse_n)
     long long pool_flow = -1;               // pool pipeline without rounds (kernels_flow.h: tracer waves + a shading wave per workgroup); 1 / 0, -1 = the build's default
@@ -65,7 +68,7 @@ inline const OptEntry * option_table(size_t * n) {
         { "CHAINS", &PrtOptions::chains, nullptr }, { "SHADE_BLOCK", &PrtOptions::shade_block, nullptr },
         { "POOL_BLOCKS_PER_CU", &PrtOptions::pool_blocks_per_cu, nullptr }, { "POOL_CAP", &PrtOptions::pool_cap, nullptr },
         { "POOL_TOPUP", &PrtOptions::pool_topup, nullptr }, { "POOL_MAX_SAMPLES", &PrtOptions::pool_max_samples, nullptr },
-        { "POOL_PARK_CAP", &PrtOptions::pool_park_cap, nullptr }, { "POOL_SHARED", &PrtOptions::pool_shared, nullptr }, { "POOL_FAIR", &PrtOptions::pool_fair, nullptr }, { "POOL_FLOW", &PrtOptions::pool_flow, nullptr }, { "WORK_REVERSE", &PrtOptions::work_reverse, nullptr },
+        { "POOL_PARK_CAP", &PrtOptions::pool_park_cap, nullptr }, { "POOL_SHARED", &PrtOptions::pool_shared, nullptr }, { "POOL_FAIR", &PrtOptions::pool_fair, nullptr }, { "POOL_EXCHANGE", &PrtOptions::pool_exchange, nullptr }, { "POOL_GUIDED", &PrtOptions::pool_guided, nullptr }, { "POOL_GUIDED_MIN", &PrtOptions::pool_guided_min, nullptr }, { "POOL_FLOW", &PrtOptions::pool_flow, nullptr }, { "WORK_REVERSE", &PrtOptions::work_reverse, nullptr },
         { "POOL_SHARED_CAP", &PrtOptions::pool_shared_cap, nullptr }, { "PASS_SAMPLES", &PrtOptions::pass_samples, nullptr },
         { "PASS_MB", &PrtOptions::pass_mb, nullptr }, { "STACK_CAP", &PrtOptions::stack_cap, nullptr }, { "NO_TILES", &PrtOptions::no_tiles, nullptr },
         { "RESERVE_CUS", &PrtOptions::reserve_cus, nullptr }, { "RESERVE_PATTERN", &PrtOptions::reserve_pattern, nullptr }, { "LEAF_MAX", &PrtOptions::leaf_max, nullptr },
