@@ -27,7 +27,10 @@
 // walks on with the rays in flight, fewer and fewer, until the last is done: 13 % of a C4 frame's wave-level node steps at 30 %
 // lane fill, 38 % of a 1/8 shard's, 49 % of the adaptive mode's.  Setting the last rays aside and resuming them in the next
 // round removes half of that and gains nothing: the carried ray's sample is shaded a round later, and pool slots, not lanes,
-// are what thin rounds are short of.
+// are what thin rounds are short of.  Handing the last rays to the other waves of the block (PRT_POOL_EXCHANGE_BUILD below)
+// shrinks the drains by a third and makes everything slower (profiles/r04_ray_exchange.txt): a drain's thin wave steps cost
+// next to nothing - the SIMD's other waves fill the issue slots - and the round ends with its longest ray, which no hand-over
+// shortens.  A kernel without rounds (kernels_flow.h) loses for another reason: its one shading wave per block is the bottleneck.
 //
 // Round 4: BLOCK-SHARED pools (template parameter SHARED).  A round that is private to a wave is thin where there is little
 // work per wave - a 1/8-frame shard of a multi-GPU run, the adaptive mode's one ray per pixel - and every thin round ends with
