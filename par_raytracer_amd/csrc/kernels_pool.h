@@ -395,8 +395,8 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_pool(const PoolArgs * args, De
                 }
             }
           } else if (n_c + n_f - n_spec + (!SHARED && Q.guided ? (Q.guided_min < Q.topup_min ? Q.guided_min : Q.topup_min) : Q.topup_min) <= cap) {
-            unsigned int want = cap - (n_c + n_f - n_spec);
-            if (want > Q.topup_max) want = Q.topup_max;
+            const unsigned int room = cap - (n_c + n_f - n_spec);
+            unsigned int want = room < Q.topup_max ? room : Q.topup_max;
             if (!SHARED && Q.guided) {
                 // guided self-scheduling (option POOL_GUIDED; adaptive mode's default): towards the end of the call no wave takes
                 // more than its share of what is left (x guided / 8), so that the last units - in adaptive mode pixels with up
@@ -409,7 +409,9 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_pool(const PoolArgs * args, De
                 const unsigned int n_units = gridDim.x * (unsigned int)(BLOCK / 64);
                 unsigned int lim = (unsigned int)(((unsigned long long)left * Q.guided) / (8ull * n_units));
                 if (lim < Q.guided_min) lim = Q.guided_min;
-                if (want < (lim < Q.topup_min ? lim : Q.topup_min)) want = 0u;          // not worth a top-up yet
+                // not worth a top-up yet?  Judged by the ROOM, not by what another clamp left of it, and never true of an empty
+                // pool (room = cap >= topup_min): a wave that could wait here for ever would never see the counter run dry
+                if (room < (lim < Q.topup_min ? lim : Q.topup_min)) want = 0u;
                 else if (want > lim) want = lim;
             }
             if (want != 0u) {
@@ -458,7 +460,7 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_pool(const PoolArgs * args, De
         const unsigned int total = n_c + n_s;
         if (total == 0u && n_f == 0u) {
             if (fetch_done) break;
-            continue;
+            continue;                      // (never twice in a row: an empty pool has room for any top-up, and a top-up that gets nothing sets fetch_done)
         }
         pool_sync<SHARED>();
         if (lead_wave) rays += total;                                      // debug->ray_count++  raytracer.cpp:161

@@ -1219,7 +1219,7 @@ int render_pixels_once(prt_ctx * ctx, const prt_camera * cam_in, const prt_param
     }
     if (h.flow_error) {
         char msg[160];
-        snprintf(msg, sizeof(msg), "prt_render: a wait inside the round-free pool kernel exceeded its watchdog (mask 0x%x): the frame is incomplete", h.flow_error);
+        snprintf(msg, sizeof(msg), "prt_render: a wait inside a pool kernel exceeded its watchdog (code 0x%x): the frame is incomplete", h.flow_error);
         ctx->error = msg;
         return -5;
     }

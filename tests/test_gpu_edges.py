@@ -458,3 +458,43 @@ def test_near_tie_resolution_that_gives_up_is_reported():
 def load_golden_or_skip(name):
     from conftest import load_golden
     return load_golden(name)
+
+
+@pytest.mark.parametrize("mode", ["fixed", "adaptive", "deep"])
+def test_the_image_does_not_depend_on_how_the_pools_are_scheduled(mode):
+    """Which wave (or workgroup) takes which sample, how much it takes at once, in which order the pixels are handed out and how
+    full a wave keeps its lanes are scheduling decisions of the pool pipeline (kernels_pool.h): pool ownership (POOL_SHARED),
+    guided top-ups (POOL_GUIDED, adaptive mode's default), capacity and thresholds (POOL_CAP, POOL_FAIR, POOL_TOPUP, KEEP_MIN,
+    NODE_MIN), work order (WORK_REVERSE, NO_TILES).  A pixel is a pure function of (scene, camera, params, seed, pixel index)
+    (SURVEY 8(b) "Determinism"), so every setting must give the same bits and the same ray count, and those are the oracle's."""
+    from par_raytracer_amd import api
+    import oracle_py as orc
+    w, h = 96, 54
+    s, hs, cam = _setup("terrain_64", w, h)
+    if mode == "fixed":
+        p = api.default_params(4, 11, pipeline=PIPELINES["pool"])
+    elif mode == "adaptive":
+        p = api.default_params(3, 11, pipeline=PIPELINES["pool"], max_spp=12)
+    else:
+        p = api.default_params(2, 11, pipeline=PIPELINES["pool"], bounce_depth=7)          # more than 15 draws: the RNG ring in memory
+    settings = [{"POOL_SHARED": 0}, {"POOL_SHARED": 1}, {"POOL_SHARED": 0, "POOL_GUIDED": 0}, {"POOL_SHARED": 0, "POOL_GUIDED": 4, "POOL_GUIDED_MIN": 1},
+                {"POOL_SHARED": 0, "POOL_GUIDED": 64, "POOL_GUIDED_MIN": 3}, {"WORK_REVERSE": 1}, {"NO_TILES": 1}, {"POOL_FAIR": 3}, {"POOL_SHARED": 1, "POOL_FAIR": 8},
+                {"POOL_CAP": 64, "POOL_TOPUP": 1}, {"POOL_CAP": 4096, "POOL_TOPUP": 64}, {"KEEP_MIN": 1, "NODE_MIN": 0}, {"KEEP_MIN": 64, "NODE_MIN": 64},
+                {"POOL_BLOCKS_PER_CU": 1}, {"POOL_SHARED": 1, "POOL_SHARED_CAP": 64, "WORK_REVERSE": 1}]
+    r = api.Renderer(0)
+    try:
+        r.upload(hs)
+        ref, cref = r.render(cam, p, w, h)
+        want, wc = orc.render(hs.desc, cam, p, w, h, 1, 8)
+        assert cref.ray_count == wc.ray_count
+        assert float(np.abs(ref[:, :3] - want.reshape(-1, 4)[:, :3]).max()) <= TOL
+        for st in settings:
+            for k, v in st.items():
+                r.set_option(k, v)
+            img, c = r.render(cam, p, w, h)
+            for k in st:
+                r.set_option(k, None)
+            assert c.ray_count == cref.ray_count, st
+            assert np.array_equal(img.view(np.uint32), ref.view(np.uint32)), st
+    finally:
+        r.close()
