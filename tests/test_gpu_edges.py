@@ -460,17 +460,20 @@ def load_golden_or_skip(name):
     return load_golden(name)
 
 
-@pytest.mark.parametrize("mode", ["fixed", "adaptive", "deep"])
-def test_the_image_does_not_depend_on_how_the_pools_are_scheduled(mode):
+@pytest.mark.parametrize("scene,light_mode,mode", [("terrain_64", 0, "fixed"), ("terrain_64", 0, "adaptive"), ("terrain_64", 0, "deep"),
+                                                   ("textured_gallery", 0, "fixed"), ("coincident", 2, "fixed"), ("coincident", 2, "adaptive"),
+                                                   ("many_materials", 1, "adaptive"), ("many_materials", 2, "deep")])
+def test_the_image_does_not_depend_on_how_the_pools_are_scheduled(scene, light_mode, mode):
     """Which wave (or workgroup) takes which sample, how much it takes at once, in which order the pixels are handed out and how
     full a wave keeps its lanes are scheduling decisions of the pool pipeline (kernels_pool.h): pool ownership (POOL_SHARED),
     guided top-ups (POOL_GUIDED, adaptive mode's default), capacity and thresholds (POOL_CAP, POOL_FAIR, POOL_TOPUP, KEEP_MIN,
     NODE_MIN), work order (WORK_REVERSE, NO_TILES).  A pixel is a pure function of (scene, camera, params, seed, pixel index)
-    (SURVEY 8(b) "Determinism"), so every setting must give the same bits and the same ray count, and those are the oracle's."""
+    (SURVEY 8(b) "Determinism"), so every setting must give the same bits and the same ray count, and those are the oracle's.
+    Scenes: plain, textured, coincident faces (rays parked for the exact launches), many materials with translucency."""
     from par_raytracer_amd import api
     import oracle_py as orc
     w, h = 96, 54
-    s, hs, cam = _setup("terrain_64", w, h)
+    s, hs, cam = _setup(scene, w, h, light_mode=light_mode)
     if mode == "fixed":
         p = api.default_params(4, 11, pipeline=PIPELINES["pool"])
     elif mode == "adaptive":
@@ -492,6 +495,36 @@ def test_the_image_does_not_depend_on_how_the_pools_are_scheduled(mode):
             for k, v in st.items():
                 r.set_option(k, v)
             img, c = r.render(cam, p, w, h)
+            for k in st:
+                r.set_option(k, None)
+            assert c.ray_count == cref.ray_count, st
+            assert np.array_equal(img.view(np.uint32), ref.view(np.uint32)), st
+    finally:
+        r.close()
+
+
+@pytest.mark.parametrize("scene,light_mode", [("terrain_64", 0), ("coincident", 2), ("textured_gallery", 0)])
+def test_the_image_does_not_depend_on_how_the_wavefront_pipeline_is_tuned(scene, light_mode):
+    """The same for the launch-per-round pipeline's knobs (kernels_wave.h): chains in flight, block sizes, blocks per CU, the
+    chunk below which rounds are merged, lane thresholds, pass size - and for which pipeline renders at all."""
+    from par_raytracer_amd import api
+    w, h = 96, 54
+    s, hs, cam = _setup(scene, w, h, light_mode=light_mode)
+    settings = [{"CHAINS": 1}, {"CHAINS": 4}, {"SHADE_BLOCK": 256}, {"SHADE_BLOCK": 1024}, {"TRACE_BLOCKS_PER_CU": 1}, {"TRACE_BLOCKS_PER_CU": 8},
+                {"CHUNK_MIN": 1}, {"CHUNK_MIN": 1000000}, {"KEEP_MIN": 1, "NODE_MIN": 0}, {"KEEP_MIN": 64, "NODE_MIN": 64}, {"PASS_SAMPLES": 777},
+                {"NO_TILES": 1}, {"STACK_CAP": 3}]
+    r = api.Renderer(0)
+    try:
+        r.upload(hs)
+        p_pool = api.default_params(4, 23, pipeline=PIPELINES["pool"], bounce_depth=3)
+        p_wave = api.default_params(4, 23, pipeline=PIPELINES["wavefront"], bounce_depth=3)
+        ref, cref = r.render(cam, p_pool, w, h)
+        img, c = r.render(cam, p_wave, w, h)
+        assert c.ray_count == cref.ray_count and np.array_equal(img.view(np.uint32), ref.view(np.uint32))
+        for st in settings:
+            for k, v in st.items():
+                r.set_option(k, v)
+            img, c = r.render(cam, p_wave, w, h)
             for k in st:
                 r.set_option(k, None)
             assert c.ray_count == cref.ray_count, st
