@@ -28,9 +28,14 @@ Extra objects on the JSON line:
                 x 16 B) / its duration, measured with HIP events on the kernel's own stream inside the timed region.  That
                 figure counts every per-lane node fetch, most of which the caches serve, so its label says what it is
                 ("cache-inclusive algorithmic bytes") and `hbm_measured` / `limiter` say what the memory system and the
-                kernel really do.  `traffic` = HBM bytes per launch from rocprofv3 PMC passes of this command
-                (profiles/traffic_C4.json, FETCH_SIZE x 2 + WRITE_SIZE as the gfx950 guide prescribes) - printed only when the
-                file was taken with the library that is running (its sha256 is in the file), else null.
+                kernel really do.  `traffic` = HBM bytes per launch, FETCH_SIZE x 2 + WRITE_SIZE as the gfx950 guide prescribes,
+                MEASURED IN THIS RUN (since round 4): before it touches the GPU the default command runs two short children of
+                itself under `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (a pass each, counters only; ~6 s each) and takes
+                the timed frames' kernel from their counter files (`traffic_source` says so).  Where that is not possible (no
+                rocprofv3, a refused or failing pass, N > 1, the quick forms with --no-cpu-baseline / --no-other-workloads) the
+                committed profiles/traffic_C4.json is used - only when it was taken with the library that is running (its
+                sha256 is in the file), else null.  The issue counters (valu_busy, ta_busy, wait_frac, L1 latency) always come
+                from that file, under the same condition.
   cpu_baseline  the CPU oracle ("port", oracle/prt_oracle.cpp, bit-identical to the compiled reference on every fixture) timed
                 on the physical cores of this host's socket 0, one pinned thread each, on a sparse pixel lattice of the SAME
                 frame; rank 0, N = 1 only.  The same lattice is the parity check of the GPU frame (max |dRGB|, ray counts).
@@ -215,6 +220,49 @@ def time_reference_on_host(obj_dir, cam_pos, cam_dir, fov, width, height, spp, d
             "sphere_check_count": int(sum(s["sphere_check_count"] for s in stats)), "mesh_check_count": int(sum(s["mesh_check_count"] for s in stats))}
 
 
+def measure_traffic_live(workload, pipeline):
+    """roofline.traffic measured in THIS run, on THIS box: FETCH_SIZE and WRITE_SIZE of the workload's kernels, each in a pass of
+    its own (counters only, no tracing - the gfx950 guide's recipe) over a short child run of this very file's timed loop.  Called
+    before this process touches the GPU; the children are ordinary child processes.  None when rocprofv3 is not there, fails,
+    or takes too long - the committed file is the fallback."""
+    import csv, glob, shutil, subprocess
+    exe = shutil.which("rocprofv3")
+    if not exe:
+        return None, "rocprofv3 not found"
+    out = tempfile.mkdtemp(prefix="prt_bench_pmc_")
+    per_kernel = {}
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", os.path.join(out, counter), "--",
+                   sys.executable, os.path.abspath(__file__), "--workload", workload, "--pipeline", str(pipeline), "--steps", "3", "--warmup", "1",
+                   "--no-cpu-baseline", "--no-other-workloads", "--no-live-traffic"]
+            env = dict(os.environ, TMPDIR="/tmp")
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=240)
+            if r.returncode != 0:
+                return None, "rocprofv3 --pmc %s failed (rc %d): %s" % (counter, r.returncode, r.stderr.decode(errors="replace")[-200:].replace("\n", " "))
+            for f in glob.glob(os.path.join(out, counter, "**", "*_counter_collection.csv"), recursive=True):
+                with open(f) as fh:
+                    for row in csv.DictReader(fh):
+                        if row["Counter_Name"] != counter:
+                            continue
+                        k = row["Kernel_Name"].replace("void prt::", "").replace("prt::", "").split("(")[0]
+                        d = per_kernel.setdefault(k, {"FETCH_SIZE": [0.0, 0], "WRITE_SIZE": [0.0, 0]})
+                        d[counter][0] += float(row["Counter_Value"]); d[counter][1] += 1
+    except Exception as e:                                       # a profiler that hangs or is refused must not cost the bench line
+        return None, "live PMC passes not usable here: %r" % (e,)
+    finally:
+        shutil.rmtree(out, ignore_errors=True)
+    res = {}
+    for k, d in per_kernel.items():
+        nf, nw = d["FETCH_SIZE"][1], d["WRITE_SIZE"][1]
+        if nf and nw:
+            f_kib, w_kib = d["FETCH_SIZE"][0] / nf, d["WRITE_SIZE"][0] / nw
+            # KiB units; FETCH_SIZE counts 64-byte requests as 32 on gfx950: corrected = 2 x FETCH + WRITE (upper bound), raw = FETCH + WRITE
+            res[k] = {"launches": nf, "bytes_corrected": int((2.0 * f_kib + w_kib) * 1024), "bytes_raw": int((f_kib + w_kib) * 1024)}
+    return (res or None), ("rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (a pass each, counters only) of 3 + 1 frames of this command, run by this "
+                           "process as children before it touched the GPU")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -230,6 +278,9 @@ def main():
                          "where its binary is present and runs, else the port")
     ap.add_argument("--cpu-seconds", type=float, default=120.0, help="CPU work of the baseline sample in core-seconds (the lattice is chosen to match)")
     ap.add_argument("--no-other-workloads", action="store_true", help="skip extra.other_workloads (C2, C3, C5, C4-adaptive)")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="do not measure roofline.traffic in this run (two rocprofv3 --pmc passes of a short child run before the GPU is touched); "
+                         "the committed profiles/traffic_<workload>.json is used instead when it was taken with this library")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend; gloo (host-staged) only exists to rehearse the N > 1 path on a 1-GPU box")
     ap.add_argument("--share-device", action="store_true", help="rehearsal: every rank uses GPU 0")
@@ -288,6 +339,14 @@ def main():
             if ref_run:
                 log("reference on %d pinned cores: lattice %d, %d rays in %.1f s (%.4f Mrays/s)" % (
                     ref_run["cores"], ref_run["lattice"], ref_run["ray_count"], ref_run["render_seconds"], ref_run["ray_count"] / ref_run["render_seconds"] / 1e6))
+    # ---- HBM traffic of the workload's kernels, measured on this box (N = 1 only; never from inside a profiler's own run)
+    live_traffic, live_traffic_note = None, None
+    under_profiler = "rocprof" in os.environ.get("LD_PRELOAD", "") or any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ)
+    # (the quick forms of this command that the A/B scripts use - no CPU baseline, no other workloads - skip it too)
+    if world == 1 and rank == 0 and not collective and not args.no_live_traffic and not under_profiler and not args.no_cpu_baseline and not args.no_other_workloads:
+        t0 = time.time()
+        live_traffic, live_traffic_note = measure_traffic_live(args.workload, args.pipeline)
+        log("live HBM traffic passes: %s (%.0f s)" % ("ok, %d kernels" % len(live_traffic) if live_traffic else live_traffic_note, time.time() - t0))
 
     import torch
     import torch.distributed as dist
@@ -521,6 +580,18 @@ def main():
         except Exception as e:
             traffic = None
             traffic_note = "profiles/traffic_%s.json unreadable: %r" % (args.workload, e)
+    if live_traffic:
+        # this run's own measurement wins over the file: the timed frames' kernel is the instantiation of `kernel_name` that was
+        # launched most often and, among those, moved the most bytes (the counting render's instantiation runs once; the EXACT
+        # follow-up launch of the same template runs as often as the fast kernel and moves next to nothing)
+        cand = [((v["launches"], v["bytes_corrected"]), k, v) for k, v in live_traffic.items() if k.startswith(kernel_name + "<") or k == kernel_name]
+        if cand:
+            _, lk, lv = max(cand)
+            traffic = lv["bytes_corrected"] * max(1, int(cc.trace_kernel_launches))      # per frame: mean launch x launches of a frame
+            traffic_note = "measured in this run: %s; kernel %s, %d launches, %.2f GB per launch corrected (2 x FETCH + WRITE), %.2f GB raw" % (
+                live_traffic_note, lk, lv["launches"], lv["bytes_corrected"] / 1e9, lv["bytes_raw"] / 1e9)
+    elif live_traffic_note:
+        traffic_note += "; live measurement: " + live_traffic_note
     launches = max(1, int(cc.trace_kernel_launches))
     lane_util = None
     if st.wave_node_steps and st.wave_tri_steps:

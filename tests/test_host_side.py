@@ -744,3 +744,46 @@ def test_driver_reports_missing_scene(tmp_path):
     p = subprocess.run([exe, "-d", str(tmp_path), "--obj", "nope.obj", "-w", "8", "-h", "8"], stdout=subprocess.PIPE,
                        stderr=subprocess.PIPE, timeout=60)
     assert p.returncode == 1 and b"Cannot load" in p.stderr
+
+
+def test_bench_folds_its_own_pmc_passes_into_bytes_per_launch(tmp_path, monkeypatch):
+    """bench.py measures roofline.traffic in the run that prints it: two `rocprofv3 --pmc` child passes of itself (FETCH_SIZE,
+    WRITE_SIZE; counters only) whose counter files it folds into bytes per launch of every kernel - corrected = 2 x FETCH + WRITE
+    (KiB units), as the gfx950 guide prescribes.  Here with a stand-in for the profiler that writes the files such a pass writes:
+    the command line must be a plain `rocprofv3 --pmc <one counter> ... -- python bench.py ... --no-live-traffic` (no tracing
+    beside the counters, no recursion), and a failing pass must give None, not an exception."""
+    import importlib.util, stat, sys
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    fake = tmp_path / "bin"
+    fake.mkdir()
+    log = tmp_path / "calls.txt"
+    script = fake / "rocprofv3"
+    script.write_text("""#!/usr/bin/env python3
+import os, sys
+a = sys.argv[1:]
+open(%r, "a").write(" ".join(a) + "\\n")
+if os.environ.get("FAKE_ROCPROF_FAILS"): sys.exit(3)
+counter, out = a[a.index("--pmc") + 1], a[a.index("-d") + 1]
+d = os.path.join(out, "host", "runc"); os.makedirs(d)
+rows = {"FETCH_SIZE": [("void prt::k_pool<256, 5, false>(prt::PoolArgs const*)", 1000.0), ("void prt::k_pool<256, 5, false>(prt::PoolArgs const*)", 3000.0), ("void prt::k_pool<256, 5, true>(prt::PoolArgs const*)", 9000.0)],
+        "WRITE_SIZE": [("void prt::k_pool<256, 5, false>(prt::PoolArgs const*)", 500.0), ("void prt::k_pool<256, 5, false>(prt::PoolArgs const*)", 700.0), ("void prt::k_pool<256, 5, true>(prt::PoolArgs const*)", 100.0)]}[counter]
+with open(os.path.join(d, "1_counter_collection.csv"), "w") as f:
+    f.write("Kernel_Name,Counter_Name,Counter_Value\\n")
+    for k, v in rows: f.write('"%%s",%%s,%%s\\n' %% (k, counter, v))
+""" % str(log))
+    script.chmod(script.stat().st_mode | stat.S_IEXEC)
+    monkeypatch.setenv("PATH", str(fake) + os.pathsep + os.environ["PATH"])
+    res, note = bench.measure_traffic_live("C4", 0)
+    fast, counting = res["k_pool<256, 5, false>"], res["k_pool<256, 5, true>"]
+    assert fast["launches"] == 2 and fast["bytes_raw"] == int((2000.0 + 600.0) * 1024) and fast["bytes_corrected"] == int((2 * 2000.0 + 600.0) * 1024)
+    assert counting["launches"] == 1 and counting["bytes_corrected"] == int((2 * 9000.0 + 100.0) * 1024)
+    calls = log.read_text().splitlines()
+    assert len(calls) == 2 and "--pmc FETCH_SIZE" in calls[0] and "--pmc WRITE_SIZE" in calls[1]
+    for c in calls:
+        assert "--no-live-traffic" in c and "--no-cpu-baseline" in c and "bench.py" in c.split(" -- ")[1]
+        assert not any(t in c.split(" -- ")[0] for t in ("--kernel-trace", "--sys-trace", "--hip-trace", "--stats", "-r ", "-s "))
+    monkeypatch.setenv("FAKE_ROCPROF_FAILS", "1")
+    res, note = bench.measure_traffic_live("C4", 0)
+    assert res is None and "failed" in note

@@ -7,7 +7,7 @@ root="$(cd "$(dirname "$0")/.." && pwd)"
 out="$root/gpurun_out/prof_round"
 rm -rf "$out"; mkdir -p "$out"       # (gpurun MERGES this directory into the local one: delete the local copy before a new round of passes)
 cd /tmp && export TMPDIR=/tmp
-BENCH="python3 $root/bench.py --no-cpu-baseline --no-other-workloads --steps 5 --warmup 1"
+BENCH="python3 $root/bench.py --no-cpu-baseline --no-other-workloads --no-live-traffic --steps 5 --warmup 1"
 echo "kernel trace" | tee -a "$out/progress.txt"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -- $BENCH > "$out/trace.log" 2>&1 || echo "trace failed" >> "$out/failed.txt"
 pass() {
@@ -22,6 +22,6 @@ pass sq2 SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_
 pass ta GRBM_GUI_ACTIVE TA_TA_BUSY_sum TA_BUSY_avr
 pass tcp TCP_TCP_LATENCY_sum TCP_TA_TCP_STATE_READ_sum TCP_PENDING_STALL_CYCLES_sum
 echo "adaptive trace" | tee -a "$out/progress.txt"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace_other" -- python3 $root/bench.py --no-cpu-baseline --steps 2 --warmup 1 > "$out/trace_other.log" 2>&1 || echo "trace_other failed" >> "$out/failed.txt"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace_other" -- python3 $root/bench.py --no-cpu-baseline --no-live-traffic --steps 2 --warmup 1 > "$out/trace_other.log" 2>&1 || echo "trace_other failed" >> "$out/failed.txt"
 echo done | tee -a "$out/progress.txt"
 cat "$out/failed.txt" 2>/dev/null
