@@ -237,7 +237,17 @@ def measure_traffic_live(workload, pipeline):
                    sys.executable, os.path.abspath(__file__), "--workload", workload, "--pipeline", str(pipeline), "--steps", "3", "--warmup", "1",
                    "--no-cpu-baseline", "--no-other-workloads", "--no-live-traffic"]
             env = dict(os.environ, TMPDIR="/tmp")
-            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=90)      # a pass takes ~6 s; a profiler that hangs costs the bench 90 s, not its line
+            # its own session, so that a pass that hangs is ended WITH its children (a pass takes ~6 s; a profiler that hangs costs
+            # the bench 90 s, not its line)
+            pr = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, start_new_session=True)
+            try:
+                _, err = pr.communicate(timeout=90)
+            except subprocess.TimeoutExpired:
+                import signal
+                os.killpg(pr.pid, signal.SIGKILL)
+                pr.communicate()
+                return None, "rocprofv3 --pmc %s did not end within 90 s" % counter
+            r = type("R", (), {"returncode": pr.returncode, "stderr": err})()
             if r.returncode != 0:
                 return None, "rocprofv3 --pmc %s failed (rc %d): %s" % (counter, r.returncode, r.stderr.decode(errors="replace")[-200:].replace("\n", " "))
             for f in glob.glob(os.path.join(out, counter, "**", "*_counter_collection.csv"), recursive=True):
