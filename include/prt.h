@@ -138,8 +138,11 @@ typedef struct prt_params {
      * The stopping rule compares a float variance of the pixel's sample colours with the threshold.  The device's sample
      * colours are reproducible bit for bit (fixed-point accumulation, see "Determinism" in DESIGN.md) but differ from the CPU
      * reference's in the last bits (device powf, throughput form of the colour polynomial), so a variance that lands within
-     * ~1e-6 of the threshold can stop a pixel one sample earlier or later than the reference would: in adaptive mode ray_count
-     * equals the reference's on every fixture tested, but that is an observation, not a guarantee as it is for fixed spp. */
+     * ~1e-6 of the threshold can stop a pixel one sample earlier or later than the reference would.  That is the ONLY way the
+     * two can part, and it is counted: prt_render_stats::variance_close_calls is the number of verdicts whose variance lay within
+     * 0.1 % of the threshold (a band some fifty times wider than the colours' last bits can move a variance).  0 - as on three of
+     * the four adaptive fixtures; the fourth has 2 such verdicts among ~10^5 and equal counts all the same - means every pixel
+     * stopped at the reference's sample and ray_count equals the reference's, as it does by construction for fixed spp. */
     uint32_t max_spp;
     float variance_threshold;
 } prt_params;
@@ -301,6 +304,8 @@ typedef struct prt_render_stats {
     uint64_t elided_shadow_rays;               /* shadow rays that are in ray_count but were not traced: their radiance-if-unoccluded
                                                 * was exactly zero, so no outcome could change the image (option
                                                 * TRACE_DEAD_SHADOW_RAYS=1 traces them all the same) */
+    uint64_t variance_close_calls;             /* adaptive mode: verdicts of the stopping rule whose variance lay within 0.1 % of the
+                                                * threshold.  0 = every pixel stopped at the reference's sample (see prt_params) */
     uint32_t stack_lds_entries, stack_bound;   /* LDS stack column height used, worst-case bound of the tree */
 } prt_render_stats;
 int prt_get_render_stats(const prt_ctx * ctx, prt_render_stats * stats);

@@ -92,7 +92,7 @@ class PrtRenderStats(C.Structure):
     _fields_ = [("node_visits", C.c_uint64), ("tri_tests", C.c_uint64), ("wave_node_steps", C.c_uint64),
                 ("wave_tri_steps", C.c_uint64), ("wave_leaf_visits", C.c_uint64), ("wave_refills", C.c_uint64),
                 ("deepest_stack", C.c_uint64), ("phase_cycles", C.c_uint64 * 5), ("parked_rays", C.c_uint64),
-                ("parked_shadow_rays", C.c_uint64), ("elided_shadow_rays", C.c_uint64), ("stack_lds_entries", C.c_uint32), ("stack_bound", C.c_uint32)]
+                ("parked_shadow_rays", C.c_uint64), ("elided_shadow_rays", C.c_uint64), ("variance_close_calls", C.c_uint64), ("stack_lds_entries", C.c_uint32), ("stack_bound", C.c_uint32)]
 
 
 PIPELINE_DEFAULT, PIPELINE_MEGAKERNEL, PIPELINE_WAVEFRONT, PIPELINE_PERSISTENT, PIPELINE_POOL = 0, 1, 2, 3, 4

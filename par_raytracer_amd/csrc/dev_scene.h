@@ -183,6 +183,9 @@ struct DevCounters {          // device-side accumulators (atomics, one add per 
     unsigned long long near_tie_unresolved;    // resolve_near_ties gave up widening its candidate set (the render call fails)
     unsigned long long flow_cycles[8];         // k_flow, COUNT builds: tracers waiting / whole loop; shading wave topping up / shading / waiting / whole loop; batches; hits in them
     unsigned int flow_error, flow_pad;         // k_flow (kernels_flow.h): a watchdog fired (bit mask of which wait; the render call fails)
+    // adaptive mode: stopping-rule verdicts whose variance lay within 0.1 % of the threshold (k_pool's finalise step): the only
+    // verdicts the device's last bits could turn against the reference's
+    unsigned long long variance_close_calls;
 };
 
 // Per-sample radiance accumulator of the wavefront and pool pipelines: 2^-32 fixed point in 64-bit integers.  A sample's

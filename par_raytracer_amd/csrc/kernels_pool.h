@@ -820,6 +820,10 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_pool(const PoolArgs * args, De
                             }
                             variance /= (float)(samp - 1u);
                             stop = variance <= P.variance_threshold;                // break BEFORE ++samp: the divisor misses this sample
+                            // a verdict this close to the threshold is the one place where the device's last bits (its powf, the
+                            // throughput form of the colour polynomial) could stop a pixel a sample away from the reference's:
+                            // counted, so that "no close call" = "the reference's sample counts" can be checked (include/prt.h)
+                            if (fabsf(variance - P.variance_threshold) <= 1e-3f * P.variance_threshold + 1e-7f) atomicAdd(&ctr->variance_close_calls, 1ull);
                         }
                         if (!stop) {
                             ++samp;

@@ -1242,6 +1242,7 @@ int render_pixels_once(prt_ctx * ctx, const prt_camera * cam_in, const prt_param
             for (int k = 0; k < 5; ++k) rs.phase_cycles[k] = h.phase_cycles[k];
             rs.parked_rays = h.park_peak[0]; rs.parked_shadow_rays = h.park_peak[1];
             rs.elided_shadow_rays = h.elided_shadow_rays;
+            rs.variance_close_calls = h.variance_close_calls;
             rs.stack_lds_entries = stack_entries; rs.stack_bound = ctx->stack_bound;
         }
         float ms = 0.0f;

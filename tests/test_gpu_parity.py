@@ -95,6 +95,45 @@ def test_adaptive_sampling_matches_reference_golden(gpu_renderer_factory, name):
         ctr.ray_count, int(g["ray_count"]), diff.max(), n_bad)
     assert n_bad == 0 and diff.max() <= TOL, "max|dRGB| = %g, %d pixels over %g" % (diff.max(), n_bad, TOL)
     assert np.all(img[:, :, 3] == 1.0)
+    # verdicts of the stopping rule within 0.1 % of the threshold are the only ones the device's last bits could turn (include/prt.h
+    # prt_params): rare - none on three of the fixtures, 2 of ~10^5 on the gallery - and not turned where they occur
+    r = gpu_renderer_factory(str(g["scene"]), int(g["light_mode"]))
+    assert r.render_stats().variance_close_calls <= 4
+
+
+def test_adaptive_close_calls_are_counted():
+    """prt_render_stats::variance_close_calls: a stopping-rule verdict whose variance lies within 0.1 % of the threshold (+1e-7) is
+    counted.  A threshold of 1e-30 makes every pixel that sees only sky (all samples the background colour, variance exactly 0)
+    such a verdict (at least one per sky pixel); the reference's 0.01 makes next to none; fixed spp has no verdicts at all."""
+    from conftest import host_scene, scene_dir
+    from par_raytracer_amd import api
+    import oracle_py as orc
+    s, _ = scene_dir("sphere_plane")
+    hs = host_scene("sphere_plane", 0)
+    w, h = 64, 48
+    cam = api.make_camera(s.fov, w, h, s.camera_position, s.camera_facing)
+    r = api.Renderer(0)
+    try:
+        r.upload(hs)
+        calls = {}
+        for thr in (1e-30, 0.01):
+            p = api.default_params(3, 5, pipeline=PIPELINES["pool"], max_spp=9, variance_threshold=thr)
+            ref, c_ref = orc.render(hs.desc, cam, p, w, h, 1, 8)
+            img, c = r.render(cam, p, w, h)
+            assert c.ray_count == c_ref.ray_count
+            calls[thr] = int(r.render_stats().variance_close_calls)
+        # (ref is the 0.01 render; the image's first pixel is sky: n + 1 samples of the background colour summed and divided by
+        # n, main.cpp:253-262 - a multiple of it)
+        bg = np.array(list(p.background_color)[:3], dtype=np.float32)
+        ratio = ref[0, 0, :3] / bg
+        assert ratio.max() - ratio.min() < 1e-5 and ratio[0] > 1.0
+        sky = int((np.abs(ref[:, :, :3] - ref[0, 0, :3]).max(axis=2) < 1e-6).sum())
+        assert sky > 50, "the camera was meant to see sky"
+        assert calls[1e-30] >= sky and calls[0.01] <= 4, calls          # (at 0.01 one of this image's ~15,000 verdicts happens to be that close)
+        img, c = r.render(cam, api.default_params(3, 5, pipeline=PIPELINES["pool"]), w, h)
+        assert r.render_stats().variance_close_calls == 0
+    finally:
+        r.close()
 
 
 def test_adaptive_sampling_shards_passes_and_refusals(gpu_renderer_factory, monkeypatch):
