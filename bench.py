@@ -789,6 +789,21 @@ def main():
                 dt = time.perf_counter() - t0
             pipelined = {"frames_in_flight": 2, "frames": n_fr, "ms_per_frame": round(dt * 1e3 / n_fr, 4),
                          "mrays_per_s": round(sum(c.ray_count for c in cs) / dt / 1e6, 1)}
+            # the same in the reference's adaptive 10..50 spp mode, whose frame ends with a long thin tail (the pixels started last
+            # run their up to 50 samples one after the other): a second frame in flight fills it
+            p_ad = api.default_params(10, SEED, bounce_depth=depth, pipeline=args.pipeline, max_spp=50)
+            def lane_ad(t, n):
+                rr, bb = pair[t]
+                return [rr.render_device(cam, p_ad, width, height, 0, width * height, bb.data_ptr(), True) for _ in range(t, n, 2)]
+            lane_ad(0, 1); lane_ad(1, 2)
+            with ThreadPoolExecutor(max_workers=2) as ex:
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                futs = [ex.submit(lane_ad, t, 4) for t in range(2)]
+                cs = [c for f in futs for c in f.result()]
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t0
+            pipelined["adaptive_10_50"] = {"frames": 4, "ms_per_frame": round(dt * 1e3 / 4, 4), "mrays_per_s": round(sum(c.ray_count for c in cs) / dt / 1e6, 1)}
             r_b.close()
             del buf_b
         except Exception as e:
