@@ -342,6 +342,48 @@ def test_multi_device_handle_gathers_on_the_device_and_matches_one_device():
     assert not lib.prt_multi_create(None, 0)
 
 
+def test_multi_device_handle_on_distinct_gpus():
+    """The same on DISTINCT devices, wherever more than one GPU is visible (a one-GPU box skips it): peer access between different
+    ordinals, peer-to-peer copies into device 0's staging, the cross-device event waits - what the n-device product path is for and
+    what a box with one GPU cannot show."""
+    import torch
+    n_gpus = torch.cuda.device_count()
+    if n_gpus < 2:
+        pytest.skip("one GPU visible")
+    from par_raytracer_amd import api, capi
+    lib = capi.hip_lib()
+    w, h = 150, 83
+    s, hs, cam = _setup("terrain_64", w, h)
+    p, p2 = api.default_params(3, 99), api.default_params(3, 100)
+    r = api.Renderer(0)
+    r.upload(hs)
+    want, wc = r.render(cam, p, w, h)
+    want2, wc2 = r.render(cam, p2, w, h)
+    r.close()
+    for n in sorted({2, min(n_gpus, 8)}):
+        ids = (C.c_int * n)(*range(n))
+        m = lib.prt_multi_create(ids, n)
+        assert m, lib.prt_multi_last_error(None)
+        try:
+            assert lib.prt_multi_upload_scene(m, hs.desc) == 0, lib.prt_multi_last_error(m)
+            out = np.zeros((h * w, 4), dtype=np.float32)
+            ctr = capi.PrtCounters()
+            for _ in range(2):
+                assert lib.prt_multi_render(m, C.byref(cam), C.byref(p), w, h, out.ctypes.data, C.byref(ctr)) == 0, lib.prt_multi_last_error(m)
+                assert ctr.ray_count == wc.ray_count and np.array_equal(out.view(np.uint32), want.view(np.uint32)), n
+            outs = [np.zeros((h * w, 4), dtype=np.float32) for _ in range(2)]
+            tickets = [C.c_uint64(0), C.c_uint64(0)]
+            assert lib.prt_multi_submit(m, C.byref(cam), C.byref(p), w, h, outs[0].ctypes.data, C.byref(tickets[0])) == 0, lib.prt_multi_last_error(m)
+            assert lib.prt_multi_submit(m, C.byref(cam), C.byref(p2), w, h, outs[1].ctypes.data, C.byref(tickets[1])) == 0, lib.prt_multi_last_error(m)
+            c1, c2 = capi.PrtCounters(), capi.PrtCounters()
+            assert lib.prt_multi_wait(m, tickets[1], C.byref(c2)) == 0, lib.prt_multi_last_error(m)
+            assert lib.prt_multi_wait(m, tickets[0], C.byref(c1)) == 0, lib.prt_multi_last_error(m)
+            assert c1.ray_count == wc.ray_count and np.array_equal(outs[0].view(np.uint32), want.view(np.uint32)), n
+            assert c2.ray_count == wc2.ray_count and np.array_equal(outs[1].view(np.uint32), want2.view(np.uint32)), n
+        finally:
+            lib.prt_multi_destroy(m)
+
+
 def test_options_are_set_through_the_abi_not_the_environment(monkeypatch):
     """prt_set_option: the environment is read once, at prt_create; afterwards only the ABI changes a knob.  Unknown names and
     values that do not parse are errors."""
