@@ -130,6 +130,11 @@ struct DevParams {
     // n - 1 - wi would - the bottom of the image first, so that the samples fetched LAST, whose bounce chains are the frame's
     // tail, are the top rows (sky in outdoor scenes: one ray and done).  n, or 0 = off.  Never with a pixel list.
     unsigned int work_reverse_n;
+    // Work order scattered (option WORK_SCATTER, round 4 experiment): the 8-pixel chunks of the tiled region (one wave-load of
+    // 8 spp samples each) are handed out in the order c -> c * mul mod n instead of one after the other, so that what a wave
+    // takes in one top-up - 8 chunks - comes from 8 places of the image and is a mix of cheap and dear pixels, not one 8 x 8
+    // tile of sky or of terrain.  n = chunks in the tiled region (0 = off), mul coprime to n, (n - 1) * mul < 2^32.
+    unsigned int work_scatter_n, work_scatter_mul;
     // 1: a shadow ray whose radiance-if-unoccluded is exactly zero is counted, not traced (kernels_wave.h shade_entry);
     // 0 (PRT_TRACE_DEAD_SHADOW_RAYS): traced like every other one
     unsigned int elide_dead_shadow_rays;
@@ -139,9 +144,11 @@ struct DevParams {
 };
 
 // Work item (position in the order pixels are handed out, whole call) -> local pixel (position in the call's output).
-PRT_HD unsigned int local_of_work(unsigned int wi, unsigned int width, unsigned int tile_pixels, unsigned int reverse_n = 0u) {
+PRT_HD unsigned int local_of_work(unsigned int wi, unsigned int width, unsigned int tile_pixels, unsigned int reverse_n = 0u,
+                                  unsigned int scatter_n = 0u, unsigned int scatter_mul = 1u) {
     if (reverse_n) wi = reverse_n - 1u - wi;
     if (wi >= tile_pixels) return wi;
+    if (scatter_n) wi = (((wi >> 3) * scatter_mul) % scatter_n) * 8u + (wi & 7u);
     const unsigned int band_px = 8u * width;
     const unsigned int b = wi / band_px, q = wi - b * band_px;
     const unsigned int t = q >> 6, i = q & 63u;
@@ -152,7 +159,7 @@ PRT_HD unsigned int local_of_work(unsigned int wi, unsigned int width, unsigned 
 PRT_HD unsigned int pixel_of_local(const DevParams & P, unsigned int lp) {
     lp += P.local_base;                         // this pass's first work item within the call's pixel set
     if (P.pixel_list) return P.pixel_list[lp];
-    lp = local_of_work(lp, P.width, P.tile_pixels, P.work_reverse_n);
+    lp = local_of_work(lp, P.width, P.tile_pixels, P.work_reverse_n, P.work_scatter_n, P.work_scatter_mul);
     if (P.shard_nranks <= 1) return P.first_pixel + lp;
     const unsigned int row = lp / P.width, x = lp - row * P.width;
     const unsigned int blk = row / P.shard_block_rows, r = row - blk * P.shard_block_rows;

@@ -15,8 +15,8 @@ PRT_D f3 load_sample_rgb(const void * sample_rgb, size_t i) {
 }
 
 // Work item p of the pass that starts at work item `base` -> its place in the call's output (dev_scene.h local_of_work).
-struct ResolveMap { unsigned int base, width, tile_pixels, reverse_n; };
-PRT_D size_t resolve_out_index(const ResolveMap & m, unsigned int p) { return local_of_work(m.base + p, m.width, m.tile_pixels, m.reverse_n); }
+struct ResolveMap { unsigned int base, width, tile_pixels, reverse_n, scatter_n, scatter_mul; };
+PRT_D size_t resolve_out_index(const ResolveMap & m, unsigned int p) { return local_of_work(m.base + p, m.width, m.tile_pixels, m.reverse_n, m.scatter_n, m.scatter_mul); }
 
 template <bool FIXED>
 __global__ void k_resolve(const void * sample_rgb, float4 * out_rgba, unsigned int n_pixels, unsigned int spp, ResolveMap map) {

@@ -950,6 +950,17 @@ int render_pixels_once(prt_ctx * ctx, const prt_camera * cam_in, const prt_param
     }
 
     P.work_reverse_n = (opt.work_reverse > 0 && !px.d_pixel_list) ? px.n_pixels : 0u;
+    P.work_scatter_n = 0; P.work_scatter_mul = 1;
+    if (opt.work_scatter > 0 && !px.d_pixel_list && P.tile_pixels >= 64u) {
+        // a multiplier near n / golden ratio spreads consecutive chunks far apart; coprime to n, and (n - 1) * mul must fit 32 bits
+        const unsigned int n = P.tile_pixels / 8u;
+        unsigned long long mul = std::max<unsigned long long>(3ull, (unsigned long long)((double)n * 0.6180339887));
+        mul = std::min<unsigned long long>(mul, 0xFFFFFFFFull / n);
+        if (!(mul & 1ull)) mul -= 1ull;                       // odd, and never above the 32-bit limit
+        auto gcd = [](unsigned long long a, unsigned long long b) { while (b) { const unsigned long long t = a % b; a = b; b = t; } return a; };
+        while (mul > 1ull && gcd(mul, n) != 1ull) mul -= 2ull;
+        if (mul > 1ull) { P.work_scatter_n = n; P.work_scatter_mul = (unsigned int)mul; }
+    }
     const bool count_visits = (params->pipeline & PRT_FLAG_COUNT_VISITS) != 0;
     // the compact 2-register RNG only covers opaque scenes with <= 15 draws per sample; textured scenes always take the
     // general variant (an alpha map can make any hit translucent)
@@ -1182,7 +1193,7 @@ int render_pixels_once(prt_ctx * ctx, const prt_camera * cam_in, const prt_param
         if (single_launch) HIP_TRY(ctx, hipEventRecord(ctx->ev[3], stream));
         // work items of this pass -> their places in the call's output (tiled work order, dev_scene.h local_of_work)
         ResolveMap rmap;
-        rmap.base = p0; rmap.width = P.width; rmap.tile_pixels = P.tile_pixels; rmap.reverse_n = P.work_reverse_n;
+        rmap.base = p0; rmap.width = P.width; rmap.tile_pixels = P.tile_pixels; rmap.reverse_n = P.work_reverse_n; rmap.scatter_n = P.work_scatter_n; rmap.scatter_mul = P.work_scatter_mul;
         if (adaptive)       // k_pool<ADAPT> has already divided by each pixel's own sample count
             hipLaunchKernelGGL(k_resolve<false>, dim3((n_px + 255) / 256), dim3(256), 0, stream,
                                ctx->adapt_f4.p + ((size_t)P.max_spp + 1u) * n_samples, d_out, n_px, 1u, rmap);

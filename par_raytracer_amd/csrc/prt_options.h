@@ -43,6 +43,7 @@ struct PrtOptions {
     long long pool_guided = -1;             // towards the end a wave takes at most this many eighths of its share of what is left (0: off; default: 16 in adaptive mode)
     long long pool_guided_min = -1;         // ... but at least this many units
     long long pool_fair = -1;               // experiment: pool capacity and largest top-up = this many eighths of a wave's fair share of the samples
+    long long work_scatter = 0;             // experiment: hand the 8-pixel chunks of the tiled region out scattered over the image (DevParams::work_scatter_n)
     long long work_reverse = 0;             // experiment: hand the call's pixels out last-to-first (dev_scene.h DevParams::work_reverse_n)
     long long pool_flow = -1;               // pool pipeline without rounds (kernels_flow.h: tracer waves + a shading wave per workgroup); 1 / 0, -1 = the build's default
     long long pool_shared_cap = -1;         // ... slots per WAVE of a shared pool before the x4 (experiments)
@@ -68,7 +69,7 @@ inline const OptEntry * option_table(size_t * n) {
         { "CHAINS", &PrtOptions::chains, nullptr }, { "SHADE_BLOCK", &PrtOptions::shade_block, nullptr },
         { "POOL_BLOCKS_PER_CU", &PrtOptions::pool_blocks_per_cu, nullptr }, { "POOL_CAP", &PrtOptions::pool_cap, nullptr },
         { "POOL_TOPUP", &PrtOptions::pool_topup, nullptr }, { "POOL_MAX_SAMPLES", &PrtOptions::pool_max_samples, nullptr },
-        { "POOL_PARK_CAP", &PrtOptions::pool_park_cap, nullptr }, { "POOL_SHARED", &PrtOptions::pool_shared, nullptr }, { "POOL_FAIR", &PrtOptions::pool_fair, nullptr }, { "POOL_EXCHANGE", &PrtOptions::pool_exchange, nullptr }, { "POOL_GUIDED", &PrtOptions::pool_guided, nullptr }, { "POOL_GUIDED_MIN", &PrtOptions::pool_guided_min, nullptr }, { "POOL_FLOW", &PrtOptions::pool_flow, nullptr }, { "WORK_REVERSE", &PrtOptions::work_reverse, nullptr },
+        { "POOL_PARK_CAP", &PrtOptions::pool_park_cap, nullptr }, { "POOL_SHARED", &PrtOptions::pool_shared, nullptr }, { "POOL_FAIR", &PrtOptions::pool_fair, nullptr }, { "POOL_EXCHANGE", &PrtOptions::pool_exchange, nullptr }, { "POOL_GUIDED", &PrtOptions::pool_guided, nullptr }, { "POOL_GUIDED_MIN", &PrtOptions::pool_guided_min, nullptr }, { "POOL_FLOW", &PrtOptions::pool_flow, nullptr }, { "WORK_REVERSE", &PrtOptions::work_reverse, nullptr }, { "WORK_SCATTER", &PrtOptions::work_scatter, nullptr },
         { "POOL_SHARED_CAP", &PrtOptions::pool_shared_cap, nullptr }, { "PASS_SAMPLES", &PrtOptions::pass_samples, nullptr },
         { "PASS_MB", &PrtOptions::pass_mb, nullptr }, { "STACK_CAP", &PrtOptions::stack_cap, nullptr }, { "NO_TILES", &PrtOptions::no_tiles, nullptr },
         { "RESERVE_CUS", &PrtOptions::reserve_cus, nullptr }, { "RESERVE_PATTERN", &PrtOptions::reserve_pattern, nullptr }, { "LEAF_MAX", &PrtOptions::leaf_max, nullptr },

@@ -523,7 +523,7 @@ def test_the_image_does_not_depend_on_how_the_pools_are_scheduled(scene, light_m
     else:
         p = api.default_params(2, 11, pipeline=PIPELINES["pool"], bounce_depth=7)          # more than 15 draws: the RNG ring in memory
     settings = [{"POOL_SHARED": 0}, {"POOL_SHARED": 1}, {"POOL_SHARED": 0, "POOL_GUIDED": 0}, {"POOL_SHARED": 0, "POOL_GUIDED": 4, "POOL_GUIDED_MIN": 1},
-                {"POOL_SHARED": 0, "POOL_GUIDED": 64, "POOL_GUIDED_MIN": 3}, {"WORK_REVERSE": 1}, {"NO_TILES": 1}, {"POOL_FAIR": 3}, {"POOL_SHARED": 1, "POOL_FAIR": 8},
+                {"POOL_SHARED": 0, "POOL_GUIDED": 64, "POOL_GUIDED_MIN": 3}, {"WORK_REVERSE": 1}, {"WORK_SCATTER": 1}, {"WORK_SCATTER": 1, "WORK_REVERSE": 1, "POOL_SHARED": 1}, {"NO_TILES": 1}, {"POOL_FAIR": 3}, {"POOL_SHARED": 1, "POOL_FAIR": 8},
                 {"POOL_CAP": 64, "POOL_TOPUP": 1}, {"POOL_CAP": 4096, "POOL_TOPUP": 64}, {"KEEP_MIN": 1, "NODE_MIN": 0}, {"KEEP_MIN": 64, "NODE_MIN": 64},
                 {"POOL_BLOCKS_PER_CU": 1}, {"POOL_SHARED": 1, "POOL_SHARED_CAP": 64, "WORK_REVERSE": 1}]
     r = api.Renderer(0)

@@ -41,6 +41,7 @@ def compare(tag, fn, n, pixels):
     for rd in range(rounds):
         for name, v in MODES:
             r.set_option(XOPT, v)
+            buf.zero_()                                        # a pixel this mode does not render must not pass for rendered
             lo, med, c = timed(fn, n)
             torch.cuda.synchronize()
             img = buf.reshape(-1, 4)[:pixels].cpu().numpy().view(np.uint32)

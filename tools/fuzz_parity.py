@@ -20,7 +20,7 @@ fuzz_opts = "opts" in sys.argv[3:]
 # option -> values (prt_options.h clamps what is out of range; every one of these is a legal request)
 OPTS = {"POOL_SHARED": [0, 1], "POOL_SHARED_CAP": [64, 128, 512, 1024], "POOL_GUIDED": [0, 1, 4, 16, 64], "POOL_GUIDED_MIN": [1, 3, 8, 64, 512],
         "POOL_FAIR": [1, 3, 4, 8, 16], "POOL_CAP": [64, 128, 192, 1024, 4096], "POOL_TOPUP": [1, 7, 64, 4096], "POOL_BLOCKS_PER_CU": [1, 2, 8],
-        "KEEP_MIN": [1, 17, 40, 64], "NODE_MIN": [0, 1, 32, 64], "NODE_FRAC": [0, 1, 4, 8], "WORK_REVERSE": [0, 1], "NO_TILES": [0, 1],
+        "KEEP_MIN": [1, 17, 40, 64], "NODE_MIN": [0, 1, 32, 64], "NODE_FRAC": [0, 1, 4, 8], "WORK_REVERSE": [0, 1], "WORK_SCATTER": [0, 1], "NO_TILES": [0, 1],
         "STACK_CAP": [2, 5, 24], "POOL_PARK_CAP": [8, 100000], "PASS_SAMPLES": [97, 4096, 100000], "CHAINS": [1, 2, 4], "SHADE_BLOCK": [256, 1024],
         "TRACE_BLOCKS_PER_CU": [1, 3, 8], "CHUNK_MIN": [64, 512], "POOL_MAX_SAMPLES": [0, 1000, 10000000], "TRACE_DEAD_SHADOW_RAYS": [0, 1]}
 for i in range(n):
